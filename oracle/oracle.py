@@ -1,0 +1,136 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import
+this module; the product package never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libr2s_oracle.so")
+
+
+class OrcGrid(ctypes.Structure):
+    _fields_ = [("amin", ctypes.c_double * 3), ("amax", ctypes.c_double * 3),
+                ("N", ctypes.c_int64 * 3), ("cell", ctypes.c_double), ("ngp", ctypes.c_int64)]
+
+    @property
+    def dims(self):
+        return tuple(int(n) + 1 for n in self.N)
+
+
+class OrcStats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int64) for k in
+                ("n_solid", "n_iso", "n_iso_solves", "n_iso_fail", "n_tri_tests", "n_invmap")]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "r2s_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _mesh(X, IEN):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    IEN = np.ascontiguousarray(IEN, dtype=np.int64)
+    assert X.ndim == 2 and X.shape[1] == 3 and IEN.ndim == 2
+    et = {8: 0, 4: 1}[IEN.shape[1]]
+    return X, IEN, et
+
+
+def grid_make(xmin, xmax, n_max, margin=3):
+    g = OrcGrid()
+    a = (ctypes.c_double * 3)(*xmin)
+    b = (ctypes.c_double * 3)(*xmax)
+    lib().orc_grid_make(a, b, ctypes.c_int64(n_max), ctypes.c_int64(margin), ctypes.byref(g))
+    return g
+
+
+def auto_grid(X, IEN):
+    X, IEN, et = _mesh(X, IEN)
+    g = OrcGrid()
+    med = ctypes.c_double()
+    rc = lib().orc_auto_grid(_d(X), ctypes.c_int64(len(X)), _i(IEN), ctypes.c_int64(len(IEN)), et,
+                             ctypes.byref(g), ctypes.byref(med))
+    assert rc == 0
+    return g, med.value
+
+
+def grid_points(g):
+    pts = np.empty((g.ngp, 3))
+    lib().orc_grid_points(ctypes.byref(g), _d(pts))
+    return pts
+
+
+def dense_in_nodes(X, IEN, rho_e):
+    X, IEN, et = _mesh(X, IEN)
+    rho_e = np.ascontiguousarray(rho_e, dtype=np.float64)
+    out = np.empty(len(X))
+    rc = lib().orc_dense_in_nodes(_d(X), ctypes.c_int64(len(X)), _i(IEN), ctypes.c_int64(len(IEN)),
+                                  et, _d(rho_e), _d(out))
+    assert rc == 0
+    return out
+
+
+def eval_distances(X, IEN, rho_n, rho_t, g, band_factor=1.1, want_xp=True):
+    X, IEN, et = _mesh(X, IEN)
+    rho_n = np.ascontiguousarray(rho_n, dtype=np.float64)
+    dist = np.empty(g.ngp)
+    xp = np.empty((g.ngp, 3)) if want_xp else None
+    st = OrcStats()
+    rc = lib().orc_eval_distances(_d(X), ctypes.c_int64(len(X)), _i(IEN), ctypes.c_int64(len(IEN)), et,
+                                  _d(rho_n), ctypes.c_double(rho_t), ctypes.byref(g),
+                                  ctypes.c_double(band_factor), _d(dist),
+                                  _d(xp) if want_xp else None, ctypes.byref(st))
+    assert rc == 0, rc
+    return dist, xp, {k: getattr(st, k) for k, _ in OrcStats._fields_}
+
+
+def sign_detection(X, IEN, rho_n, rho_t, g, bruteforce=False):
+    X, IEN, et = _mesh(X, IEN)
+    rho_n = np.ascontiguousarray(rho_n, dtype=np.float64)
+    s = np.empty(g.ngp)
+    if bruteforce:
+        rc = lib().orc_sign_detection_bruteforce(_d(X), ctypes.c_int64(len(X)), _i(IEN),
+                                                 ctypes.c_int64(len(IEN)), _d(rho_n),
+                                                 ctypes.c_double(rho_t), ctypes.byref(g), _d(s))
+    else:
+        rc = lib().orc_sign_detection(_d(X), ctypes.c_int64(len(X)), _i(IEN), ctypes.c_int64(len(IEN)),
+                                      et, _d(rho_n), ctypes.c_double(rho_t), ctypes.byref(g), _d(s))
+    assert rc == 0, rc
+    return s
+
+
+def iso_project_hex8(x, Xe, rho_e, rho_t):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    Xe = np.ascontiguousarray(Xe, dtype=np.float64)
+    rho_e = np.ascontiguousarray(rho_e, dtype=np.float64)
+    xi = np.zeros(3)
+    f = lib().orc_iso_project_hex8
+    f.restype = ctypes.c_int
+    it = f(_d(x), _d(Xe), _d(rho_e), ctypes.c_double(rho_t), _d(xi))
+    return xi, it

@@ -1,0 +1,1188 @@
+/*
+ * r2s_oracle.c - CPU restatement of the Rho2sdf.jl hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (rho2sdf.jl_amd/,
+ * include/) may include, link or call this file; only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() use it, as the checker.
+ *
+ * It restates, function by function, what the Julia reference computes
+ * (citations are paths under /root/reference).  Plain scalar C, single
+ * thread, written in the reference's own loop structure (element-major
+ * scatter through the point->cell linked list), which is deliberately NOT
+ * the structure of the HIP kernels (voxel-major gather over tile bins).
+ *
+ * Third-party arithmetic that is absent from /root/reference:
+ *   - NLopt 2.10.0 LD_SLSQP  (ComputeCoordsOnIso.jl:19-86): the constrained
+ *     closest-point problem is restated (objective, constraint, bounds,
+ *     start point) and solved to tight tolerance by the SQP documented at
+ *     iso_project_hex8() below.  PARITY UNPINNED for curved iso-surfaces
+ *     beyond the reference's own known answers (tests/golden) and an
+ *     independent SLSQP (scipy's Kraft SLSQP) cross-check.
+ *   - NLopt LD_LBFGS (FindLocalCoordinates.jl:71-106): bounded inverse
+ *     isoparametric map; restated as a box-clamped Newton iteration.
+ *   - LAPACK eigen / LU: restated as cyclic Jacobi / partial-pivot LU.
+ *
+ * Compile with -ffp-contract=off: every expression that feeds an integer or
+ * boolean decision keeps the reference's operation order and must not be
+ * contracted into FMAs.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BIG 1.0e10
+
+typedef struct {
+    double amin[3];
+    double amax[3];
+    int64_t N[3];
+    double cell;
+    int64_t ngp;
+} orc_grid;
+
+/* ------------------------------------------------------------------ */
+/* Grid  (src/MeshGrid/Grid.jl:10-34)                                  */
+/* ------------------------------------------------------------------ */
+int orc_grid_make(const double xmin[3], const double xmax[3], int64_t n_max,
+                  int64_t margin, orc_grid *g)
+{
+    double ext = xmax[0] - xmin[0];
+    for (int i = 1; i < 3; ++i)
+        if (xmax[i] - xmin[i] > ext) ext = xmax[i] - xmin[i];
+    double cell = ext / (double)n_max;                 /* Grid.jl:17 */
+    double m = (double)margin * cell;
+    g->ngp = 1;
+    for (int i = 0; i < 3; ++i) {
+        double lo = xmin[i] - m;                       /* Grid.jl:20 */
+        double hi = xmax[i] + m;                       /* Grid.jl:21 */
+        g->N[i] = (int64_t)ceil((hi - lo) / cell);     /* Grid.jl:24 */
+        g->amin[i] = lo;
+        g->amax[i] = lo + (double)g->N[i] * cell;      /* Grid.jl:26 */
+        g->ngp *= g->N[i] + 1;                         /* Grid.jl:30 */
+    }
+    g->cell = cell;
+    return 0;
+}
+
+/* grid point i,j,k  (Grid.jl:87: AABB_min .+ cell_size .* [i,j,k]) */
+static inline void grid_point(const orc_grid *g, int64_t i, int64_t j, int64_t k, double p[3])
+{
+    p[0] = g->amin[0] + g->cell * (double)i;
+    p[1] = g->amin[1] + g->cell * (double)j;
+    p[2] = g->amin[2] + g->cell * (double)k;
+}
+
+/* cell index of a coordinate (Grid.jl:58, :134-135): floor(N*(x-min)/(max-min)) */
+static inline double cell_of(const orc_grid *g, int ax, double x)
+{
+    return floor((double)g->N[ax] * (x - g->amin[ax]) / (g->amax[ax] - g->amin[ax]));
+}
+
+void orc_grid_points(const orc_grid *g, double *pts /* 3*ngp */)
+{
+    int64_t a = 0;
+    for (int64_t k = 0; k <= g->N[2]; ++k)
+        for (int64_t j = 0; j <= g->N[1]; ++j)
+            for (int64_t i = 0; i <= g->N[0]; ++i, ++a)
+                grid_point(g, i, j, k, pts + 3 * a);
+}
+
+/* ------------------------------------------------------------------ */
+/* Element tables  (src/ElementTypes/ElementTypes.jl:15-78)            */
+/* ------------------------------------------------------------------ */
+static const int HEX_ISN[6][4] = {{0, 3, 2, 1}, {0, 1, 5, 4}, {1, 2, 6, 5},
+                                  {2, 3, 7, 6}, {3, 0, 4, 7}, {4, 5, 6, 7}};
+static const int TET_ISN[4][3] = {{0, 2, 1}, {0, 1, 3}, {1, 2, 3}, {0, 3, 2}};
+static const int HEX_EDGES[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6},
+                                     {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+static const int TET_EDGES[6][2] = {{0, 1}, {1, 2}, {2, 0}, {0, 3}, {1, 3}, {2, 3}};
+
+/* ------------------------------------------------------------------ */
+/* Shape functions (src/ShapeFunctions/hex8_shape.jl:2-70)             */
+/* ------------------------------------------------------------------ */
+static void hex8_shape(const double xi[3], double N[8])
+{
+    double x1m = xi[0] - 1, x1p = xi[0] + 1, x2m = xi[1] - 1, x2p = xi[1] + 1;
+    double x3m = xi[2] - 1, x3p = xi[2] + 1;
+    double t1 = x1m * x2m, t2 = x1p * x2m, t3 = x1p * x2p, t4 = x1m * x2p;
+    const double c = 0.125;
+    N[0] = -c * t1 * x3m;
+    N[1] = c * t2 * x3m;
+    N[2] = -c * t3 * x3m;
+    N[3] = c * t4 * x3m;
+    N[4] = c * t1 * x3p;
+    N[5] = -c * t2 * x3p;
+    N[6] = c * t3 * x3p;
+    N[7] = -c * t4 * x3p;
+}
+
+static void hex8_shape_d(const double xi[3], double N[8], double dN[8][3])
+{
+    double x1m = xi[0] - 1, x1p = xi[0] + 1, x2m = xi[1] - 1, x2p = xi[1] + 1;
+    double x3m = xi[2] - 1, x3p = xi[2] + 1;
+    double t1 = x1m * x2m, t2 = x1p * x2m, t3 = x1p * x2p, t4 = x1m * x2p;
+    const double c = 0.125;
+    N[0] = -c * t1 * x3m;
+    N[1] = c * t2 * x3m;
+    N[2] = -c * t3 * x3m;
+    N[3] = c * t4 * x3m;
+    N[4] = c * t1 * x3p;
+    N[5] = -c * t2 * x3p;
+    N[6] = c * t3 * x3p;
+    N[7] = -c * t4 * x3p;
+    double d1 = c * x3m, d1p = c * x3p;
+    dN[0][0] = -d1 * x2m;  dN[1][0] = d1 * x2m;   dN[2][0] = -d1 * x2p;  dN[3][0] = d1 * x2p;
+    dN[4][0] = d1p * x2m;  dN[5][0] = -d1p * x2m; dN[6][0] = d1p * x2p;  dN[7][0] = -d1p * x2p;
+    dN[0][1] = -d1 * x1m;  dN[1][1] = d1 * x1p;   dN[2][1] = -d1 * x1p;  dN[3][1] = d1 * x1m;
+    dN[4][1] = d1p * x1m;  dN[5][1] = -d1p * x1p; dN[6][1] = d1p * x1p;  dN[7][1] = -d1p * x1m;
+    dN[0][2] = -c * t1;    dN[1][2] = c * t2;     dN[2][2] = -c * t3;    dN[3][2] = c * t4;
+    dN[4][2] = c * t1;     dN[5][2] = -c * t2;    dN[6][2] = c * t3;     dN[7][2] = -c * t4;
+}
+
+/* mixed second derivatives of the trilinear shape functions (pure ones are 0);
+ * m[k][0] = d2N/dxi1 dxi2, m[k][1] = d2N/dxi1 dxi3, m[k][2] = d2N/dxi2 dxi3 */
+static void hex8_shape_mixed(const double xi[3], double m[8][3])
+{
+    static const double sg[8] = {-1, 1, -1, 1, 1, -1, 1, -1};
+    double x1[2] = {xi[0] - 1, xi[0] + 1}, x2[2] = {xi[1] - 1, xi[1] + 1};
+    double x3[2] = {xi[2] - 1, xi[2] + 1};
+    static const int s1[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+    static const int s2[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+    static const int s3[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    for (int k = 0; k < 8; ++k) {
+        double c = 0.125 * sg[k];
+        m[k][0] = c * x3[s3[k]];
+        m[k][1] = c * x2[s2[k]];
+        m[k][2] = c * x1[s1[k]];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* small dense helpers                                                 */
+/* ------------------------------------------------------------------ */
+static inline double norm3(const double v[3])
+{
+    return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+}
+
+/* n x n LU with partial pivoting (stands in for LAPACK getrf/getrs behind
+ * Julia's `\`); returns 0 on success, 1 if singular. */
+static int lu_solve(int n, double *A /* n*n row-major, destroyed */, double *b)
+{
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        double best = fabs(A[c * n + c]);
+        for (int r = c + 1; r < n; ++r)
+            if (fabs(A[r * n + c]) > best) { best = fabs(A[r * n + c]); p = r; }
+        if (best == 0.0) return 1;
+        if (p != c) {
+            for (int k = 0; k < n; ++k) { double t = A[c * n + k]; A[c * n + k] = A[p * n + k]; A[p * n + k] = t; }
+            double t = b[c]; b[c] = b[p]; b[p] = t;
+        }
+        for (int r = c + 1; r < n; ++r) {
+            double l = A[r * n + c] / A[c * n + c];
+            A[r * n + c] = l;
+            for (int k = c + 1; k < n; ++k) A[r * n + k] -= l * A[c * n + k];
+            b[r] -= l * b[c];
+        }
+    }
+    for (int r = n - 1; r >= 0; --r) {
+        double s = b[r];
+        for (int k = r + 1; k < n; ++k) s -= A[r * n + k] * b[k];
+        b[r] = s / A[r * n + r];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Inverse isoparametric map, HEX8                                     */
+/* (src/SignedDistances/FindLocalCoordinates.jl:16-107)                */
+/*                                                                     */
+/* Reference: min ||Xe N(xi) - x||^2 over the box [-1.1,1.1]^3 with    */
+/* NLopt L-BFGS from 9 starts.  Restated as Newton on Xe N(xi) = x     */
+/* from xi = 0 with every iterate clamped to the same box: a root      */
+/* inside the box is found to machine precision; when the root lies    */
+/* outside the iterate sticks to the box boundary (max|xi| = 1.1),      */
+/* which every caller rejects (thresholds 1.001 / 1.01), exactly as it  */
+/* rejects the reference's boundary minimiser.  Non-convergence returns */
+/* (10,10,10) like the reference's failure path (:106).                */
+/* ------------------------------------------------------------------ */
+#define INV_MAXIT 50
+#define INV_TOL 1e-13
+static int inv_map_hex8(const double Xe[8][3], const double x[3], double xi[3])
+{
+    xi[0] = xi[1] = xi[2] = 0.0;
+    for (int it = 0; it < INV_MAXIT; ++it) {
+        double N[8], dN[8][3], R[3], J[3][3];
+        hex8_shape_d(xi, N, dN);
+        for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < 8; ++k) s += Xe[k][i] * N[k];
+            R[i] = s - x[i];
+            for (int j = 0; j < 3; ++j) {
+                double t = 0.0;
+                for (int k = 0; k < 8; ++k) t += Xe[k][i] * dN[k][j];
+                J[i][j] = t;
+            }
+        }
+        /* delta = -J^{-1} R by the adjugate */
+        double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        double c10 = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+        double c11 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+        double c12 = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+        double c20 = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+        double c21 = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+        double c22 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        double d0 = -(c00 * R[0] + c10 * R[1] + c20 * R[2]) / det;
+        double d1 = -(c01 * R[0] + c11 * R[1] + c21 * R[2]) / det;
+        double d2 = -(c02 * R[0] + c12 * R[1] + c22 * R[2]) / det;
+        double n0 = fmin(fmax(xi[0] + d0, -1.1), 1.1);
+        double n1 = fmin(fmax(xi[1] + d1, -1.1), 1.1);
+        double n2 = fmin(fmax(xi[2] + d2, -1.1), 1.1);
+        double step = fmax(fabs(n0 - xi[0]), fmax(fabs(n1 - xi[1]), fabs(n2 - xi[2])));
+        xi[0] = n0; xi[1] = n1; xi[2] = n2;
+        if (!(step > INV_TOL)) {
+            if (step != step) break; /* NaN: degenerate element */
+            return 1;
+        }
+    }
+    xi[0] = xi[1] = xi[2] = 10.0;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Projection onto the density iso-surface inside one HEX8             */
+/* (src/SignedDistances/ComputeCoordsOnIso.jl:16-87)                   */
+/*                                                                     */
+/*   min_xi ||x - Xe N(xi)||^2  s.t.  N(xi).rho_e = rho_t, -1<=xi<=1    */
+/*   start xi = 0 (ComputeCoordsOnIso.jl:25-26,70,78)                  */
+/*                                                                     */
+/* Reference optimiser: NLopt LD_SLSQP (tolerances 1e-5).  Restated as */
+/* an SQP on the same problem from the same start, converged to 1e-10: */
+/*   - Hessian of the Lagrangian: exact (Gauss-Newton part 2 J^T J plus */
+/*     the mixed second derivatives of the trilinear maps) when that is */
+/*     positive definite, Gauss-Newton otherwise;                       */
+/*   - QP sub-problem (3 unknowns, 1 linear equality, box) solved       */
+/*     exactly: the previous active set is accepted if it satisfies the */
+/*     KKT conditions, otherwise all 27 free/lower/upper patterns are   */
+/*     solved and the primal-feasible one of least QP value is taken    */
+/*     (for a strictly convex QP that is the unique minimiser);         */
+/*   - if the linearised equality cannot be met inside the box the step */
+/*     goes to the box corner that comes closest to meeting it;         */
+/*   - backtracking on the L1 merit f + mu |c|.                         */
+/* ------------------------------------------------------------------ */
+#define ISO_MAXIT 60
+#define ISO_TOL 1e-10
+#define QP_PTOL 1e-12
+
+typedef struct {
+    double f, c;
+} iso_fc;
+
+static inline iso_fc iso_eval_fc(const double x[3], const double Xe[8][3], const double re[8],
+                                 double rt, const double xi[3])
+{
+    double N[8];
+    hex8_shape(xi, N);
+    iso_fc o;
+    double f = 0.0, rho = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < 8; ++k) s += Xe[k][i] * N[k];
+        double r = x[i] - s;
+        f += r * r;
+    }
+    for (int k = 0; k < 8; ++k) rho += re[k] * N[k];
+    o.f = f;
+    o.c = rho - rt;
+    return o;
+}
+
+/* one active-set pattern of the QP; returns 1 if primal feasible */
+static int qp_pattern(int pat, const double H[3][3], const double g[3], const double a[3],
+                      double e, const double lo[3], const double hi[3], double d[3],
+                      double *lam_out, double *q_out, int *kkt_out)
+{
+    int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+    double dB[3], aa[3], b[3], M[3][3];
+    for (int i = 0; i < 3; ++i) dB[i] = (s[i] == 1) ? lo[i] : ((s[i] == 2) ? hi[i] : 0.0);
+    double ep = e;
+    for (int i = 0; i < 3; ++i) {
+        if (s[i]) {
+            ep -= a[i] * dB[i];
+            aa[i] = 0.0;
+            b[i] = 0.0;
+        } else {
+            aa[i] = a[i];
+            double t = -g[i];
+            for (int j = 0; j < 3; ++j)
+                if (s[j]) t -= H[i][j] * dB[j];
+            b[i] = t;
+        }
+        for (int j = 0; j < 3; ++j)
+            M[i][j] = (s[i] || s[j]) ? ((i == j) ? 1.0 : 0.0) : H[i][j];
+    }
+    /* LDL^T of the masked (SPD) matrix */
+    double D0 = M[0][0];
+    double l10 = M[1][0] / D0, l20 = M[2][0] / D0;
+    double D1 = M[1][1] - l10 * M[1][0];
+    double l21 = (M[2][1] - l20 * M[1][0]) / D1;
+    double D2 = M[2][2] - l20 * M[2][0] - l21 * l21 * D1;
+    if (!(D0 > 0.0 && D1 > 0.0 && D2 > 0.0)) return 0;
+    double u[3], v[3];
+    /* forward */
+    u[0] = aa[0]; u[1] = aa[1] - l10 * u[0]; u[2] = aa[2] - l20 * u[0] - l21 * u[1];
+    v[0] = b[0];  v[1] = b[1] - l10 * v[0];  v[2] = b[2] - l20 * v[0] - l21 * v[1];
+    /* diagonal + backward */
+    u[2] = u[2] / D2; u[1] = u[1] / D1 - l21 * u[2]; u[0] = u[0] / D0 - l10 * u[1] - l20 * u[2];
+    v[2] = v[2] / D2; v[1] = v[1] / D1 - l21 * v[2]; v[0] = v[0] / D0 - l10 * v[1] - l20 * v[2];
+    double den = aa[0] * u[0] + aa[1] * u[1] + aa[2] * u[2];
+    if (!(den > 0.0)) return 0;
+    double lam = (aa[0] * v[0] + aa[1] * v[1] + aa[2] * v[2] - ep) / den;
+    int ok = 1;
+    for (int i = 0; i < 3; ++i) {
+        if (s[i]) {
+            d[i] = dB[i];
+        } else {
+            d[i] = v[i] - lam * u[i];
+            if (!(d[i] >= lo[i] - QP_PTOL && d[i] <= hi[i] + QP_PTOL)) ok = 0;
+        }
+    }
+    if (!ok) return 0;
+    double Hd[3], q = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        Hd[i] = H[i][0] * d[0] + H[i][1] * d[1] + H[i][2] * d[2];
+        q += d[i] * (0.5 * Hd[i] + g[i]);
+    }
+    int kkt = 1;
+    for (int i = 0; i < 3; ++i) {
+        if (s[i]) {
+            double z = Hd[i] + g[i] + lam * a[i];
+            if (s[i] == 1 && !(z >= 0.0)) kkt = 0;
+            if (s[i] == 2 && !(z <= 0.0)) kkt = 0;
+        }
+    }
+    *lam_out = lam;
+    *q_out = q;
+    *kkt_out = kkt;
+    return 1;
+}
+
+static int spd3(const double H[3][3], double floor_)
+{
+    double D0 = H[0][0];
+    if (!(D0 > floor_)) return 0;
+    double l10 = H[1][0] / D0, l20 = H[2][0] / D0;
+    double D1 = H[1][1] - l10 * H[1][0];
+    if (!(D1 > floor_)) return 0;
+    double l21 = (H[2][1] - l20 * H[1][0]) / D1;
+    double D2 = H[2][2] - l20 * H[2][0] - l21 * l21 * D1;
+    return D2 > floor_;
+}
+
+/* returns number of iterations used (ISO_MAXIT+1 if not converged) */
+int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, const double re[8],
+                         double rt, double xi[3])
+{
+    const double(*Xe)[3] = (const double(*)[3])Xe_flat;
+    xi[0] = xi[1] = xi[2] = 0.0;
+    double mu = 0.0, lam = 0.0, Delta = 2.0;
+    int pat = 0;
+    for (int it = 0; it < ISO_MAXIT; ++it) {
+        double N[8], dN[8][3], m2[8][3], r[3], J[3][3], a[3], g[3], G[3][3];
+        hex8_shape_d(xi, N, dN);
+        double f = 0.0, rho = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < 8; ++k) s += Xe[k][i] * N[k];
+            r[i] = x[i] - s;
+            f += r[i] * r[i];
+            for (int j = 0; j < 3; ++j) {
+                double t = 0.0;
+                for (int k = 0; k < 8; ++k) t += Xe[k][i] * dN[k][j];
+                J[i][j] = t;
+            }
+        }
+        for (int k = 0; k < 8; ++k) rho += re[k] * N[k];
+        double c = rho - rt;
+        for (int j = 0; j < 3; ++j) {
+            double t = 0.0;
+            for (int k = 0; k < 8; ++k) t += re[k] * dN[k][j];
+            a[j] = t;
+            g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
+        }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                G[i][j] = 2.0 * (J[0][i] * J[0][j] + J[1][i] * J[1][j] + J[2][i] * J[2][j]);
+        /* multiplier estimate for the Hessian: least squares over the variables
+         * that were free in the last QP solution */
+        {
+            double num = 0.0, den = 0.0;
+            int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+            for (int i = 0; i < 3; ++i)
+                if (!s[i]) { num += a[i] * g[i]; den += a[i] * a[i]; }
+            lam = (den > 0.0) ? -num / den : 0.0;
+        }
+        /* second-order part: S_jl = -2 sum_i r_i d2p_i/djdl + lam d2rho/djdl */
+        hex8_shape_mixed(xi, m2);
+        double S[3]; /* (0,1) (0,2) (1,2) */
+        for (int q = 0; q < 3; ++q) {
+            double pr = 0.0, rr = 0.0;
+            for (int k = 0; k < 8; ++k) {
+                pr += (r[0] * Xe[k][0] + r[1] * Xe[k][1] + r[2] * Xe[k][2]) * m2[k][q];
+                rr += re[k] * m2[k][q];
+            }
+            S[q] = -2.0 * pr + lam * rr;
+        }
+        double lo[3], hi[3], d[3];
+        for (int i = 0; i < 3; ++i) {
+            lo[i] = fmax(-1.0 - xi[i], -Delta);
+            hi[i] = fmin(1.0 - xi[i], Delta);
+        }
+        double e = -c, mplus = 0.0, mminus = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            double p = a[i] * lo[i], q = a[i] * hi[i];
+            mplus += fmax(p, q);
+            mminus += fmin(p, q);
+        }
+        double trG = G[0][0] + G[1][1] + G[2][2];
+        double aa2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+        double sigma = 100.0 * trG / aa2;
+        int use_exact = 1, corner, stop = 0;
+        double lam_new, alpha;
+        for (;;) {
+            corner = 0;
+            lam_new = lam;
+            if (e >= mplus) {
+                for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
+                corner = 1;
+            } else if (e <= mminus) {
+                for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
+                corner = 1;
+            } else {
+                /* convexified QP data: H' = H + sigma a a^T, g' = g - sigma e a
+                 * (identical to (H,g) on the plane a.d = e) */
+                double H[3][3], gp[3];
+                for (int i = 0; i < 3; ++i) {
+                    for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
+                    gp[i] = g[i] - sigma * e * a[i];
+                }
+                if (use_exact) {
+                    H[0][1] += S[0]; H[1][0] += S[0];
+                    H[0][2] += S[1]; H[2][0] += S[1];
+                    H[1][2] += S[2]; H[2][1] += S[2];
+                }
+                double q, dd[3], l2;
+                int kkt, found = 0;
+                if (qp_pattern(pat, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt) && kkt) {
+                    found = 1;
+                    d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
+                    lam_new = l2;
+                } else {
+                    double bestq = INFINITY;
+                    for (int p = 0; p < 27; ++p) {
+                        if (qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt) && q < bestq) {
+                            bestq = q;
+                            found = 1;
+                            pat = p;
+                            d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
+                            lam_new = l2;
+                        }
+                    }
+                }
+                if (!found) {
+                    if (use_exact) { use_exact = 0; continue; }
+                    /* numerically degenerate: corner move towards feasibility */
+                    for (int i = 0; i < 3; ++i)
+                        d[i] = (e > 0.0) ? ((a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0))
+                                         : ((a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0));
+                    corner = 1;
+                }
+                for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
+            }
+            double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+            alpha = 1.0;
+            if (!(dmax > ISO_TOL)) { /* converged (or stuck at an infeasible corner) */
+                stop = corner ? 2 : 1;
+                break;
+            }
+            double ad = a[0] * d[0] + a[1] * d[1] + a[2] * d[2];
+            double pred_c = fabs(c) - fabs(c + ad);
+            double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+            double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
+            if (!(gd - mu_t * pred_c < 0.0)) {
+                if (pred_c > 0.0) {
+                    mu_t = 2.0 * gd / pred_c;
+                } else if (use_exact && !corner) {
+                    use_exact = 0;
+                    continue;
+                } else {
+                    stop = 2;
+                    break;
+                }
+            }
+            mu = mu_t;
+            double D = gd - mu * pred_c;
+            double phi0 = f + mu * fabs(c);
+            for (int ls = 0; ls < 30; ++ls) {
+                double xt[3];
+                for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
+                iso_fc t = iso_eval_fc(x, Xe, re, rt, xt);
+                if (t.f + mu * fabs(t.c) <= phi0 + 1e-4 * alpha * D) break;
+                alpha *= 0.5;
+            }
+            break;
+        }
+        {
+            double dm = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+            Delta = (alpha < 1.0) ? alpha * dm : fmin(2.0, fmax(Delta, 2.0 * dm));
+        }
+#ifdef ISO_DEBUG
+        printf("it %d xi %.6f %.6f %.6f f %.3e c %.3e d %.3e %.3e %.3e alpha %.3e pat %d corner %d ex %d lam %.3e mu %.3e\n",
+               it, xi[0], xi[1], xi[2], f, c, d[0], d[1], d[2], alpha, pat, corner, use_exact, lam, mu);
+#endif
+        if (stop == 2) return ISO_MAXIT + 1;
+        for (int i = 0; i < 3; ++i) xi[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
+        if (stop == 1) return it + 1;
+    }
+    return ISO_MAXIT + 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* Mesh helpers                                                        */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    const double *X;    /* [nnp][3]  (Julia 3 x nnp column-major)        */
+    const int64_t *IEN; /* [nel][nen] 1-based (Julia nen x nel)          */
+    int64_t nnp, nel;
+    int nen, nes, nsn;
+    int elem_type; /* 0 = HEX8, 1 = TET4 */
+    /* node -> elements CSR (MeshInformations.jl:69-77), ascending element order */
+    int64_t *ine_ptr;
+    int64_t *ine;
+} orc_mesh;
+
+static int mesh_init(orc_mesh *m, const double *X, int64_t nnp, const int64_t *IEN, int64_t nel,
+                     int elem_type)
+{
+    m->X = X; m->IEN = IEN; m->nnp = nnp; m->nel = nel; m->elem_type = elem_type;
+    if (elem_type == 0) { m->nen = 8; m->nes = 6; m->nsn = 4; }
+    else { m->nen = 4; m->nes = 4; m->nsn = 3; }
+    m->ine_ptr = (int64_t *)calloc((size_t)nnp + 1, sizeof(int64_t));
+    for (int64_t e = 0; e < nel; ++e)
+        for (int a = 0; a < m->nen; ++a) {
+            int64_t n = IEN[e * m->nen + a] - 1;
+            if (n < 0 || n >= nnp) return -1;
+            m->ine_ptr[n + 1]++;
+        }
+    for (int64_t n = 0; n < nnp; ++n) m->ine_ptr[n + 1] += m->ine_ptr[n];
+    m->ine = (int64_t *)malloc(sizeof(int64_t) * (size_t)m->ine_ptr[nnp]);
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)nnp);
+    memcpy(cur, m->ine_ptr, sizeof(int64_t) * (size_t)nnp);
+    for (int64_t e = 0; e < nel; ++e)
+        for (int a = 0; a < m->nen; ++a) {
+            int64_t n = IEN[e * m->nen + a] - 1;
+            m->ine[cur[n]++] = e;
+        }
+    free(cur);
+    return 0;
+}
+static void mesh_free(orc_mesh *m) { free(m->ine_ptr); free(m->ine); }
+
+static inline int face_node(const orc_mesh *m, int sg, int a)
+{
+    return m->elem_type == 0 ? HEX_ISN[sg][a] : TET_ISN[sg][a];
+}
+
+/* boundary test of sdfOnDensityField.jl:511-519: intersect the node->element
+ * lists of the face nodes; boundary <=> exactly one common element */
+static int face_is_boundary(const orc_mesh *m, int64_t el, int sg)
+{
+    int64_t n0 = m->IEN[el * m->nen + face_node(m, sg, 0)] - 1;
+    int count = 0;
+    for (int64_t p = m->ine_ptr[n0]; p < m->ine_ptr[n0 + 1]; ++p) {
+        int64_t e = m->ine[p];
+        int all = 1;
+        for (int a = 1; a < m->nsn && all; ++a) {
+            int64_t na = m->IEN[el * m->nen + face_node(m, sg, a)] - 1;
+            int found = 0;
+            for (int64_t q = m->ine_ptr[na]; q < m->ine_ptr[na + 1]; ++q)
+                if (m->ine[q] == e) { found = 1; break; }
+            all = found;
+        }
+        count += all;
+    }
+    return count == 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* evalDistances (src/SignedDistances/sdfOnDensityField.jl:139-486)    */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    const orc_grid *g;
+    int64_t *head, *next;
+    double *dist; /* running |dist_local| (sdfOnDensityField.jl:183: -1e10 -> abs) */
+    double *xp;   /* [ngp][3] */
+    double delta;
+    /* statistics */
+    int64_t n_iso_solves, n_iso_fail, n_tri_tests, n_invmap;
+} dist_ctx;
+
+/* mini AABB of a point set, as cell index ranges (Grid.jl:122-154) */
+static void mini_aabb(const orc_grid *g, const double (*P)[3], int np, double delta,
+                      int64_t Imin[3], int64_t Imax[3])
+{
+    for (int ax = 0; ax < 3; ++ax) {
+        double mn = P[0][ax], mx = P[0][ax];
+        for (int k = 1; k < np; ++k) {
+            if (P[k][ax] < mn) mn = P[k][ax];
+            if (P[k][ax] > mx) mx = P[k][ax];
+        }
+        double lo = cell_of(g, ax, mn - delta);
+        double hi = cell_of(g, ax, mx + delta);
+        if (lo < 0) lo = 0;
+        if (hi >= (double)g->N[ax]) hi = (double)g->N[ax];
+        Imin[ax] = (int64_t)lo;
+        Imax[ax] = (int64_t)hi;
+    }
+}
+
+/* WriteValue (sdfOnDensityField.jl:44-57) / update_distance_parallel! (:121-136) */
+static inline int write_value(dist_ctx *c, int64_t v, double d, const double xp[3])
+{
+    if (fabs(d) < c->dist[v]) {
+        c->dist[v] = d;
+        c->xp[3 * v] = xp[0]; c->xp[3 * v + 1] = xp[1]; c->xp[3 * v + 2] = xp[2];
+        return 1;
+    }
+    return 0;
+}
+
+/* IsProjectedOnFullSegment, HEX8 branch (sdfOnDensityField.jl:78-119) */
+static int projected_on_full_segment_hex8(dist_ctx *c, const double Xe[8][3], const double re[8],
+                                          double rt, const double xp[3], const double x[3], int64_t v)
+{
+    double xi[3], N[8];
+    inv_map_hex8(Xe, xp, xi);
+    c->n_invmap++;
+    double m = fmax(fabs(xi[0]), fmax(fabs(xi[1]), fabs(xi[2])));
+    if (m < 1.001) {
+        hex8_shape(xi, N);
+        double rho = 0.0;
+        for (int k = 0; k < 8; ++k) rho += N[k] * re[k];
+        if (rho >= rt) {
+            double dv[3] = {x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]};
+            write_value(c, v, norm3(dv), xp);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* barycentricCoordinates (src/SignedDistances/TriangularMeshUtils.jl:1-24) */
+static void barycentric(const double x1[3], const double x2[3], const double x3[3],
+                        const double n[3], const double x[3], double lam[3])
+{
+    double A[9] = {
+        x1[1] * n[2] - x1[2] * n[1], x2[1] * n[2] - x2[2] * n[1], x3[1] * n[2] - x3[2] * n[1],
+        x1[2] * n[0] - x1[0] * n[2], x2[2] * n[0] - x2[0] * n[2], x3[2] * n[0] - x3[0] * n[2],
+        x1[0] * n[1] - x1[1] * n[0], x2[0] * n[1] - x2[1] * n[0], x3[0] * n[1] - x3[1] * n[0]};
+    double b[3] = {x[1] * n[2] - x[2] * n[1], x[2] * n[0] - x[0] * n[2], x[0] * n[1] - x[1] * n[0]};
+    int im = 0;
+    double nm = fabs(n[0]);
+    if (fabs(n[1]) > nm) { nm = fabs(n[1]); im = 1; }
+    if (fabs(n[2]) > nm) { nm = fabs(n[2]); im = 2; }
+    A[3 * im] = 1.0; A[3 * im + 1] = 1.0; A[3 * im + 2] = 1.0;
+    b[im] = 1.0;
+    if (lu_solve(3, A, b)) { b[0] = b[1] = b[2] = NAN; }
+    lam[0] = b[0]; lam[1] = b[1]; lam[2] = b[2];
+}
+
+/* process_triangle_projection! (sdfOnDensityField.jl:628-815), HEX8 validation */
+static void process_triangle(dist_ctx *c, const double Xt[3][3], int is_solid,
+                             const double Xe[8][3], const double re[8], double rt)
+{
+    const orc_grid *g = c->g;
+    double Et[3][3], n[3];
+    for (int i = 0; i < 3; ++i) {
+        Et[0][i] = Xt[1][i] - Xt[0][i];
+        Et[1][i] = Xt[2][i] - Xt[1][i];
+        Et[2][i] = Xt[0][i] - Xt[2][i];
+    }
+    n[0] = Et[0][1] * Et[1][2] - Et[0][2] * Et[1][1];
+    n[1] = Et[0][2] * Et[1][0] - Et[0][0] * Et[1][2];
+    n[2] = Et[0][0] * Et[1][1] - Et[0][1] * Et[1][0];
+    double nn = norm3(n);
+    n[0] /= nn; n[1] /= nn; n[2] /= nn;
+    int64_t Imin[3], Imax[3];
+    mini_aabb(g, Xt, 3, c->delta, Imin, Imax);
+    for (int64_t I3 = Imin[2]; I3 <= Imax[2]; ++I3)
+      for (int64_t I2 = Imin[1]; I2 <= Imax[1]; ++I2)
+        for (int64_t I1 = Imin[0]; I1 <= Imax[0]; ++I1) {
+            int64_t ii = I3 * (g->N[0] + 1) * (g->N[1] + 1) + I2 * (g->N[0] + 1) + I1;
+            for (int64_t v = c->head[ii]; v != -1; v = c->next[v]) {
+                int64_t vi = v % (g->N[0] + 1), vj = (v / (g->N[0] + 1)) % (g->N[1] + 1);
+                int64_t vk = v / ((g->N[0] + 1) * (g->N[1] + 1));
+                double x[3], lam[3], xp[3], dv[3];
+                grid_point(g, vi, vj, vk, x);
+                c->n_tri_tests++;
+                barycentric(Xt[0], Xt[1], Xt[2], n, x, lam);
+                int ok = 0;
+                double lmin = lam[0];
+                /* Julia minimum(): NaN-propagating */
+                if (lam[1] < lmin || lam[1] != lam[1]) lmin = lam[1];
+                if (lam[2] < lmin || lam[2] != lam[2]) lmin = lam[2];
+                if (lam[0] != lam[0]) lmin = lam[0];
+                if (lmin >= 0.0) {
+                    for (int i = 0; i < 3; ++i)
+                        xp[i] = lam[0] * Xt[0][i] + lam[1] * Xt[1][i] + lam[2] * Xt[2][i];
+                    for (int i = 0; i < 3; ++i) dv[i] = x[i] - xp[i];
+                    double d = norm3(dv);
+                    if (is_solid) ok = write_value(c, v, d, xp);
+                    else ok = projected_on_full_segment_hex8(c, Xe, re, rt, xp, x, v);
+                } else {
+                    for (int j = 0; j < 3; ++j) {
+                        double L = norm3(Et[j]);
+                        double eh[3] = {Et[j][0] / L, Et[j][1] / L, Et[j][2] / L};
+                        double P = (x[0] - Xt[j][0]) * eh[0] + (x[1] - Xt[j][1]) * eh[1] +
+                                   (x[2] - Xt[j][2]) * eh[2];
+                        if (P >= 0 && P <= L) {
+                            for (int i = 0; i < 3; ++i) xp[i] = Xt[j][i] + eh[i] * P;
+                            for (int i = 0; i < 3; ++i) dv[i] = x[i] - xp[i];
+                            double d = norm3(dv);
+                            if (is_solid) ok = write_value(c, v, d, xp);
+                            else ok = projected_on_full_segment_hex8(c, Xe, re, rt, xp, x, v);
+                            if (ok) break;
+                        }
+                    }
+                }
+                if (!ok) {
+                    double dd[3];
+                    for (int j = 0; j < 3; ++j) {
+                        for (int i = 0; i < 3; ++i) dv[i] = x[i] - Xt[j][i];
+                        dd[j] = norm3(dv);
+                    }
+                    int idx = 0; /* findmin: first minimum, NaN wins */
+                    for (int j = 1; j < 3; ++j)
+                        if (dd[j] < dd[idx] || (dd[j] != dd[j] && dd[idx] == dd[idx])) idx = j;
+                    for (int i = 0; i < 3; ++i) xp[i] = Xt[idx][i];
+                    if (is_solid) write_value(c, v, dd[idx], xp);
+                    else projected_on_full_segment_hex8(c, Xe, re, rt, xp, x, v);
+                }
+            }
+        }
+}
+
+/* process_boundary_faces! (sdfOnDensityField.jl:489-558) */
+static void process_boundary_faces(dist_ctx *c, const orc_mesh *m, int64_t el, int is_solid,
+                                   const double Xe[8][3], const double re[8], double rt)
+{
+    for (int sg = 0; sg < m->nes; ++sg) {
+        if (!face_is_boundary(m, el, sg)) continue;
+        double Xs[4][3], Xc[3];
+        for (int a = 0; a < m->nsn; ++a)
+            for (int i = 0; i < 3; ++i) Xs[a][i] = Xe[face_node(m, sg, a)][i];
+        for (int i = 0; i < 3; ++i) {
+            double s = Xs[0][i];
+            for (int a = 1; a < m->nsn; ++a) s += Xs[a][i];
+            Xc[i] = s / (double)m->nsn;
+        }
+        for (int a = 0; a < m->nsn; ++a) {
+            double Xt[3][3];
+            int b = (a + 1) % m->nsn;
+            for (int i = 0; i < 3; ++i) { Xt[0][i] = Xs[a][i]; Xt[1][i] = Xs[b][i]; Xt[2][i] = Xc[i]; }
+            process_triangle(c, Xt, is_solid, Xe, re, rt);
+        }
+    }
+}
+
+typedef struct {
+    int64_t n_solid, n_iso, n_iso_solves, n_iso_fail, n_tri_tests, n_invmap;
+} orc_stats;
+
+int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int elem_type,
+                       const double *rho_n, double rho_t, const orc_grid *g, double band_factor,
+                       double *dist_out, double *xp_out, orc_stats *stats)
+{
+    if (elem_type != 0) return -2; /* TET4: see orc_eval_distances_tet4 */
+    orc_mesh m;
+    if (mesh_init(&m, X, nnp, IEN, nel, elem_type)) return -1;
+    int64_t ngp = g->ngp;
+    dist_ctx c;
+    memset(&c, 0, sizeof c);
+    c.g = g;
+    c.delta = band_factor * g->cell; /* sdfOnDensityField.jl:158 */
+    c.head = (int64_t *)malloc(sizeof(int64_t) * (size_t)ngp);
+    c.next = (int64_t *)malloc(sizeof(int64_t) * (size_t)ngp);
+    c.dist = dist_out;
+    c.xp = xp_out ? xp_out : (double *)calloc((size_t)ngp * 3, sizeof(double));
+    for (int64_t i = 0; i < ngp; ++i) { c.head[i] = -1; c.next[i] = -1; c.dist[i] = BIG; }
+    if (xp_out) memset(xp_out, 0, sizeof(double) * 3 * (size_t)ngp);
+    /* LinkedList (Grid.jl:47-68) */
+    {
+        int64_t v = 0;
+        for (int64_t k = 0; k <= g->N[2]; ++k)
+          for (int64_t j = 0; j <= g->N[1]; ++j)
+            for (int64_t i = 0; i <= g->N[0]; ++i, ++v) {
+                double p[3];
+                grid_point(g, i, j, k, p);
+                double I1 = cell_of(g, 0, p[0]), I2 = cell_of(g, 1, p[1]), I3 = cell_of(g, 2, p[2]);
+                int64_t Ia = (int64_t)(I3 * (double)(g->N[0] + 1) * (double)(g->N[1] + 1) +
+                                       I2 * (double)(g->N[0] + 1) + I1);
+                c.next[v] = c.head[Ia];
+                c.head[Ia] = v;
+            }
+    }
+    int64_t n_solid = 0, n_iso = 0;
+    for (int64_t el = 0; el < nel; ++el) {
+        double Xe[8][3], re[8];
+        double rmin = INFINITY, rmax = -INFINITY;
+        for (int a = 0; a < 8; ++a) {
+            int64_t n = IEN[el * 8 + a] - 1;
+            for (int i = 0; i < 3; ++i) Xe[a][i] = X[3 * n + i];
+            re[a] = rho_n[n];
+            if (re[a] < rmin) rmin = re[a];
+            if (re[a] > rmax) rmax = re[a];
+        }
+        if (rmin >= rho_t) { /* :201 */
+            n_solid++;
+            process_boundary_faces(&c, &m, el, 1, Xe, re, rho_t);
+        } else if (rmax > rho_t) { /* :312 */
+            n_iso++;
+            process_boundary_faces(&c, &m, el, 0, Xe, re, rho_t); /* :584-603 */
+            int64_t Imin[3], Imax[3];
+            mini_aabb(g, Xe, 8, c.delta, Imin, Imax); /* :606 */
+            for (int64_t I3 = Imin[2]; I3 <= Imax[2]; ++I3)
+              for (int64_t I2 = Imin[1]; I2 <= Imax[1]; ++I2)
+                for (int64_t I1 = Imin[0]; I1 <= Imax[0]; ++I1) {
+                    int64_t ii = I3 * (g->N[0] + 1) * (g->N[1] + 1) + I2 * (g->N[0] + 1) + I1;
+                    for (int64_t v = c.head[ii]; v != -1; v = c.next[v]) {
+                        int64_t vi = v % (g->N[0] + 1), vj = (v / (g->N[0] + 1)) % (g->N[1] + 1);
+                        int64_t vk = v / ((g->N[0] + 1) * (g->N[1] + 1));
+                        double x[3], xi[3], N[8], xp[3], dv[3];
+                        grid_point(g, vi, vj, vk, x);
+                        int it = orc_iso_project_hex8(x, &Xe[0][0], re, rho_t, xi); /* :616 */
+                        c.n_iso_solves++;
+                        if (it > ISO_MAXIT) c.n_iso_fail++;
+                        hex8_shape(xi, N);
+                        for (int i = 0; i < 3; ++i) {
+                            double s = 0.0;
+                            for (int k = 0; k < 8; ++k) s += Xe[k][i] * N[k];
+                            xp[i] = s;
+                            dv[i] = x[i] - s;
+                        }
+                        write_value(&c, v, norm3(dv), xp); /* :617-621 */
+                    }
+                }
+        }
+    }
+    if (stats) {
+        stats->n_solid = n_solid; stats->n_iso = n_iso;
+        stats->n_iso_solves = c.n_iso_solves; stats->n_iso_fail = c.n_iso_fail;
+        stats->n_tri_tests = c.n_tri_tests; stats->n_invmap = c.n_invmap;
+    }
+    free(c.head); free(c.next);
+    if (!xp_out) free(c.xp);
+    mesh_free(&m);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Sign_Detection_HEX8 (src/SignedDistances/SignDetection.jl:6-81)     */
+/* ------------------------------------------------------------------ */
+static void elem_gather_hex8(const double *X, const int64_t *IEN, const double *rho_n, int64_t el,
+                             double Xe[8][3], double re[8], double mn[3], double mx[3], double *rmax)
+{
+    *rmax = -INFINITY;
+    for (int a = 0; a < 8; ++a) {
+        int64_t n = IEN[el * 8 + a] - 1;
+        for (int i = 0; i < 3; ++i) {
+            Xe[a][i] = X[3 * n + i];
+            if (a == 0 || Xe[a][i] < mn[i]) mn[i] = Xe[a][i];
+            if (a == 0 || Xe[a][i] > mx[i]) mx[i] = Xe[a][i];
+        }
+        re[a] = rho_n[n];
+        if (re[a] > *rmax) *rmax = re[a];
+    }
+}
+
+/* per-voxel state machine of SignDetection.jl:41-70 for one candidate element */
+static inline void sign_visit(const double Xe[8][3], const double re[8], double rt, const double x[3],
+                              double *max_local, double *sign, int *done)
+{
+    double xi[3], N[8];
+    inv_map_hex8(Xe, x, xi);
+    double m = fmax(fabs(xi[0]), fmax(fabs(xi[1]), fabs(xi[2])));
+    if (m < 1.01 && *max_local > m) {
+        hex8_shape(xi, N);
+        double rho = 0.0;
+        for (int k = 0; k < 8; ++k) rho += N[k] * re[k];
+        if (rho >= rt) *sign = 1.0;
+        if (m < 0.95) *done = 1;
+        else *max_local = m;
+    }
+}
+
+/* literal O(ngp*nel) form: per voxel, ascending candidate elements (:27-70) */
+int orc_sign_detection_bruteforce(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel,
+                                  const double *rho_n, double rho_t, const orc_grid *g, double *signs)
+{
+    (void)nnp;
+    double *mn = (double *)malloc(sizeof(double) * 3 * (size_t)nel);
+    double *mx = (double *)malloc(sizeof(double) * 3 * (size_t)nel);
+    double *rm = (double *)malloc(sizeof(double) * (size_t)nel);
+    for (int64_t el = 0; el < nel; ++el) {
+        double Xe[8][3], re[8];
+        elem_gather_hex8(X, IEN, rho_n, el, Xe, re, mn + 3 * el, mx + 3 * el, rm + el);
+    }
+    int64_t v = 0;
+    for (int64_t k = 0; k <= g->N[2]; ++k)
+      for (int64_t j = 0; j <= g->N[1]; ++j)
+        for (int64_t i = 0; i <= g->N[0]; ++i, ++v) {
+            double x[3];
+            grid_point(g, i, j, k, x);
+            signs[v] = -1.0;
+            int any = 0;
+            double cmax = -INFINITY;
+            for (int64_t el = 0; el < nel; ++el) {
+                const double *a = mn + 3 * el, *b = mx + 3 * el;
+                if (a[0] <= x[0] && a[1] <= x[1] && a[2] <= x[2] && x[0] <= b[0] && x[1] <= b[1] && x[2] <= b[2]) {
+                    any = 1;
+                    if (rm[el] > cmax) cmax = rm[el];
+                }
+            }
+            if (!any || cmax < rho_t) continue; /* :36 */
+            double max_local = 10.0;
+            int done = 0;
+            for (int64_t el = 0; el < nel && !done; ++el) {
+                const double *a = mn + 3 * el, *b = mx + 3 * el;
+                if (!(a[0] <= x[0] && a[1] <= x[1] && a[2] <= x[2] && x[0] <= b[0] && x[1] <= b[1] && x[2] <= b[2]))
+                    continue;
+                double Xe[8][3], re[8], t1[3], t2[3], t3;
+                elem_gather_hex8(X, IEN, rho_n, el, Xe, re, t1, t2, &t3);
+                sign_visit(Xe, re, rho_t, x, &max_local, &signs[v], &done);
+            }
+        }
+    free(mn); free(mx); free(rm);
+    return 0;
+}
+
+/* same result, element-major traversal (candidates still met in ascending
+ * element order by every voxel); used for anything but tiny grids */
+int orc_sign_detection(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int elem_type,
+                       const double *rho_n, double rho_t, const orc_grid *g, double *signs)
+{
+    (void)nnp;
+    if (elem_type != 0) return -2;
+    int64_t ngp = g->ngp, nx = g->N[0] + 1, ny = g->N[1] + 1;
+    double *cmax = (double *)malloc(sizeof(double) * (size_t)ngp);
+    double *mloc = (double *)malloc(sizeof(double) * (size_t)ngp);
+    unsigned char *flag = (unsigned char *)calloc((size_t)ngp, 1); /* bit0 any, bit1 done */
+    for (int64_t v = 0; v < ngp; ++v) { signs[v] = -1.0; cmax[v] = -INFINITY; mloc[v] = 10.0; }
+    for (int pass = 0; pass < 2; ++pass)
+        for (int64_t el = 0; el < nel; ++el) {
+            double Xe[8][3], re[8], mn[3], mx[3], rmax;
+            elem_gather_hex8(X, IEN, rho_n, el, Xe, re, mn, mx, &rmax);
+            int64_t lo[3], hi[3];
+            for (int ax = 0; ax < 3; ++ax) { /* conservative lattice range; exact test below */
+                double a = floor((mn[ax] - g->amin[ax]) / g->cell) - 1.0;
+                double b = ceil((mx[ax] - g->amin[ax]) / g->cell) + 1.0;
+                if (a < 0) a = 0;
+                if (b > (double)g->N[ax]) b = (double)g->N[ax];
+                lo[ax] = (int64_t)a; hi[ax] = (int64_t)b;
+            }
+            for (int64_t k = lo[2]; k <= hi[2]; ++k)
+              for (int64_t j = lo[1]; j <= hi[1]; ++j)
+                for (int64_t i = lo[0]; i <= hi[0]; ++i) {
+                    double x[3];
+                    grid_point(g, i, j, k, x);
+                    if (!(mn[0] <= x[0] && mn[1] <= x[1] && mn[2] <= x[2] && x[0] <= mx[0] &&
+                          x[1] <= mx[1] && x[2] <= mx[2]))
+                        continue;
+                    int64_t v = k * nx * ny + j * nx + i;
+                    if (pass == 0) {
+                        flag[v] |= 1;
+                        if (rmax > cmax[v]) cmax[v] = rmax;
+                    } else {
+                        if ((flag[v] & 2) || cmax[v] < rho_t) continue;
+                        int done = 0;
+                        sign_visit(Xe, re, rho_t, x, &mloc[v], &signs[v], &done);
+                        if (done) flag[v] |= 2;
+                    }
+                }
+        }
+    free(cmax); free(mloc); free(flag);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* DenseInNodes (src/MeshGrid/NodalDensities.jl:89-218)                */
+/* ------------------------------------------------------------------ */
+/* symmetric n x n eigen-decomposition by cyclic Jacobi (stands in for
+ * LAPACK `eigen`, NodalDensities.jl:159); eigenvalues ascending, V columns */
+static void jacobi_eig(int n, double *A /* n*n, destroyed */, double *w, double *V)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+        if (off == 0.0) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                double t = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; ++k) {
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = cs * akp - sn * akq;
+                    A[k * n + q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = cs * apk - sn * aqk;
+                    A[q * n + k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = cs * vkp - sn * vkq;
+                    V[k * n + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+    for (int i = 0; i < n; ++i) { /* selection sort ascending */
+        int m = i;
+        for (int j = i + 1; j < n; ++j)
+            if (w[j] < w[m]) m = j;
+        if (m != i) {
+            double t = w[i]; w[i] = w[m]; w[m] = t;
+            for (int k = 0; k < n; ++k) { t = V[k * n + i]; V[k * n + i] = V[k * n + m]; V[k * n + m] = t; }
+        }
+    }
+}
+
+int orc_dense_in_nodes(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int elem_type,
+                       const double *rho_e, double *rho_n)
+{
+    orc_mesh m;
+    if (mesh_init(&m, X, nnp, IEN, nel, elem_type)) return -1;
+    int nen = m.nen;
+    double *C = (double *)malloc(sizeof(double) * 3 * (size_t)nel); /* GeometricCentre :71-80 */
+    for (int64_t e = 0; e < nel; ++e)
+        for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+            for (int a = 0; a < nen; ++a) s += X[3 * (IEN[e * nen + a] - 1) + i];
+            C[3 * e + i] = s / (double)nen;
+        }
+    for (int64_t nd = 0; nd < nnp; ++nd) {
+        int64_t p0 = m.ine_ptr[nd], cnt = m.ine_ptr[nd + 1] - p0;
+        const int64_t *els = m.ine + p0;
+        double out = 0.0;
+        if (cnt == 1) {
+            out = rho_e[els[0]];                                   /* :99-100 */
+        } else if (cnt > 1 && cnt < 4) {                           /* FilterForNodalDensity :117-136 */
+            double L[3], Lmax = 0.0;
+            for (int64_t j = 0; j < cnt; ++j) {
+                double dv[3];
+                for (int i = 0; i < 3; ++i) dv[i] = X[3 * nd + i] - C[3 * els[j] + i];
+                L[j] = norm3(dv);
+                if (L[j] > Lmax) Lmax = L[j];
+            }
+            Lmax = Lmax * 1.2;
+            double dm = 0.0, den = 0.0;
+            for (int64_t j = 0; j < cnt; ++j) {
+                dm += rho_e[els[j]] * (1 - L[j] / Lmax);
+                den += (1 - L[j] / Lmax);
+            }
+            out = dm / den;
+        } else if (cnt > 3) {                                      /* NodalDensityLeastSquares :145-181 */
+            double AtA[16] = {0}, Atb[4] = {0}, bsum = 0.0;
+            for (int64_t j = 0; j < cnt; ++j) {
+                double row[4] = {1.0, C[3 * els[j]], C[3 * els[j] + 1], C[3 * els[j] + 2]};
+                for (int r = 0; r < 4; ++r) {
+                    for (int c = 0; c < 4; ++c) AtA[r * 4 + c] += row[r] * row[c];
+                    Atb[r] += row[r] * rho_e[els[j]];
+                }
+                bsum += rho_e[els[j]];
+            }
+            double w[4], V[16];
+            jacobi_eig(4, AtA, w, V);
+            /* LamReduction :190-218 */
+            double wmax = w[3], wmin = w[0];
+            double e1 = fabs(wmax / wmin), e2 = fabs(wmax / w[1]), e3 = fabs(wmax / w[2]);
+            int first = -1; /* index of first kept eigenvalue; -1 = none */
+            if (1e7 > e1 && 3e3 > e2) first = 0;
+            else if (1e7 < e1 && 3e3 > e2) first = 1;
+            else if (1e7 < e1 && 3e3 < e2) first = (3e3 > e3) ? 2 : 3;
+            if (first < 0) {
+                out = bsum / (double)cnt;
+            } else {
+                double b1[4], x2[4], xs[4];
+                for (int c = 0; c < 4; ++c) {
+                    double s = 0.0;
+                    for (int r = 0; r < 4; ++r) s += V[r * 4 + c] * Atb[r];
+                    b1[c] = s;
+                }
+                for (int c = 0; c < 4; ++c) x2[c] = (c >= first) ? b1[c] / w[c] : 0.0;
+                for (int r = 0; r < 4; ++r) {
+                    double s = 0.0;
+                    for (int c = 0; c < 4; ++c) s += V[r * 4 + c] * x2[c];
+                    xs[r] = s;
+                }
+                out = xs[0] + X[3 * nd] * xs[1] + X[3 * nd + 1] * xs[2] + X[3 * nd + 2] * xs[3];
+            }
+        }
+        rho_n[nd] = out;
+    }
+    free(C);
+    mesh_free(&m);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* noninteractive_sdf_grid_setup (src/MeshGrid/Grid_setup.jl:28-108)   */
+/* ------------------------------------------------------------------ */
+static int cmp_double(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+int orc_auto_grid(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int elem_type,
+                  orc_grid *g, double *median_edge)
+{
+    int nen = elem_type == 0 ? 8 : 4, noe = elem_type == 0 ? 12 : 6;
+    double *d = (double *)malloc(sizeof(double) * (size_t)(noe * nel));
+    for (int64_t e = 0; e < nel; ++e)
+        for (int k = 0; k < noe; ++k) {
+            int s = elem_type == 0 ? HEX_EDGES[k][0] : TET_EDGES[k][0];
+            int f = elem_type == 0 ? HEX_EDGES[k][1] : TET_EDGES[k][1];
+            const double *ps = X + 3 * (IEN[e * nen + s] - 1), *pf = X + 3 * (IEN[e * nen + f] - 1);
+            double dx = pf[0] - ps[0], dy = pf[1] - ps[1], dz = pf[2] - ps[2];
+            d[e * noe + k] = sqrt(dx * dx + dy * dy + dz * dz);
+        }
+    int64_t n = noe * nel;
+    qsort(d, (size_t)n, sizeof(double), cmp_double);
+    double B = (n % 2) ? d[n / 2] : (d[n / 2 - 1] + d[n / 2]) / 2;
+    free(d);
+    double mn[3], mx[3];
+    for (int i = 0; i < 3; ++i) { mn[i] = INFINITY; mx[i] = -INFINITY; }
+    for (int64_t p = 0; p < nnp; ++p)
+        for (int i = 0; i < 3; ++i) {
+            if (X[3 * p + i] < mn[i]) mn[i] = X[3 * p + i];
+            if (X[3 * p + i] > mx[i]) mx[i] = X[3 * p + i];
+        }
+    double ext = fmax(mx[0] - mn[0], fmax(mx[1] - mn[1], mx[2] - mn[2]));
+    int64_t n_new = (int64_t)floor(ext / B); /* Grid_setup.jl:103 */
+    if (median_edge) *median_edge = B;
+    return orc_grid_make(mn, mx, n_new, 3, g);
+}
