@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py - Mvoxels/s of SDF extraction (BASELINE.json metric).
+
+A "step" is one pass of the hot path (r2s_plan_run_dev: mesh prep -> work items -> tile bins
+-> sentinel sweep -> projection/sign kernel, then the Z-slab all-gather when N > 1) over the
+north-star workload of BASELINE.md section 4 ("NS"): synthetic jittered HEX8 46^3 = 97 336
+elements, 512^3 grid (N_max = 505), rho_t = 0.5.  Inputs are resident in HBM before the
+timed region; the output SDF stays in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 512] [--mesh 46]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 the fixed 512^3 grid is split into N equal Z-slabs (one rank per GPU) and stitched
+with ONE all_gather_into_tensor over RCCL/xGMI ("scaling": "strong").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALG_BYTES_PER_VOXEL = 8.0      # one Float64 store per voxel; + mesh bytes / ngp
+
+
+def slab_bounds(nz, world):
+    """equal Z-slabs, nz padded up to a multiple of `world`"""
+    per = (nz + world - 1) // world
+    return per, [(min(r * per, nz), min((r + 1) * per, nz)) for r in range(world)]
+
+
+def cpu_baseline(X, IEN, rho_n, rho_t, n_max, stride):
+    """The oracle (CPU restatement, kind "port") on a bounded sample of the SAME workload:
+    every `stride`-th Z plane of the same grid over the same mesh, one thread."""
+    O = graft.load_oracle()
+    og = O.grid_make(X.min(0), X.max(0), n_max, 3)
+    O.set_k_sampling(stride, 0)
+    t0 = time.perf_counter()
+    dist, _, st = O.eval_distances(X, IEN, rho_n, rho_t, og, 1.1, want_xp=False)
+    sign = O.sign_detection(X, IEN, rho_n, rho_t, og)
+    sdf = dist * sign
+    dt = time.perf_counter() - t0
+    O.set_k_sampling(1, 0)
+    nx, ny, nz = og.dims
+    planes = len(range(0, nz, stride))
+    nvox = planes * nx * ny
+    return {"value": nvox / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample": f"every {stride}th Z plane ({planes} of {nz} planes, {nvox} voxels) of the same "
+                      f"{nx}x{ny}x{nz} grid over the same mesh; {dt:.1f} s single thread",
+            "seconds": dt}, sdf
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=512, help="grid points per axis (512 = north star)")
+    ap.add_argument("--mesh", type=int, default=46, help="HEX8 cells per axis (46 -> 97 336 elements)")
+    ap.add_argument("--cpu-stride", type=int, default=16, help="CPU baseline samples every n-th Z plane")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare the sampled planes with the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    pkg = graft.build()
+    from rho2sdf_jl_amd import synthetic
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload (synthetic, deterministic) ----
+    X, IEN, rho_n = synthetic.hex_mesh(args.mesh)
+    rho_t = 0.5
+    n_max = synthetic.grid_n_max_for_points(args.grid)
+    grid = pkg.Grid(X.min(0), X.max(0), n_max, 3)
+    nx, ny, nz = grid.dims
+    ngp = grid.ngp
+    dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rho_n))
+    per, bounds = slab_bounds(nz, world)
+    k0, k1 = bounds[rank]
+    plane = nx * ny
+    gathered = torch.empty(world * per * plane, dtype=torch.float64, device=dev)
+    mine = gathered[rank * per * plane:(rank + 1) * per * plane]      # in-place all-gather
+    plan = pkg.DevicePlan(local_rank)
+    stats_acc = []
+
+    def step():
+        st = None
+        if k1 > k0:
+            st = plan.run(dX, dI, dR, rho_t, grid, k_begin=k0, k_end=k1, sdf=mine[:(k1 - k0) * plane])
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, mine)
+        return st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats_acc.append(step())
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = ngp / (elapsed / args.steps) / 1e6
+
+    if rank == 0:
+        sts = [s for s in stats_acc if s]
+        avg = {k: float(np.mean([s[k] for s in sts])) for k in ("ms_prep", "ms_bins", "ms_fill", "ms_main")}
+        st0 = sts[-1]
+        nvox_rank = (k1 - k0) * plane
+        mesh_bytes = X.nbytes + IEN.nbytes + rho_n.nbytes
+        alg_bytes = ALG_BYTES_PER_VOXEL * nvox_rank + mesh_bytes
+        main_s = avg["ms_main"] * 1e-3
+        achieved = alg_bytes / main_s / 1e9 if main_s > 0 else 0.0
+        out = {
+            "metric": "Mvoxels/s SDF extract on 512^3 grid over 100k HEX8; max|err| vs ref",
+            "value": value, "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"NS: synthetic jittered HEX8 {args.mesh}^3 = {len(IEN)} elements, "
+                                   f"{nx}x{ny}x{nz} grid (N_max={n_max}), rho_t=0.5, band factor 1.1, "
+                                   f"fused dist*sign, Z-slabs over {world} GPU(s)",
+                       "elements": int(len(IEN)), "voxels": int(ngp), "parallelism": f"zslab{world}"},
+            "roofline": {"bound": "hbm", "kernel": "sdf_tiles_kernel<true,true>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["ms_main"],
+                         "note": "FP64-VALU/latency-bound kernel (SURVEY.md 0.7); algorithmic bytes = 8 B/voxel "
+                                 "of the slab + mesh bytes; see DESIGN.md"},
+            "stages_ms": avg,
+            "fill_kernel": {"GBps": (8.0 * nvox_rank) / (avg["ms_fill"] * 1e-3) / 1e9 if avg["ms_fill"] > 0 else None,
+                            "frac_of_hbm_peak": (8.0 * nvox_rank) / (avg["ms_fill"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                            if avg["ms_fill"] > 0 else None},
+            "work": {k: int(st0[k]) for k in ("n_items", "n_band_entries", "n_sign_entries", "n_tiles", "n_active_tiles")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref = cpu_baseline(X, IEN, rho_n, rho_t, n_max, args.cpu_stride)
+            out["cpu_baseline"] = cb
+            if args.check:
+                got = gathered[:ngp].view(nz, ny, nx)[::args.cpu_stride].cpu().numpy().ravel()
+                want = ref.reshape(nz, ny, nx)[::args.cpu_stride].ravel()
+                sent = np.abs(want) > 1e9
+                real = ~sent
+                rel = np.abs(got[real] - want[real]) / np.maximum(np.abs(want[real]), 1e-300)
+                out["check"] = {"voxels": int(want.size), "sentinel_mismatch": int((sent != (np.abs(got) > 1e9)).sum()),
+                                "sign_mismatch": int((np.sign(got) != np.sign(want)).sum()),
+                                "max_rel_err": float(rel.max()) if rel.size else 0.0,
+                                "bit_equal": int((got == want).sum())}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

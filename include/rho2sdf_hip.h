@@ -1,0 +1,131 @@
+/*
+ * rho2sdf_hip.h - C ABI of the MI355X-native signed-distance extraction engine.
+ *
+ * The reference (kopacja/rho2sdf.jl) has no FFI of its own for this path; the
+ * drop-in boundary is the set of Julia functions `rho2sdf()` calls
+ * (src/RhoToSDF.jl:148-224).  Each entry point below replaces the body of one of
+ * them; the Julia-side `ccall` stubs are in INTEGRATION.md and
+ * rho2sdf.jl_amd/julia/Rho2sdfHIP.jl.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (streams are void*).
+ *   - array layouts are the reference's Julia column-major layouts:
+ *       X    3 x nnp  Float64  -> double[nnp][3]
+ *       IEN  nen x nel Int64, 1-based -> int64_t[nel][nen]
+ *       grid linear index (0-based) = k*(N1+1)*(N2+1) + j*(N1+1) + i   (Grid.jl:84-92)
+ *   - return 0 on success, negative on error; r2s_last_error() gives the text
+ *     (the Julia wrapper turns it into `error(...)`, as the reference does).
+ *   - `*_dev` entry points take DEVICE pointers (resident in HBM) and a HIP
+ *     stream handle; the host-pointer entry points allocate/copy internally and
+ *     never keep caller pointers after returning.
+ *   - the library fails with R2S_ERR_NO_DEVICE when no gfx950 device is usable;
+ *     there is no CPU fallback.
+ */
+#ifndef RHO2SDF_HIP_H
+#define RHO2SDF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R2S_VERSION 100 /* 0.1.0 */
+
+#define R2S_OK 0
+#define R2S_ERR_ARG (-1)
+#define R2S_ERR_NO_DEVICE (-2)
+#define R2S_ERR_HIP (-3)
+#define R2S_ERR_UNSUPPORTED (-4)
+#define R2S_ERR_NOMEM (-5)
+
+#define R2S_HEX8 0
+#define R2S_TET4 1
+
+/* mirrors `mutable struct Grid` (src/MeshGrid/Grid.jl:2-7) */
+typedef struct {
+    double aabb_min[3];
+    double aabb_max[3];
+    int64_t N[3];      /* cells per axis; grid points per axis = N+1 */
+    double cell_size;
+    int64_t ngp;
+} r2s_grid;
+
+/* constants that are hard-coded in the reference become fields with the same defaults */
+typedef struct {
+    double band_factor; /* 1.1  : delta = band_factor*cell_size (sdfOnDensityField.jl:158) */
+    int32_t elem_type;  /* R2S_HEX8 / R2S_TET4 (Rho2sdfOptions.element_type, RhoToSDF.jl:20) */
+    int32_t device;     /* HIP device ordinal, -1 = current device */
+    int32_t reserved[4];
+} r2s_params;
+
+/* per-call counters (optional; pass NULL) */
+typedef struct {
+    int64_t n_solid;        /* elements with min(rho_e) >= rho_t           */
+    int64_t n_iso;          /* elements crossed by the iso-surface         */
+    int64_t n_items;        /* band work items (boundary triangles + iso)  */
+    int64_t n_band_entries; /* tile->item list entries                     */
+    int64_t n_sign_entries; /* tile->element list entries                  */
+    int64_t n_tiles;        /* 4x4x4 voxel tiles in the slab               */
+    int64_t n_active_tiles; /* tiles that ran the projection kernel        */
+    double ms_prep, ms_bins, ms_fill, ms_main; /* HIP-event times of the last call */
+} r2s_stats;
+
+int r2s_version(void);
+const char *r2s_last_error(void);
+int r2s_device_count(void);
+void r2s_default_params(r2s_params *p);
+
+/* Grid(AABB_min, AABB_max, N_max, margineCells)          src/MeshGrid/Grid.jl:10-34 */
+int r2s_grid_make(const double xmin[3], const double xmax[3], int64_t n_max, int64_t margin,
+                  r2s_grid *out);
+
+/* noninteractive_sdf_grid_setup(mesh)                    src/MeshGrid/Grid_setup.jl:94-108 */
+int r2s_auto_grid(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int32_t elem_type,
+                  r2s_grid *out, double *median_edge);
+
+/* evalDistances(mesh, grid, points, rho_n, rho_t) -> (dist, xp)
+ *                                         src/SignedDistances/sdfOnDensityField.jl:139-486
+ * dist_out[ngp] (1e10 = untouched), xp_out[ngp][3] or NULL. */
+int r2s_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel,
+                       const double *rho_n, double rho_t, const r2s_grid *grid,
+                       const r2s_params *params, double *dist_out, double *xp_out, r2s_stats *stats);
+
+/* Sign_Detection(mesh, grid, points, rho_n, rho_t) -> signs in {-1,+1}
+ *                                         src/SignedDistances/SignDetection.jl:275-283 */
+int r2s_sign_detection(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel,
+                       const double *rho_n, double rho_t, const r2s_grid *grid,
+                       const r2s_params *params, double *signs_out, r2s_stats *stats);
+
+/* fused `dists .* signs` (RhoToSDF.jl:169-171) - the path rho2sdf() uses */
+int r2s_sdf(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_n,
+            double rho_t, const r2s_grid *grid, const r2s_params *params, double *sdf_out,
+            r2s_stats *stats);
+
+/* ---- device-resident plan API (bench, multi-GPU Z-slabs) ------------------ */
+typedef struct r2s_plan r2s_plan;
+
+int r2s_plan_create(int32_t device, r2s_plan **out);
+void r2s_plan_destroy(r2s_plan *plan);
+
+/* mode bits for r2s_plan_run_dev */
+#define R2S_OUT_DIST 1 /* d_dist[nvox]            */
+#define R2S_OUT_SIGN 2 /* d_sign[nvox]            */
+#define R2S_OUT_SDF 4  /* d_sdf[nvox] = dist*sign */
+#define R2S_OUT_XP 8   /* d_xp[nvox][3]           */
+
+/* One pass of the hot path over the Z-slab of grid planes [k_begin, k_end):
+ * all inputs/outputs are device pointers; outputs hold (k_end-k_begin)*(N1+1)*(N2+1)
+ * voxels in the reference's x-fastest order.  Work is enqueued on `stream`
+ * (hipStream_t as void*, NULL = default stream) and the call returns after the
+ * stream has been synchronised (sizes of the bin lists are read back). */
+int r2s_plan_run_dev(r2s_plan *plan, const double *dX, int64_t nnp, const int64_t *dIEN, int64_t nel,
+                     const double *d_rho_n, double rho_t, const r2s_grid *grid,
+                     const r2s_params *params, int64_t k_begin, int64_t k_end, int32_t mode,
+                     double *d_dist, double *d_sign, double *d_sdf, double *d_xp, void *stream,
+                     r2s_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RHO2SDF_HIP_H */

@@ -134,3 +134,8 @@ def iso_project_hex8(x, Xe, rho_e, rho_t):
     f.restype = ctypes.c_int
     it = f(_d(x), _d(Xe), _d(rho_e), ctypes.c_double(rho_t), _d(xi))
     return xi, it
+
+
+def set_k_sampling(stride=1, phase=0):
+    """bench.py cpu_baseline: evaluate only planes k % stride == phase"""
+    lib().orc_set_k_sampling(ctypes.c_int64(stride), ctypes.c_int64(phase))

@@ -657,7 +657,7 @@ static inline int write_value(dist_ctx *c, int64_t v, double d, const double xp[
 {
     if (fabs(d) < c->dist[v]) {
         c->dist[v] = d;
-        c->xp[3 * v] = xp[0]; c->xp[3 * v + 1] = xp[1]; c->xp[3 * v + 2] = xp[2];
+        if (c->xp) { c->xp[3 * v] = xp[0]; c->xp[3 * v + 1] = xp[1]; c->xp[3 * v + 2] = xp[2]; }
         return 1;
     }
     return 0;
@@ -805,6 +805,15 @@ typedef struct {
     int64_t n_solid, n_iso, n_iso_solves, n_iso_fail, n_tri_tests, n_invmap;
 } orc_stats;
 
+/* bench.py's bounded CPU sample: only grid planes with k % stride == phase are
+ * evaluated (all other voxels keep the untouched values); default = every plane */
+static int64_t g_kstride = 1, g_kphase = 0;
+void orc_set_k_sampling(int64_t stride, int64_t phase)
+{
+    g_kstride = stride > 0 ? stride : 1;
+    g_kphase = phase;
+}
+
 int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int elem_type,
                        const double *rho_n, double rho_t, const orc_grid *g, double band_factor,
                        double *dist_out, double *xp_out, orc_stats *stats)
@@ -820,7 +829,7 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
     c.head = (int64_t *)malloc(sizeof(int64_t) * (size_t)ngp);
     c.next = (int64_t *)malloc(sizeof(int64_t) * (size_t)ngp);
     c.dist = dist_out;
-    c.xp = xp_out ? xp_out : (double *)calloc((size_t)ngp * 3, sizeof(double));
+    c.xp = xp_out; /* may be NULL: projection points not requested */
     for (int64_t i = 0; i < ngp; ++i) { c.head[i] = -1; c.next[i] = -1; c.dist[i] = BIG; }
     if (xp_out) memset(xp_out, 0, sizeof(double) * 3 * (size_t)ngp);
     /* LinkedList (Grid.jl:47-68) */
@@ -830,6 +839,7 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
           for (int64_t j = 0; j <= g->N[1]; ++j)
             for (int64_t i = 0; i <= g->N[0]; ++i, ++v) {
                 double p[3];
+                if (k % g_kstride != g_kphase) continue;
                 grid_point(g, i, j, k, p);
                 double I1 = cell_of(g, 0, p[0]), I2 = cell_of(g, 1, p[1]), I3 = cell_of(g, 2, p[2]);
                 int64_t Ia = (int64_t)(I3 * (double)(g->N[0] + 1) * (double)(g->N[1] + 1) +
@@ -887,7 +897,6 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
         stats->n_tri_tests = c.n_tri_tests; stats->n_invmap = c.n_invmap;
     }
     free(c.head); free(c.next);
-    if (!xp_out) free(c.xp);
     mesh_free(&m);
     return 0;
 }
@@ -1000,6 +1009,7 @@ int orc_sign_detection(const double *X, int64_t nnp, const int64_t *IEN, int64_t
               for (int64_t j = lo[1]; j <= hi[1]; ++j)
                 for (int64_t i = lo[0]; i <= hi[0]; ++i) {
                     double x[3];
+                    if (k % g_kstride != g_kphase) continue;
                     grid_point(g, i, j, k, x);
                     if (!(mn[0] <= x[0] && mn[1] <= x[1] && mn[2] <= x[2] && x[0] <= mx[0] &&
                           x[1] <= mx[1] && x[2] <= mx[2]))

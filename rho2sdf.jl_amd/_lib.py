@@ -1,0 +1,99 @@
+"""Loader for the C-ABI shared library (include/rho2sdf_hip.h).
+
+The library is the product; there is no CPU fallback.  If the in-tree
+librho2sdf_hip.so is missing or does not load, importing this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librho2sdf_hip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+class R2SGrid(ctypes.Structure):
+    """mirrors `mutable struct Grid` (reference src/MeshGrid/Grid.jl:2-7)"""
+    _fields_ = [("aabb_min", ctypes.c_double * 3), ("aabb_max", ctypes.c_double * 3),
+                ("N", ctypes.c_int64 * 3), ("cell_size", ctypes.c_double), ("ngp", ctypes.c_int64)]
+
+
+class R2SParams(ctypes.Structure):
+    _fields_ = [("band_factor", ctypes.c_double), ("elem_type", ctypes.c_int32),
+                ("device", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+
+
+class R2SStats(ctypes.Structure):
+    _fields_ = [("n_solid", ctypes.c_int64), ("n_iso", ctypes.c_int64), ("n_items", ctypes.c_int64),
+                ("n_band_entries", ctypes.c_int64), ("n_sign_entries", ctypes.c_int64),
+                ("n_tiles", ctypes.c_int64), ("n_active_tiles", ctypes.c_int64),
+                ("ms_prep", ctypes.c_double), ("ms_bins", ctypes.c_double),
+                ("ms_fill", ctypes.c_double), ("ms_main", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/rho2sdf_hip.h declares: (name, restype, argtypes)
+_P = ctypes.c_void_p
+_MESH = [c_double_p, ctypes.c_int64, c_int64_p, ctypes.c_int64]
+_COMMON = _MESH + [c_double_p, ctypes.c_double, ctypes.POINTER(R2SGrid), ctypes.POINTER(R2SParams)]
+SYMBOLS = [
+    ("r2s_version", ctypes.c_int, []),
+    ("r2s_last_error", ctypes.c_char_p, []),
+    ("r2s_device_count", ctypes.c_int, []),
+    ("r2s_default_params", None, [ctypes.POINTER(R2SParams)]),
+    ("r2s_grid_make", ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int64, ctypes.c_int64,
+                                     ctypes.POINTER(R2SGrid)]),
+    ("r2s_auto_grid", ctypes.c_int, _MESH + [ctypes.c_int32, ctypes.POINTER(R2SGrid), c_double_p]),
+    ("r2s_eval_distances", ctypes.c_int, _COMMON + [c_double_p, c_double_p, ctypes.POINTER(R2SStats)]),
+    ("r2s_sign_detection", ctypes.c_int, _COMMON + [c_double_p, ctypes.POINTER(R2SStats)]),
+    ("r2s_sdf", ctypes.c_int, _COMMON + [c_double_p, ctypes.POINTER(R2SStats)]),
+    ("r2s_plan_create", ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(_P)]),
+    ("r2s_plan_destroy", None, [_P]),
+    ("r2s_plan_run_dev", ctypes.c_int,
+     [_P, _P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_double, ctypes.POINTER(R2SGrid),
+      ctypes.POINTER(R2SParams), ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P,
+      ctypes.POINTER(R2SStats)]),
+]
+
+OUT_DIST, OUT_SIGN, OUT_SDF, OUT_XP = 1, 2, 4, 8
+HEX8, TET4 = 0, 1
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same SONAME as
+        # /opt/rocm's).  If torch is going to be used for device memory / streams it has to be
+        # loaded first so this library binds to the runtime torch already initialised;
+        # otherwise two runtimes fight over the device ("No HIP GPUs are available").
+        if os.environ.get("R2S_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)          # AttributeError if the symbol is not exported
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class R2SError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """C-ABI status -> exception, like the reference's `error(...)` calls."""
+    if rc != 0:
+        raise R2SError(f"rho2sdf_hip error {rc}: {lib().r2s_last_error().decode()}")

@@ -1,0 +1,591 @@
+// Device-side element math for the signed-distance hot path (gfx950, FP64 VALU).
+//
+// Every function states which reference function it replaces.  Expressions that
+// feed integer / boolean decisions keep the reference's operation order; the
+// translation unit is compiled with -ffp-contract=off so nothing is contracted.
+// All small arrays are indexed with compile-time constants after unrolling so
+// they live in VGPRs (no scratch).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace r2s {
+
+#define R2S_DEV __device__ __forceinline__
+
+// One pre-gathered HEX8 element: X[:, IEN[:, el]] and rho_n[IEN[:, el]] plus the
+// element AABB (SignDetection.jl:16-21) and max nodal density (SignDetection.jl:33-36).
+struct alignas(16) ElemRec {
+    double X[8][3];
+    double r[8];
+    double mn[3];
+    double mx[3];
+    double rmax;
+    double rmin;
+};
+
+// band work item: one boundary-face triangle (process_triangle_projection!,
+// sdfOnDensityField.jl:628-815) or one iso-surface projection
+// (process_isocontour_element!, :606-624), with its mini-AABB cell box
+// (calculateMiniAABB_grid, Grid.jl:122-154).
+struct alignas(16) BandItem {
+    int32_t imin[3];
+    int32_t imax[3];
+    int32_t el;    // 0-based element
+    int32_t kind;  // 0 iso projection, 1 triangle of a solid element, 2 triangle of an iso element
+    int32_t im;    // row of the barycentric system replaced by ones (TriangularMeshUtils.jl:19-21)
+    int32_t p0, p1;  // partial-pivot row swaps of the 3x3 LU
+    int32_t sing;  // LU hit a zero pivot
+    int32_t pad[4];
+    double tri[3][3];  // vertices x1,x2,x3
+    double n[3];       // unit normal
+    double L[3];       // edge lengths
+    double eh[3][3];   // unit edge directions Et[j]/L
+    double lu[3][3];   // LU factors of the barycentric matrix (L unit-lower, U upper)
+};
+
+struct GridDev {
+    double amin[3];
+    double amax[3];
+    double cell;
+    int32_t N[3];
+    int32_t nx, ny, nz;  // N+1
+};
+
+// ---- shape functions (src/ShapeFunctions/hex8_shape.jl:2-108) -------------------
+R2S_DEV void hex8_shape(const double xi[3], double N[8])
+{
+    double x1m = xi[0] - 1, x1p = xi[0] + 1, x2m = xi[1] - 1, x2p = xi[1] + 1;
+    double x3m = xi[2] - 1, x3p = xi[2] + 1;
+    double t1 = x1m * x2m, t2 = x1p * x2m, t3 = x1p * x2p, t4 = x1m * x2p;
+    const double c = 0.125;
+    N[0] = -c * t1 * x3m;
+    N[1] = c * t2 * x3m;
+    N[2] = -c * t3 * x3m;
+    N[3] = c * t4 * x3m;
+    N[4] = c * t1 * x3p;
+    N[5] = -c * t2 * x3p;
+    N[6] = c * t3 * x3p;
+    N[7] = -c * t4 * x3p;
+}
+
+R2S_DEV void hex8_shape_d(const double xi[3], double N[8], double dN[8][3])
+{
+    double x1m = xi[0] - 1, x1p = xi[0] + 1, x2m = xi[1] - 1, x2p = xi[1] + 1;
+    double x3m = xi[2] - 1, x3p = xi[2] + 1;
+    double t1 = x1m * x2m, t2 = x1p * x2m, t3 = x1p * x2p, t4 = x1m * x2p;
+    const double c = 0.125;
+    N[0] = -c * t1 * x3m;
+    N[1] = c * t2 * x3m;
+    N[2] = -c * t3 * x3m;
+    N[3] = c * t4 * x3m;
+    N[4] = c * t1 * x3p;
+    N[5] = -c * t2 * x3p;
+    N[6] = c * t3 * x3p;
+    N[7] = -c * t4 * x3p;
+    double d1 = c * x3m, d1p = c * x3p;
+    dN[0][0] = -d1 * x2m;  dN[1][0] = d1 * x2m;   dN[2][0] = -d1 * x2p;  dN[3][0] = d1 * x2p;
+    dN[4][0] = d1p * x2m;  dN[5][0] = -d1p * x2m; dN[6][0] = d1p * x2p;  dN[7][0] = -d1p * x2p;
+    dN[0][1] = -d1 * x1m;  dN[1][1] = d1 * x1p;   dN[2][1] = -d1 * x1p;  dN[3][1] = d1 * x1m;
+    dN[4][1] = d1p * x1m;  dN[5][1] = -d1p * x1p; dN[6][1] = d1p * x1p;  dN[7][1] = -d1p * x1m;
+    dN[0][2] = -c * t1;    dN[1][2] = c * t2;     dN[2][2] = -c * t3;    dN[3][2] = c * t4;
+    dN[4][2] = c * t1;     dN[5][2] = -c * t2;    dN[6][2] = c * t3;     dN[7][2] = -c * t4;
+}
+
+// mixed second derivatives d2N/dxi1dxi2, d2N/dxi1dxi3, d2N/dxi2dxi3
+R2S_DEV void hex8_shape_mixed(const double xi[3], double m[8][3])
+{
+    const double x1m = xi[0] - 1, x1p = xi[0] + 1, x2m = xi[1] - 1, x2p = xi[1] + 1;
+    const double x3m = xi[2] - 1, x3p = xi[2] + 1;
+    const double c = 0.125;
+    m[0][0] = -c * x3m; m[0][1] = -c * x2m; m[0][2] = -c * x1m;
+    m[1][0] = c * x3m;  m[1][1] = c * x2m;  m[1][2] = c * x1p;
+    m[2][0] = -c * x3m; m[2][1] = -c * x2p; m[2][2] = -c * x1p;
+    m[3][0] = c * x3m;  m[3][1] = c * x2p;  m[3][2] = c * x1m;
+    m[4][0] = c * x3p;  m[4][1] = c * x2m;  m[4][2] = c * x1m;
+    m[5][0] = -c * x3p; m[5][1] = -c * x2m; m[5][2] = -c * x1p;
+    m[6][0] = c * x3p;  m[6][1] = c * x2p;  m[6][2] = c * x1p;
+    m[7][0] = -c * x3p; m[7][1] = -c * x2p; m[7][2] = -c * x1m;
+}
+
+R2S_DEV double norm3(double a, double b, double c) { return sqrt(a * a + b * b + c * c); }
+
+// grid point (Grid.jl:87) and its cell index (Grid.jl:58)
+R2S_DEV double grid_coord(const GridDev& g, int ax, int i) { return g.amin[ax] + g.cell * (double)i; }
+R2S_DEV double cell_of(const GridDev& g, int ax, double x)
+{
+    return floor((double)g.N[ax] * (x - g.amin[ax]) / (g.amax[ax] - g.amin[ax]));
+}
+
+// ---- inverse isoparametric map (FindLocalCoordinates.jl:16-107) ------------------
+// Box-clamped Newton from xi = 0 on Xe N(xi) = x; see DESIGN.md "inverse map".
+R2S_DEV bool inv_map_hex8(const ElemRec& E, const double x[3], double xi[3])
+{
+    xi[0] = xi[1] = xi[2] = 0.0;
+    for (int it = 0; it < 50; ++it) {
+        double N[8], dN[8][3], R[3], J[3][3];
+        hex8_shape_d(xi, N, dN);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += E.X[k][i] * N[k];
+            R[i] = s - x[i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += E.X[k][i] * dN[k][j];
+                J[i][j] = t;
+            }
+        }
+        double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        double c10 = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+        double c11 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+        double c12 = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+        double c20 = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+        double c21 = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+        double c22 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        double d0 = -(c00 * R[0] + c10 * R[1] + c20 * R[2]) / det;
+        double d1 = -(c01 * R[0] + c11 * R[1] + c21 * R[2]) / det;
+        double d2 = -(c02 * R[0] + c12 * R[1] + c22 * R[2]) / det;
+        double n0 = fmin(fmax(xi[0] + d0, -1.1), 1.1);
+        double n1 = fmin(fmax(xi[1] + d1, -1.1), 1.1);
+        double n2 = fmin(fmax(xi[2] + d2, -1.1), 1.1);
+        double step = fmax(fabs(n0 - xi[0]), fmax(fabs(n1 - xi[1]), fabs(n2 - xi[2])));
+        xi[0] = n0; xi[1] = n1; xi[2] = n2;
+        if (!(step > 1e-13)) {
+            if (step != step) break;
+            return true;
+        }
+    }
+    xi[0] = xi[1] = xi[2] = 10.0;
+    return false;
+}
+
+// ---- projection onto the iso-surface inside one HEX8 ----------------------------
+// Replaces compute_coords_on_iso (ComputeCoordsOnIso.jl:16-87, NLopt SLSQP):
+// same objective / constraint / bounds / start; SQP described in DESIGN.md.
+struct QpOut {
+    double d[3];
+    double lam;
+    double q;
+    bool kkt;
+};
+
+R2S_DEV bool qp_pattern(int pat, const double H[3][3], const double g[3], const double a[3], double e,
+                        const double lo[3], const double hi[3], QpOut& o)
+{
+    const int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+    double dB[3], aa[3], b[3], M[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dB[i] = (s[i] == 1) ? lo[i] : ((s[i] == 2) ? hi[i] : 0.0);
+    double ep = e;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (s[i]) {
+            ep -= a[i] * dB[i];
+            aa[i] = 0.0;
+            b[i] = 0.0;
+        } else {
+            aa[i] = a[i];
+            double t = -g[i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (s[j]) t -= H[i][j] * dB[j];
+            b[i] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[i][j] = (s[i] || s[j]) ? ((i == j) ? 1.0 : 0.0) : H[i][j];
+    }
+    double D0 = M[0][0];
+    double l10 = M[1][0] / D0, l20 = M[2][0] / D0;
+    double D1 = M[1][1] - l10 * M[1][0];
+    double l21 = (M[2][1] - l20 * M[1][0]) / D1;
+    double D2 = M[2][2] - l20 * M[2][0] - l21 * l21 * D1;
+    if (!(D0 > 0.0 && D1 > 0.0 && D2 > 0.0)) return false;
+    double u[3], v[3];
+    u[0] = aa[0]; u[1] = aa[1] - l10 * u[0]; u[2] = aa[2] - l20 * u[0] - l21 * u[1];
+    v[0] = b[0];  v[1] = b[1] - l10 * v[0];  v[2] = b[2] - l20 * v[0] - l21 * v[1];
+    u[2] = u[2] / D2; u[1] = u[1] / D1 - l21 * u[2]; u[0] = u[0] / D0 - l10 * u[1] - l20 * u[2];
+    v[2] = v[2] / D2; v[1] = v[1] / D1 - l21 * v[2]; v[0] = v[0] / D0 - l10 * v[1] - l20 * v[2];
+    double den = aa[0] * u[0] + aa[1] * u[1] + aa[2] * u[2];
+    if (!(den > 0.0)) return false;
+    double lam = (aa[0] * v[0] + aa[1] * v[1] + aa[2] * v[2] - ep) / den;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (s[i]) {
+            o.d[i] = dB[i];
+        } else {
+            o.d[i] = v[i] - lam * u[i];
+            if (!(o.d[i] >= lo[i] - 1e-12 && o.d[i] <= hi[i] + 1e-12)) ok = false;
+        }
+    }
+    if (!ok) return false;
+    double Hd[3], q = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Hd[i] = H[i][0] * o.d[0] + H[i][1] * o.d[1] + H[i][2] * o.d[2];
+        q += o.d[i] * (0.5 * Hd[i] + g[i]);
+    }
+    bool kkt = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (s[i]) {
+            double z = Hd[i] + g[i] + lam * a[i];
+            if (s[i] == 1 && !(z >= 0.0)) kkt = false;
+            if (s[i] == 2 && !(z <= 0.0)) kkt = false;
+        }
+    }
+    o.lam = lam;
+    o.q = q;
+    o.kkt = kkt;
+    return true;
+}
+
+R2S_DEV void iso_eval_fc(const ElemRec& E, const double x[3], double rt, const double xi[3], double& f,
+                         double& c)
+{
+    double N[8];
+    hex8_shape(xi, N);
+    double ff = 0.0, rho = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += E.X[k][i] * N[k];
+        double r = x[i] - s;
+        ff += r * r;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rho += E.r[k] * N[k];
+    f = ff;
+    c = rho - rt;
+}
+
+#define R2S_ISO_MAXIT 60
+#define R2S_ISO_TOL 1e-10
+
+// returns iterations used (R2S_ISO_MAXIT+1 when not converged)
+R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, double xi[3])
+{
+    xi[0] = xi[1] = xi[2] = 0.0;
+    double mu = 0.0, lam = 0.0, Delta = 2.0;
+    int pat = 0;
+    for (int it = 0; it < R2S_ISO_MAXIT; ++it) {
+        double N[8], dN[8][3], m2[8][3], r[3], J[3][3], a[3], g[3], G[3][3];
+        hex8_shape_d(xi, N, dN);
+        double f = 0.0, rho = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += E.X[k][i] * N[k];
+            r[i] = x[i] - s;
+            f += r[i] * r[i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += E.X[k][i] * dN[k][j];
+                J[i][j] = t;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rho += E.r[k] * N[k];
+        const double c = rho - rt;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += E.r[k] * dN[k][j];
+            a[j] = t;
+            g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                G[i][j] = 2.0 * (J[0][i] * J[0][j] + J[1][i] * J[1][j] + J[2][i] * J[2][j]);
+        {
+            double num = 0.0, den = 0.0;
+            const int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (!s[i]) { num += a[i] * g[i]; den += a[i] * a[i]; }
+            lam = (den > 0.0) ? -num / den : 0.0;
+        }
+        hex8_shape_mixed(xi, m2);
+        double S[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double pr = 0.0, rr = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                pr += (r[0] * E.X[k][0] + r[1] * E.X[k][1] + r[2] * E.X[k][2]) * m2[k][q];
+                rr += E.r[k] * m2[k][q];
+            }
+            S[q] = -2.0 * pr + lam * rr;
+        }
+        double lo[3], hi[3], d[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lo[i] = fmax(-1.0 - xi[i], -Delta);
+            hi[i] = fmin(1.0 - xi[i], Delta);
+        }
+        const double e = -c;
+        double mplus = 0.0, mminus = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double p = a[i] * lo[i], q = a[i] * hi[i];
+            mplus += fmax(p, q);
+            mminus += fmin(p, q);
+        }
+        const double trG = G[0][0] + G[1][1] + G[2][2];
+        const double aa2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+        const double sigma = 100.0 * trG / aa2;
+        bool use_exact = true, corner = false;
+        int stop = 0;
+        double lam_new = lam, alpha = 1.0;
+        for (;;) {
+            corner = false;
+            lam_new = lam;
+            if (e >= mplus) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
+                corner = true;
+            } else if (e <= mminus) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
+                corner = true;
+            } else {
+                double H[3][3], gp[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
+                    gp[i] = g[i] - sigma * e * a[i];
+                }
+                if (use_exact) {
+                    H[0][1] += S[0]; H[1][0] += S[0];
+                    H[0][2] += S[1]; H[2][0] += S[1];
+                    H[1][2] += S[2]; H[2][1] += S[2];
+                }
+                QpOut o;
+                bool found = false;
+                if (qp_pattern(pat, H, gp, a, e, lo, hi, o) && o.kkt) {
+                    found = true;
+                    d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
+                    lam_new = o.lam;
+                } else {
+                    double bestq = INFINITY;
+                    for (int p = 0; p < 27; ++p) {
+                        if (qp_pattern(p, H, gp, a, e, lo, hi, o) && o.q < bestq) {
+                            bestq = o.q;
+                            found = true;
+                            pat = p;
+                            d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
+                            lam_new = o.lam;
+                        }
+                    }
+                }
+                if (!found) {
+                    if (use_exact) { use_exact = false; continue; }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        d[i] = (e > 0.0) ? ((a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0))
+                                         : ((a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0));
+                    corner = true;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
+            }
+            const double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+            alpha = 1.0;
+            if (!(dmax > R2S_ISO_TOL)) {
+                stop = corner ? 2 : 1;
+                break;
+            }
+            const double ad = a[0] * d[0] + a[1] * d[1] + a[2] * d[2];
+            const double pred_c = fabs(c) - fabs(c + ad);
+            const double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+            double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
+            if (!(gd - mu_t * pred_c < 0.0)) {
+                if (pred_c > 0.0) {
+                    mu_t = 2.0 * gd / pred_c;
+                } else if (use_exact && !corner) {
+                    use_exact = false;
+                    continue;
+                } else {
+                    stop = 2;
+                    break;
+                }
+            }
+            mu = mu_t;
+            const double D = gd - mu * pred_c;
+            const double phi0 = f + mu * fabs(c);
+            for (int ls = 0; ls < 30; ++ls) {
+                double xt[3], ft, ct;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
+                iso_eval_fc(E, x, rt, xt, ft, ct);
+                if (ft + mu * fabs(ct) <= phi0 + 1e-4 * alpha * D) break;
+                alpha *= 0.5;
+            }
+            break;
+        }
+        {
+            const double dm = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+            Delta = (alpha < 1.0) ? alpha * dm : fmin(2.0, fmax(Delta, 2.0 * dm));
+        }
+        if (stop == 2) return R2S_ISO_MAXIT + 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xi[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
+        if (stop == 1) return it + 1;
+    }
+    return R2S_ISO_MAXIT + 1;
+}
+
+// running minimum of one voxel: WriteValue / update_distance_parallel!
+// (sdfOnDensityField.jl:44-57, :121-136) - strict '<' on the magnitude.
+struct VoxState {
+    double cur;    // |dist_local[v]|, starts at 1e10 (sdfOnDensityField.jl:172-183)
+    double xp[3];  // projection point, starts at 0 (:174)
+};
+
+R2S_DEV bool write_value(VoxState& s, double d, const double xp[3])
+{
+    if (fabs(d) < s.cur) {
+        s.cur = d;
+        s.xp[0] = xp[0]; s.xp[1] = xp[1]; s.xp[2] = xp[2];
+        return true;
+    }
+    return false;
+}
+
+// IsProjectedOnFullSegment, HEX8 (sdfOnDensityField.jl:78-119)
+R2S_DEV bool projected_on_full_segment(VoxState& s, const ElemRec& E, double rt, const double xp[3],
+                                       const double x[3])
+{
+    double xi[3], N[8];
+    inv_map_hex8(E, xp, xi);
+    const double m = fmax(fabs(xi[0]), fmax(fabs(xi[1]), fabs(xi[2])));
+    if (m < 1.001) {
+        hex8_shape(xi, N);
+        double rho = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rho += N[k] * E.r[k];
+        if (rho >= rt) {
+            write_value(s, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), xp);
+            return true;
+        }
+    }
+    return false;
+}
+
+R2S_DEV bool tri_candidate(VoxState& s, bool solid, const ElemRec& E, double rt, const double xp[3],
+                           const double x[3], double d)
+{
+    return solid ? write_value(s, d, xp) : projected_on_full_segment(s, E, rt, xp, x);
+}
+
+// process_triangle_projection! for one voxel (sdfOnDensityField.jl:675-813)
+R2S_DEV void process_triangle(VoxState& s, const BandItem& T, const ElemRec& E, double rt,
+                              const double x[3])
+{
+    const bool solid = (T.kind == 1);
+    // barycentricCoordinates (TriangularMeshUtils.jl:1-24) with the factored matrix
+    double b0 = x[1] * T.n[2] - x[2] * T.n[1];
+    double b1 = x[2] * T.n[0] - x[0] * T.n[2];
+    double b2 = x[0] * T.n[1] - x[1] * T.n[0];
+    if (T.im == 0) b0 = 1.0; else if (T.im == 1) b1 = 1.0; else b2 = 1.0;
+    // forward substitution with the stored row swaps (the factors are stored in their
+    // final row order, so the second swap is applied before the first elimination step)
+    if (T.p0 == 1) { double t = b0; b0 = b1; b1 = t; }
+    else if (T.p0 == 2) { double t = b0; b0 = b2; b2 = t; }
+    if (T.p1 == 2) { double t = b1; b1 = b2; b2 = t; }
+    b1 -= T.lu[1][0] * b0;
+    b2 -= T.lu[2][0] * b0;
+    b2 -= T.lu[2][1] * b1;
+    double l2 = b2 / T.lu[2][2];
+    double l1 = (b1 - T.lu[1][2] * l2) / T.lu[1][1];
+    double l0 = (b0 - T.lu[0][1] * l1 - T.lu[0][2] * l2) / T.lu[0][0];
+    if (T.sing) { l0 = l1 = l2 = NAN; }
+    bool ok = false;
+    double xp[3];
+    // minimum(lam) >= 0 with Julia's NaN-propagating minimum
+    const bool inside = (l0 >= 0.0) && (l1 >= 0.0) && (l2 >= 0.0);
+    if (inside) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xp[i] = l0 * T.tri[0][i] + l1 * T.tri[1][i] + l2 * T.tri[2][i];
+        const double d = norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]);
+        ok = tri_candidate(s, solid, E, rt, xp, x, d);
+    } else {
+#pragma unroll 1
+        for (int j = 0; j < 3; ++j) {
+            const double L = T.L[j];
+            const double P = (x[0] - T.tri[j][0]) * T.eh[j][0] + (x[1] - T.tri[j][1]) * T.eh[j][1] +
+                             (x[2] - T.tri[j][2]) * T.eh[j][2];
+            if (P >= 0 && P <= L) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xp[i] = T.tri[j][i] + T.eh[j][i] * P;
+                const double d = norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]);
+                ok = tri_candidate(s, solid, E, rt, xp, x, d);
+                if (ok) break;
+            }
+        }
+    }
+    if (!ok) {
+        double dd[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dd[j] = norm3(x[0] - T.tri[j][0], x[1] - T.tri[j][1], x[2] - T.tri[j][2]);
+        int idx = 0;
+        double dm = dd[0];
+        if (dd[1] < dm || (dd[1] != dd[1] && dm == dm)) { idx = 1; dm = dd[1]; }
+        if (dd[2] < dm || (dd[2] != dd[2] && dm == dm)) { idx = 2; dm = dd[2]; }
+        xp[0] = (idx == 0) ? T.tri[0][0] : ((idx == 1) ? T.tri[1][0] : T.tri[2][0]);
+        xp[1] = (idx == 0) ? T.tri[0][1] : ((idx == 1) ? T.tri[1][1] : T.tri[2][1]);
+        xp[2] = (idx == 0) ? T.tri[0][2] : ((idx == 1) ? T.tri[1][2] : T.tri[2][2]);
+        tri_candidate(s, solid, E, rt, xp, x, dm);
+    }
+}
+
+// iso-surface candidate of one voxel (process_isocontour_element!, :612-623)
+R2S_DEV void process_iso(VoxState& s, const ElemRec& E, double rt, const double x[3])
+{
+    double xi[3], N[8], xp[3];
+    iso_project_hex8(E, x, rt, xi);
+    hex8_shape(xi, N);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += E.X[k][i] * N[k];
+        xp[i] = t;
+    }
+    write_value(s, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), xp);
+}
+
+// per-voxel state machine of Sign_Detection_HEX8 for one candidate (SignDetection.jl:41-70)
+R2S_DEV void sign_visit(const ElemRec& E, double rt, const double x[3], double& max_local, double& sign,
+                        bool& done)
+{
+    double xi[3], N[8];
+    inv_map_hex8(E, x, xi);
+    const double m = fmax(fabs(xi[0]), fmax(fabs(xi[1]), fabs(xi[2])));
+    if (m < 1.01 && max_local > m) {
+        hex8_shape(xi, N);
+        double rho = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rho += N[k] * E.r[k];
+        if (rho >= rt) sign = 1.0;
+        if (m < 0.95) done = true;
+        else max_local = m;
+    }
+}
+
+}  // namespace r2s

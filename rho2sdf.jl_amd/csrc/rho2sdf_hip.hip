@@ -1,0 +1,1003 @@
+// MI355X (gfx950) signed-distance extraction engine: kernels + C ABI.
+//
+// Pipeline of one r2s_plan_run_dev() call (all on one HIP stream):
+//   node_degree / ine_fill      node -> element CSR            (MeshInformations.jl:69-77)
+//   elem_prep                   gather element records, classify solid/iso, boundary faces
+//   item_build                  band work items (boundary triangles + iso projections)
+//   bin_count / scan / bin_fill / bin_sort
+//                               4x4x4-voxel tile -> item list and tile -> element list
+//   fill                        sentinel sweep (HBM-bound)
+//   sdf_tiles                   one wavefront per active tile: ordered gather over the
+//                               tile's lists, FP64 VALU (projection + inverse map)
+// See DESIGN.md for the data layout and the roofline of each kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rho2sdf_hip.h"
+#include "r2s_device_math.hpp"
+
+using namespace r2s;
+
+// ------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(R2S_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// element topology (src/ElementTypes/ElementTypes.jl:15-78), 0-based
+// ------------------------------------------------------------------------------------
+__constant__ int c_hex_isn[6][4] = {{0, 3, 2, 1}, {0, 1, 5, 4}, {1, 2, 6, 5},
+                                    {2, 3, 7, 6}, {3, 0, 4, 7}, {4, 5, 6, 7}};
+
+// ------------------------------------------------------------------------------------
+// exclusive scan of uint32 (block = 256 threads x 4 items)
+// ------------------------------------------------------------------------------------
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 4
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_block_kernel(const uint32_t* __restrict__ in,
+                                                               uint32_t* __restrict__ out,
+                                                               uint32_t* __restrict__ block_sums,
+                                                               int64_t n)
+{
+    __shared__ uint32_t wave_sums[SCAN_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0u;
+        sum += v[i];
+    }
+    // inclusive scan of per-thread sums inside the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+        if (w < wave) wave_off += wave_sums[w];
+        total += wave_sums[w];
+    }
+    uint32_t run = wave_off + incl - sum;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 0 && block_sums) block_sums[blockIdx.x] = total;
+}
+
+__global__ void scan_add_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_offs,
+                                int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x;
+    const uint32_t add = block_offs[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        int64_t j = i + (int64_t)k * SCAN_BLOCK;
+        if (j < n) out[j] += add;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// mesh preparation kernels
+// ------------------------------------------------------------------------------------
+__global__ void node_degree_kernel(const int64_t* __restrict__ IEN, int64_t nel, int nen, int64_t nnp,
+                                   uint32_t* __restrict__ deg, int* __restrict__ bad)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nel * nen) return;
+    int64_t n = IEN[t] - 1;
+    if (n < 0 || n >= nnp) { *bad = 1; return; }
+    atomicAdd(&deg[n], 1u);
+}
+
+__global__ void ine_fill_kernel(const int64_t* __restrict__ IEN, int64_t nel, int nen, int64_t nnp,
+                                const uint32_t* __restrict__ ptr, uint32_t* __restrict__ cursor,
+                                uint32_t* __restrict__ ine)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nel * nen) return;
+    int64_t n = IEN[t] - 1;
+    if (n < 0 || n >= nnp) return;
+    uint32_t pos = atomicAdd(&cursor[n], 1u);
+    ine[ptr[n] + pos] = (uint32_t)(t / nen);
+}
+
+// element classes
+#define CLS_SKIP 0
+#define CLS_SOLID 1
+#define CLS_ISO 2
+
+struct SlabInfo {
+    int32_t k0, k1;          // lattice planes [k0,k1)
+    int32_t ntx, nty, ntz;   // tiles
+    int32_t ntiles;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// 1 thread / element: gather record, classify (sdfOnDensityField.jl:197-201,312), boundary
+// faces (:511-519), work-item count, lattice range of the element AABB for the sign bins.
+__global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __restrict__ IEN,
+                                 const double* __restrict__ rho_n, int64_t nel, double rho_t,
+                                 const uint32_t* __restrict__ ine_ptr, const uint32_t* __restrict__ ine,
+                                 ElemRec* __restrict__ erec, uint8_t* __restrict__ cls,
+                                 uint8_t* __restrict__ fmask, uint32_t* __restrict__ nitems)
+{
+    int64_t el = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (el >= nel) return;
+    int64_t nd[8];
+    ElemRec R;
+    double rmin = INFINITY, rmax = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        nd[a] = IEN[el * 8 + a] - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) R.X[a][i] = X[3 * nd[a] + i];
+        R.r[a] = rho_n[nd[a]];
+        if (R.r[a] < rmin) rmin = R.r[a];
+        if (R.r[a] > rmax) rmax = R.r[a];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double mn = R.X[0][i], mx = R.X[0][i];
+#pragma unroll
+        for (int a = 1; a < 8; ++a) {
+            if (R.X[a][i] < mn) mn = R.X[a][i];
+            if (R.X[a][i] > mx) mx = R.X[a][i];
+        }
+        R.mn[i] = mn;
+        R.mx[i] = mx;
+    }
+    R.rmax = rmax;
+    R.rmin = rmin;
+    erec[el] = R;
+    int c = CLS_SKIP;
+    if (rmin >= rho_t) c = CLS_SOLID;
+    else if (rmax > rho_t) c = CLS_ISO;
+    uint32_t fm = 0, cnt = 0;
+    if (c != CLS_SKIP) {
+        for (int sg = 0; sg < 6; ++sg) {
+            const int64_t n0 = nd[c_hex_isn[sg][0]];
+            int common = 0;
+            for (uint32_t p = ine_ptr[n0]; p < ine_ptr[n0 + 1]; ++p) {
+                const uint32_t e = ine[p];
+                bool all = true;
+                for (int a = 1; a < 4 && all; ++a) {
+                    const int64_t na = nd[c_hex_isn[sg][a]];
+                    bool found = false;
+                    for (uint32_t q = ine_ptr[na]; q < ine_ptr[na + 1]; ++q)
+                        if (ine[q] == e) { found = true; break; }
+                    all = found;
+                }
+                common += all ? 1 : 0;
+            }
+            if (common == 1) { fm |= (1u << sg); cnt += 4; }
+        }
+        if (c == CLS_ISO) cnt += 1;
+    }
+    cls[el] = (uint8_t)c;
+    fmask[el] = (uint8_t)fm;
+    nitems[el] = cnt;
+}
+
+// mini-AABB cell range of a coordinate interval (Grid.jl:130-145)
+__device__ __forceinline__ void mini_range(const GridDev& g, int ax, double mn, double mx, double delta,
+                                           int32_t& imin, int32_t& imax)
+{
+    double lo = cell_of(g, ax, mn - delta);
+    double hi = cell_of(g, ax, mx + delta);
+    if (lo < 0) lo = 0;
+    if (hi >= (double)g.N[ax]) hi = (double)g.N[ax];
+    // keep empty ranges empty, but inside int32
+    lo = fmin(lo, 2.0e9);
+    hi = fmax(hi, -2.0e9);
+    imin = (int32_t)lo;
+    imax = (int32_t)hi;
+}
+
+// 1 thread / element with items: writes its triangles (face order sg, fan order a) and then the
+// iso item - the reference's processing order inside one element (:584-624).
+__global__ void item_build_kernel(const ElemRec* __restrict__ erec, const uint8_t* __restrict__ cls,
+                                  const uint8_t* __restrict__ fmask, const uint32_t* __restrict__ item_off,
+                                  int64_t nel, GridDev g, double delta, BandItem* __restrict__ items)
+{
+    int64_t el = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (el >= nel) return;
+    const int c = cls[el];
+    if (c == CLS_SKIP) return;
+    const ElemRec& E = erec[el];
+    uint32_t w = item_off[el];
+    const uint32_t fm = fmask[el];
+    for (int sg = 0; sg < 6; ++sg) {
+        if (!(fm & (1u << sg))) continue;
+        double Xs[4][3], Xc[3];
+        for (int a = 0; a < 4; ++a)
+            for (int i = 0; i < 3; ++i) Xs[a][i] = E.X[c_hex_isn[sg][a]][i];
+        for (int i = 0; i < 3; ++i) Xc[i] = (((Xs[0][i] + Xs[1][i]) + Xs[2][i]) + Xs[3][i]) / 4.0;
+        for (int a = 0; a < 4; ++a) {
+            BandItem T;
+            const int b = (a + 1) & 3;
+            for (int i = 0; i < 3; ++i) { T.tri[0][i] = Xs[a][i]; T.tri[1][i] = Xs[b][i]; T.tri[2][i] = Xc[i]; }
+            double Et[3][3];
+            for (int i = 0; i < 3; ++i) {
+                Et[0][i] = T.tri[1][i] - T.tri[0][i];
+                Et[1][i] = T.tri[2][i] - T.tri[1][i];
+                Et[2][i] = T.tri[0][i] - T.tri[2][i];
+            }
+            double n0 = Et[0][1] * Et[1][2] - Et[0][2] * Et[1][1];
+            double n1 = Et[0][2] * Et[1][0] - Et[0][0] * Et[1][2];
+            double n2 = Et[0][0] * Et[1][1] - Et[0][1] * Et[1][0];
+            const double nn = norm3(n0, n1, n2);
+            n0 /= nn; n1 /= nn; n2 /= nn;
+            T.n[0] = n0; T.n[1] = n1; T.n[2] = n2;
+            for (int j = 0; j < 3; ++j) {
+                const double L = norm3(Et[j][0], Et[j][1], Et[j][2]);
+                T.L[j] = L;
+                for (int i = 0; i < 3; ++i) T.eh[j][i] = Et[j][i] / L;
+            }
+            // barycentric matrix (TriangularMeshUtils.jl:9-21) and its partial-pivot LU
+            double A[3][3];
+            for (int v = 0; v < 3; ++v) {
+                const double* p = T.tri[v];
+                A[0][v] = p[1] * n2 - p[2] * n1;
+                A[1][v] = p[2] * n0 - p[0] * n2;
+                A[2][v] = p[0] * n1 - p[1] * n0;
+            }
+            int im = 0;
+            double nm = fabs(n0);
+            if (fabs(n1) > nm) { nm = fabs(n1); im = 1; }
+            if (fabs(n2) > nm) { nm = fabs(n2); im = 2; }
+            for (int v = 0; v < 3; ++v) A[im][v] = 1.0;
+            T.im = im;
+            int sing = 0, p0 = 0, p1 = 1;
+            {
+                double best = fabs(A[0][0]);
+                if (fabs(A[1][0]) > best) { best = fabs(A[1][0]); p0 = 1; }
+                if (fabs(A[2][0]) > best) { best = fabs(A[2][0]); p0 = 2; }
+                if (best == 0.0) sing = 1;
+                if (p0 != 0)
+                    for (int k = 0; k < 3; ++k) { double t = A[0][k]; A[0][k] = A[p0][k]; A[p0][k] = t; }
+                for (int r = 1; r < 3; ++r) {
+                    const double l = A[r][0] / A[0][0];
+                    A[r][0] = l;
+                    A[r][1] -= l * A[0][1];
+                    A[r][2] -= l * A[0][2];
+                }
+                best = fabs(A[1][1]);
+                if (fabs(A[2][1]) > best) { best = fabs(A[2][1]); p1 = 2; }
+                if (best == 0.0) sing = 1;
+                if (p1 != 1)
+                    for (int k = 0; k < 3; ++k) { double t = A[1][k]; A[1][k] = A[2][k]; A[2][k] = t; }
+                const double l = A[2][1] / A[1][1];
+                A[2][1] = l;
+                A[2][2] -= l * A[1][2];
+                if (A[2][2] == 0.0) sing = 1;
+            }
+            for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < 3; ++k) T.lu[r][k] = A[r][k];
+            T.p0 = p0; T.p1 = p1; T.sing = sing;
+            T.el = (int32_t)el;
+            T.kind = (c == CLS_SOLID) ? 1 : 2;
+            for (int ax = 0; ax < 3; ++ax) {
+                double mn = fmin(fmin(T.tri[0][ax], T.tri[1][ax]), T.tri[2][ax]);
+                double mx = fmax(fmax(T.tri[0][ax], T.tri[1][ax]), T.tri[2][ax]);
+                mini_range(g, ax, mn, mx, delta, T.imin[ax], T.imax[ax]);
+            }
+            T.pad[0] = T.pad[1] = T.pad[2] = T.pad[3] = 0;
+            items[w++] = T;
+        }
+    }
+    if (c == CLS_ISO) {
+        BandItem T;
+        memset(&T, 0, sizeof T);
+        T.el = (int32_t)el;
+        T.kind = 0;
+        for (int ax = 0; ax < 3; ++ax) mini_range(g, ax, E.mn[ax], E.mx[ax], delta, T.imin[ax], T.imax[ax]);
+        items[w++] = T;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// tile binning.  A tile is a 4x4x4 block of VOXELS (lattice indices); a voxel's cell
+// index (Grid.jl:58) is its lattice index or one less, so an item with cell box
+// [imin,imax] can touch voxels with lattice index in [imin, imax+1].
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool band_tile_range(const BandItem& T, const GridDev& g, const SlabInfo& s,
+                                                int lo[3], int hi[3])
+{
+    const int nmax[3] = {g.nx - 1, g.ny - 1, g.nz - 1};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        int a = T.imin[ax], b = T.imax[ax];
+        if (a > b || a > nmax[ax]) return false;
+        b = (b >= nmax[ax]) ? nmax[ax] : b + 1;
+        if (ax == 2) {
+            if (b < s.k0 || a >= s.k1) return false;
+            a = (a < s.k0 ? s.k0 : a) - s.k0;
+            b = (b >= s.k1 ? s.k1 - 1 : b) - s.k0;
+        }
+        lo[ax] = a >> 2;
+        hi[ax] = b >> 2;
+    }
+    return true;
+}
+
+// lattice range that can contain points of the element AABB (conservative by one)
+__device__ __forceinline__ bool sign_tile_range(const ElemRec& E, const GridDev& g, const SlabInfo& s,
+                                                int lo[3], int hi[3])
+{
+    const int nmax[3] = {g.nx - 1, g.ny - 1, g.nz - 1};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        double fa = floor((E.mn[ax] - g.amin[ax]) / g.cell) - 1.0;
+        double fb = ceil((E.mx[ax] - g.amin[ax]) / g.cell) + 1.0;
+        if (!(fb >= 0.0) || !(fa <= (double)nmax[ax])) return false;
+        int a = (fa < 0.0) ? 0 : (int)fa;
+        int b = (fb > (double)nmax[ax]) ? nmax[ax] : (int)fb;
+        if (ax == 2) {
+            if (b < s.k0 || a >= s.k1) return false;
+            a = (a < s.k0 ? s.k0 : a) - s.k0;
+            b = (b >= s.k1 ? s.k1 - 1 : b) - s.k0;
+        }
+        lo[ax] = a >> 2;
+        hi[ax] = b >> 2;
+    }
+    return true;
+}
+
+template <bool FILL>
+__global__ void band_bin_kernel(const BandItem* __restrict__ items, uint32_t nitems, GridDev g, SlabInfo s,
+                                uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                uint32_t* __restrict__ entries)
+{
+    uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= nitems) return;
+    int lo[3], hi[3];
+    if (!band_tile_range(items[it], g, s, lo, hi)) return;
+    for (int tz = lo[2]; tz <= hi[2]; ++tz)
+        for (int ty = lo[1]; ty <= hi[1]; ++ty)
+            for (int tx = lo[0]; tx <= hi[0]; ++tx) {
+                const uint32_t t = ((uint32_t)tz * s.nty + ty) * s.ntx + tx;
+                const uint32_t pos = atomicAdd(&cnt[t], 1u);
+                if (FILL) entries[off[t] + pos] = it;
+            }
+}
+
+template <bool FILL>
+__global__ void sign_bin_kernel(const ElemRec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s,
+                                uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                uint32_t* __restrict__ entries)
+{
+    uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
+    if (el >= nel) return;
+    int lo[3], hi[3];
+    if (!sign_tile_range(erec[el], g, s, lo, hi)) return;
+    for (int tz = lo[2]; tz <= hi[2]; ++tz)
+        for (int ty = lo[1]; ty <= hi[1]; ++ty)
+            for (int tx = lo[0]; tx <= hi[0]; ++tx) {
+                const uint32_t t = ((uint32_t)tz * s.nty + ty) * s.ntx + tx;
+                const uint32_t pos = atomicAdd(&cnt[t], 1u);
+                if (FILL) entries[off[t] + pos] = el;
+            }
+}
+
+// active tiles = tiles with a non-empty band list, or a sign list whose elements reach rho_t
+__global__ void active_tiles_kernel(const uint32_t* __restrict__ band_cnt,
+                                    const uint32_t* __restrict__ sign_cnt, uint32_t ntiles,
+                                    uint32_t* __restrict__ active, uint32_t* __restrict__ n_active)
+{
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    if (band_cnt[t] | sign_cnt[t]) active[atomicAdd(n_active, 1u)] = t;
+}
+
+// one wavefront per active tile: rank-sort both lists ascending (the reference visits
+// elements 1..nel in order; the ordered gather needs the same order).
+__global__ void __launch_bounds__(256) bin_sort_kernel(const uint32_t* __restrict__ active, uint32_t n_active,
+                                                      const uint32_t* __restrict__ off_a,
+                                                      const uint32_t* __restrict__ in_a,
+                                                      uint32_t* __restrict__ out_a,
+                                                      const uint32_t* __restrict__ off_b,
+                                                      const uint32_t* __restrict__ in_b,
+                                                      uint32_t* __restrict__ out_b)
+{
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n_active) return;
+    const uint32_t t = active[w];
+    for (int which = 0; which < 2; ++which) {
+        const uint32_t* off = which ? off_b : off_a;
+        const uint32_t* in = which ? in_b : in_a;
+        uint32_t* out = which ? out_b : out_a;
+        const uint32_t b = off[t], n = off[t + 1] - b;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t v = in[b + i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) rank += (in[b + j] < v) ? 1u : 0u;
+            out[b + rank] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// sentinel sweep: untouched voxels are dist = 1e10, sign = -1 (sdfOnDensityField.jl:172-173,483;
+// SignDetection.jl:13) => sdf = -1e10.  Pure HBM write stream, 16 B per lane.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fill_kernel(double* __restrict__ p, int64_t n, double v)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n2 = n >> 1;
+    double2* p2 = reinterpret_cast<double2*>(p);
+    const double2 vv = make_double2(v, v);
+    for (int64_t j = i; j < n2; j += stride) p2[j] = vv;
+    if (i == 0 && (n & 1)) p[n - 1] = v;
+}
+
+// ------------------------------------------------------------------------------------
+// main kernel: one wavefront = one 4x4x4 voxel tile
+// ------------------------------------------------------------------------------------
+struct MainArgs {
+    GridDev g;
+    SlabInfo s;
+    double rho_t;
+    const uint32_t* active;
+    uint32_t n_active;
+    const uint32_t* band_off;
+    const uint32_t* band_ent;
+    const uint32_t* sign_off;
+    const uint32_t* sign_ent;
+    const BandItem* items;
+    const ElemRec* erec;
+    double* dist;
+    double* sign;
+    double* sdf;
+    double* xp;
+};
+
+template <bool DO_DIST, bool DO_SIGN>
+__global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
+{
+    // wave-uniform tile id: everything derived from it lives in SGPRs / scalar loads
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= A.n_active) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = A.active[w];
+    const int tx = t % A.s.ntx, ty = (t / A.s.ntx) % A.s.nty, tz = t / (A.s.ntx * A.s.nty);
+    const int i = tx * 4 + (lane & 3), j = ty * 4 + ((lane >> 2) & 3), kl = tz * 4 + (lane >> 4);
+    const int k = kl + A.s.k0;
+    const bool valid = (i < A.g.nx) && (j < A.g.ny) && (k < A.s.k1);
+    double x[3];
+    x[0] = grid_coord(A.g, 0, i);
+    x[1] = grid_coord(A.g, 1, j);
+    x[2] = grid_coord(A.g, 2, k);
+
+    VoxState st;
+    st.cur = 1.0e10;
+    st.xp[0] = st.xp[1] = st.xp[2] = 0.0;
+    if (DO_DIST) {
+        const int ci = (int)cell_of(A.g, 0, x[0]), cj = (int)cell_of(A.g, 1, x[1]),
+                  ck = (int)cell_of(A.g, 2, x[2]);
+        const uint32_t b = A.band_off[t], e = A.band_off[t + 1];
+        for (uint32_t p = b; p < e; ++p) {
+            const BandItem& T = A.items[A.band_ent[p]];
+            const bool in = valid && ci >= T.imin[0] && ci <= T.imax[0] && cj >= T.imin[1] &&
+                            cj <= T.imax[1] && ck >= T.imin[2] && ck <= T.imax[2];
+            if (in) {
+                const ElemRec& E = A.erec[T.el];
+                if (T.kind == 0) process_iso(st, E, A.rho_t, x);
+                else process_triangle(st, T, E, A.rho_t, x);
+            }
+        }
+    }
+    double sg = -1.0;
+    if (DO_SIGN) {
+        const uint32_t b = A.sign_off[t], e = A.sign_off[t + 1];
+        bool any = false;
+        double cmax = -INFINITY;
+        for (uint32_t p = b; p < e; ++p) {
+            const ElemRec& E = A.erec[A.sign_ent[p]];
+            const bool in = E.mn[0] <= x[0] && E.mn[1] <= x[1] && E.mn[2] <= x[2] && x[0] <= E.mx[0] &&
+                            x[1] <= E.mx[1] && x[2] <= E.mx[2];
+            if (in) {
+                any = true;
+                if (E.rmax > cmax) cmax = E.rmax;
+            }
+        }
+        bool go = valid && any && !(cmax < A.rho_t);  // SignDetection.jl:36
+        double max_local = 10.0;
+        bool done = false;
+        if (__any(go)) {
+            for (uint32_t p = b; p < e; ++p) {
+                const ElemRec& E = A.erec[A.sign_ent[p]];
+                const bool in = go && !done && E.mn[0] <= x[0] && E.mn[1] <= x[1] && E.mn[2] <= x[2] &&
+                                x[0] <= E.mx[0] && x[1] <= E.mx[1] && x[2] <= E.mx[2];
+                if (in) sign_visit(E, A.rho_t, x, max_local, sg, done);
+            }
+        }
+    }
+    if (valid) {
+        const int64_t v = ((int64_t)kl * A.g.ny + j) * A.g.nx + i;
+        if (A.dist) A.dist[v] = st.cur;
+        if (A.sign) A.sign[v] = sg;
+        if (A.sdf) A.sdf[v] = st.cur * sg;
+        if (A.xp) {
+            A.xp[3 * v] = st.xp[0];
+            A.xp[3 * v + 1] = st.xp[1];
+            A.xp[3 * v + 2] = st.xp[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// plan: device workspace that survives across calls
+// ------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipMalloc(&p, bytes) != hipSuccess) return -1;
+            want = bytes;
+        }
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct r2s_plan {
+    int device = 0;
+    DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
+    DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
+    DevBuf active, counters, scan_tmp[3];
+    uint32_t* h_pinned = nullptr;  // 8 words
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+static int scan_exclusive(r2s_plan* P, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st, int level = 0)
+{
+    if (n <= 0) return 0;
+    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb == 1) {
+        scan_block_kernel<<<1, SCAN_BLOCK, 0, st>>>(in, out, nullptr, n);
+        return 0;
+    }
+    if (level >= 3) return fail(R2S_ERR_ARG, "scan too large");
+    if (P->scan_tmp[level].ensure(sizeof(uint32_t) * (size_t)nb)) return fail(R2S_ERR_NOMEM, "scan workspace");
+    uint32_t* sums = P->scan_tmp[level].as<uint32_t>();
+    scan_block_kernel<<<(unsigned)nb, SCAN_BLOCK, 0, st>>>(in, out, sums, n);
+    int rc = scan_exclusive(P, sums, sums, nb, st, level + 1);
+    if (rc) return rc;
+    scan_add_kernel<<<(unsigned)nb, SCAN_BLOCK, 0, st>>>(out, sums, n);
+    return 0;
+}
+
+static int check_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(R2S_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    }
+    if (device >= n) return fail(R2S_ERR_ARG, "device %d out of range (%d devices)", device, n);
+    return 0;
+}
+
+extern "C" {
+
+int r2s_version(void) { return R2S_VERSION; }
+const char* r2s_last_error(void) { return g_err.c_str(); }
+
+int r2s_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void r2s_default_params(r2s_params* p)
+{
+    memset(p, 0, sizeof *p);
+    p->band_factor = 1.1;
+    p->elem_type = R2S_HEX8;
+    p->device = -1;
+}
+
+int r2s_grid_make(const double xmin[3], const double xmax[3], int64_t n_max, int64_t margin, r2s_grid* out)
+{
+    if (!xmin || !xmax || !out || n_max <= 0 || margin < 0) return fail(R2S_ERR_ARG, "r2s_grid_make: bad argument");
+    double ext = xmax[0] - xmin[0];
+    for (int i = 1; i < 3; ++i) ext = std::max(ext, xmax[i] - xmin[i]);
+    const double cell = ext / (double)n_max;       // Grid.jl:17
+    const double m = (double)margin * cell;
+    out->ngp = 1;
+    for (int i = 0; i < 3; ++i) {
+        const double lo = xmin[i] - m;              // Grid.jl:20
+        const double hi = xmax[i] + m;              // Grid.jl:21
+        out->N[i] = (int64_t)std::ceil((hi - lo) / cell);  // Grid.jl:24
+        out->aabb_min[i] = lo;
+        out->aabb_max[i] = lo + (double)out->N[i] * cell;  // Grid.jl:26
+        out->ngp *= out->N[i] + 1;                  // Grid.jl:30
+    }
+    out->cell_size = cell;
+    return 0;
+}
+
+int r2s_auto_grid(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, int32_t elem_type,
+                  r2s_grid* out, double* median_edge)
+{
+    if (!X || !IEN || !out || nnp <= 0 || nel <= 0) return fail(R2S_ERR_ARG, "r2s_auto_grid: bad argument");
+    static const int hex_edges[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6},
+                                         {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    static const int tet_edges[6][2] = {{0, 1}, {1, 2}, {2, 0}, {0, 3}, {1, 3}, {2, 3}};
+    const int nen = elem_type == R2S_HEX8 ? 8 : 4, noe = elem_type == R2S_HEX8 ? 12 : 6;
+    std::vector<double> d((size_t)noe * nel);
+    for (int64_t e = 0; e < nel; ++e)
+        for (int k = 0; k < noe; ++k) {  // calculate_edge_distances, Grid_setup.jl:28-51
+            const int s = elem_type == R2S_HEX8 ? hex_edges[k][0] : tet_edges[k][0];
+            const int f = elem_type == R2S_HEX8 ? hex_edges[k][1] : tet_edges[k][1];
+            const int64_t ns = IEN[e * nen + s] - 1, nf = IEN[e * nen + f] - 1;
+            if (ns < 0 || ns >= nnp || nf < 0 || nf >= nnp) return fail(R2S_ERR_ARG, "IEN out of range");
+            const double dx = X[3 * nf] - X[3 * ns], dy = X[3 * nf + 1] - X[3 * ns + 1],
+                         dz = X[3 * nf + 2] - X[3 * ns + 2];
+            d[(size_t)e * noe + k] = std::sqrt(dx * dx + dy * dy + dz * dz);
+        }
+    const size_t n = d.size();
+    double B;
+    std::nth_element(d.begin(), d.begin() + n / 2, d.end());
+    B = d[n / 2];
+    if (n % 2 == 0) {  // median of an even count = mean of the middle pair
+        const double lo = *std::max_element(d.begin(), d.begin() + n / 2);
+        B = (lo + B) / 2;
+    }
+    double mn[3], mx[3];
+    for (int i = 0; i < 3; ++i) { mn[i] = INFINITY; mx[i] = -INFINITY; }
+    for (int64_t p = 0; p < nnp; ++p)
+        for (int i = 0; i < 3; ++i) {
+            mn[i] = std::min(mn[i], X[3 * p + i]);
+            mx[i] = std::max(mx[i], X[3 * p + i]);
+        }
+    const double ext = std::max(mx[0] - mn[0], std::max(mx[1] - mn[1], mx[2] - mn[2]));
+    const int64_t n_new = (int64_t)std::floor(ext / B);  // Grid_setup.jl:103
+    if (median_edge) *median_edge = B;
+    return r2s_grid_make(mn, mx, n_new, 3, out);
+}
+
+int r2s_plan_create(int32_t device, r2s_plan** out)
+{
+    if (!out) return fail(R2S_ERR_ARG, "r2s_plan_create: null out");
+    if (device < 0) {
+        int rc = check_device(0);
+        if (rc) return rc;
+        HIP_TRY(hipGetDevice(&device));
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    r2s_plan* P = new r2s_plan();
+    P->device = device;
+    HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocDefault));
+    for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
+    *out = P;
+    return 0;
+}
+
+void r2s_plan_destroy(r2s_plan* P)
+{
+    if (!P) return;
+    (void)hipSetDevice(P->device);
+    DevBuf* all[] = {&P->deg, &P->ine_ptr, &P->ine, &P->cursor, &P->erec, &P->cls, &P->fmask, &P->nitems,
+                     &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
+                     &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->counters,
+                     &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
+    for (DevBuf* b : all) b->release();
+    if (P->h_pinned) (void)hipHostFree(P->h_pinned);
+    for (int i = 0; i < 5; ++i)
+        if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
+    delete P;
+}
+
+#define ENSURE(buf, bytes)                                                       \
+    do {                                                                         \
+        if ((buf).ensure(bytes)) return fail(R2S_ERR_NOMEM, "hipMalloc of %zu bytes failed", (size_t)(bytes)); \
+    } while (0)
+
+int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* dIEN, int64_t nel,
+                     const double* d_rho_n, double rho_t, const r2s_grid* grid, const r2s_params* params,
+                     int64_t k_begin, int64_t k_end, int32_t mode, double* d_dist, double* d_sign,
+                     double* d_sdf, double* d_xp, void* stream, r2s_stats* stats)
+{
+    if (!P || !dX || !dIEN || !d_rho_n || !grid) return fail(R2S_ERR_ARG, "r2s_plan_run_dev: null argument");
+    r2s_params prm;
+    if (params) prm = *params; else r2s_default_params(&prm);
+    if (prm.elem_type != R2S_HEX8) return fail(R2S_ERR_UNSUPPORTED, "element type %d not supported yet (HEX8 only)", prm.elem_type);
+    if (nnp <= 0 || nel <= 0) return fail(R2S_ERR_ARG, "empty mesh");
+    if (nel * 8 >= (int64_t)1 << 31) return fail(R2S_ERR_ARG, "mesh too large");
+    for (int i = 0; i < 3; ++i)
+        if (grid->N[i] < 1 || grid->N[i] > 100000) return fail(R2S_ERR_ARG, "bad grid dimension");
+    if (k_begin < 0 || k_end > grid->N[2] + 1 || k_begin >= k_end) return fail(R2S_ERR_ARG, "bad slab [%lld,%lld)", (long long)k_begin, (long long)k_end);
+    const bool want_dist = (mode & (R2S_OUT_DIST | R2S_OUT_SDF | R2S_OUT_XP)) != 0;
+    const bool want_sign = (mode & (R2S_OUT_SIGN | R2S_OUT_SDF)) != 0;
+    if (!want_dist && !want_sign) return fail(R2S_ERR_ARG, "mode selects no output");
+    if ((mode & R2S_OUT_DIST) && !d_dist) return fail(R2S_ERR_ARG, "d_dist is null");
+    if ((mode & R2S_OUT_SIGN) && !d_sign) return fail(R2S_ERR_ARG, "d_sign is null");
+    if ((mode & R2S_OUT_SDF) && !d_sdf) return fail(R2S_ERR_ARG, "d_sdf is null");
+    if ((mode & R2S_OUT_XP) && !d_xp) return fail(R2S_ERR_ARG, "d_xp is null");
+    HIP_TRY(hipSetDevice(P->device));
+    hipStream_t st = (hipStream_t)stream;
+
+    GridDev g;
+    for (int i = 0; i < 3; ++i) {
+        g.amin[i] = grid->aabb_min[i];
+        g.amax[i] = grid->aabb_max[i];
+        g.N[i] = (int32_t)grid->N[i];
+    }
+    g.cell = grid->cell_size;
+    g.nx = g.N[0] + 1; g.ny = g.N[1] + 1; g.nz = g.N[2] + 1;
+    SlabInfo s;
+    s.k0 = (int32_t)k_begin; s.k1 = (int32_t)k_end;
+    s.ntx = (g.nx + 3) / 4; s.nty = (g.ny + 3) / 4; s.ntz = (int32_t)((k_end - k_begin + 3) / 4);
+    const int64_t ntiles64 = (int64_t)s.ntx * s.nty * s.ntz;
+    if (ntiles64 >= ((int64_t)1 << 31)) return fail(R2S_ERR_ARG, "slab too large");
+    s.ntiles = (int32_t)ntiles64;
+    const uint32_t ntiles = (uint32_t)s.ntiles;
+    const int64_t nvox = (k_end - k_begin) * (int64_t)g.nx * g.ny;
+    const double delta = prm.band_factor * g.cell;  // sdfOnDensityField.jl:158
+
+    // ---- workspace ----
+    ENSURE(P->deg, sizeof(uint32_t) * (size_t)(nnp + 1));
+    ENSURE(P->ine_ptr, sizeof(uint32_t) * (size_t)(nnp + 1));
+    ENSURE(P->cursor, sizeof(uint32_t) * (size_t)(nnp + 1));
+    ENSURE(P->ine, sizeof(uint32_t) * (size_t)(nel * 8));
+    ENSURE(P->erec, sizeof(ElemRec) * (size_t)nel);
+    ENSURE(P->cls, (size_t)nel);
+    ENSURE(P->fmask, (size_t)nel);
+    ENSURE(P->nitems, sizeof(uint32_t) * (size_t)(nel + 1));
+    ENSURE(P->item_off, sizeof(uint32_t) * (size_t)(nel + 1));
+    ENSURE(P->band_cnt, sizeof(uint32_t) * (size_t)(ntiles + 1));
+    ENSURE(P->band_off, sizeof(uint32_t) * (size_t)(ntiles + 1));
+    ENSURE(P->sign_cnt, sizeof(uint32_t) * (size_t)(ntiles + 1));
+    ENSURE(P->sign_off, sizeof(uint32_t) * (size_t)(ntiles + 1));
+    ENSURE(P->active, sizeof(uint32_t) * (size_t)ntiles);
+    ENSURE(P->counters, 64);
+    uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] n_active
+
+    HIP_TRY(hipEventRecord(P->ev[0], st));
+    // ---- node -> element CSR ----
+    HIP_TRY(hipMemsetAsync(P->deg.p, 0, sizeof(uint32_t) * (size_t)(nnp + 1), st));
+    HIP_TRY(hipMemsetAsync(P->cursor.p, 0, sizeof(uint32_t) * (size_t)(nnp + 1), st));
+    HIP_TRY(hipMemsetAsync(counters, 0, 64, st));
+    {
+        const int64_t n = nel * 8;
+        node_degree_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, 8, nnp, P->deg.as<uint32_t>(), (int*)counters);
+        int rc = scan_exclusive(P, P->deg.as<uint32_t>(), P->ine_ptr.as<uint32_t>(), nnp + 1, st);
+        if (rc) return rc;
+        ine_fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, 8, nnp, P->ine_ptr.as<uint32_t>(), P->cursor.as<uint32_t>(), P->ine.as<uint32_t>());
+    }
+    // ---- element records, classes, item counts ----
+    HIP_TRY(hipMemsetAsync(P->nitems.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
+    elem_prep_kernel<<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
+        dX, dIEN, d_rho_n, nel, rho_t, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), P->erec.as<ElemRec>(),
+        P->cls.as<uint8_t>(), P->fmask.as<uint8_t>(), P->nitems.as<uint32_t>());
+    {
+        int rc = scan_exclusive(P, P->nitems.as<uint32_t>(), P->item_off.as<uint32_t>(), nel + 1, st);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[0], P->item_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[1], counters, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (P->h_pinned[1]) return fail(R2S_ERR_ARG, "IEN contains node ids outside 1..nnp");
+    const uint32_t n_items = want_dist ? P->h_pinned[0] : 0;
+    ENSURE(P->items, sizeof(BandItem) * (size_t)std::max<uint32_t>(n_items, 1));
+    if (n_items)
+        item_build_kernel<<<(unsigned)((nel + 63) / 64), 64, 0, st>>>(
+            P->erec.as<ElemRec>(), P->cls.as<uint8_t>(), P->fmask.as<uint8_t>(), P->item_off.as<uint32_t>(), nel,
+            g, delta, P->items.as<BandItem>());
+    HIP_TRY(hipEventRecord(P->ev[1], st));
+
+    // ---- tile bins ----
+    HIP_TRY(hipMemsetAsync(P->band_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
+    HIP_TRY(hipMemsetAsync(P->sign_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
+    if (n_items)
+        band_bin_kernel<false><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr);
+    if (want_sign)
+        sign_bin_kernel<false><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr);
+    {
+        int rc = scan_exclusive(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
+        if (rc) return rc;
+        rc = scan_exclusive(P, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
+        if (rc) return rc;
+    }
+    active_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), ntiles, P->active.as<uint32_t>(), counters + 1);
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[2], P->band_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[3], P->sign_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4];
+    ENSURE(P->band_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
+    ENSURE(P->band_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
+    ENSURE(P->sign_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_sign, 1));
+    ENSURE(P->sign_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_sign, 1));
+    HIP_TRY(hipMemsetAsync(P->band_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
+    HIP_TRY(hipMemsetAsync(P->sign_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
+    if (n_items)
+        band_bin_kernel<true><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>());
+    if (want_sign)
+        sign_bin_kernel<true><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>());
+    if (n_active)
+        bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>(),
+                                                          P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>());
+    HIP_TRY(hipEventRecord(P->ev[2], st));
+
+    // ---- sentinel sweep ----
+    const unsigned fill_grid = 256 * 8;
+    if (mode & R2S_OUT_DIST) fill_kernel<<<fill_grid, 256, 0, st>>>(d_dist, nvox, 1.0e10);
+    if (mode & R2S_OUT_SIGN) fill_kernel<<<fill_grid, 256, 0, st>>>(d_sign, nvox, -1.0);
+    if (mode & R2S_OUT_SDF) fill_kernel<<<fill_grid, 256, 0, st>>>(d_sdf, nvox, -1.0e10);
+    if (mode & R2S_OUT_XP) HIP_TRY(hipMemsetAsync(d_xp, 0, sizeof(double) * 3 * (size_t)nvox, st));
+    HIP_TRY(hipEventRecord(P->ev[3], st));
+
+    // ---- projection / sign kernel over the active tiles ----
+    if (n_active) {
+        MainArgs A;
+        A.g = g; A.s = s; A.rho_t = rho_t;
+        A.active = P->active.as<uint32_t>(); A.n_active = n_active;
+        A.band_off = P->band_off.as<uint32_t>(); A.band_ent = P->band_ent.as<uint32_t>();
+        A.sign_off = P->sign_off.as<uint32_t>(); A.sign_ent = P->sign_ent.as<uint32_t>();
+        A.items = P->items.as<BandItem>(); A.erec = P->erec.as<ElemRec>();
+        A.dist = (mode & R2S_OUT_DIST) ? d_dist : nullptr;
+        A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
+        A.sdf = (mode & R2S_OUT_SDF) ? d_sdf : nullptr;
+        A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
+        const unsigned grid_main = (n_active + 3) / 4;
+        if (want_dist && want_sign) sdf_tiles_kernel<true, true><<<grid_main, 256, 0, st>>>(A);
+        else if (want_dist) sdf_tiles_kernel<true, false><<<grid_main, 256, 0, st>>>(A);
+        else sdf_tiles_kernel<false, true><<<grid_main, 256, 0, st>>>(A);
+    }
+    HIP_TRY(hipEventRecord(P->ev[4], st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_items = n_items;
+        stats->n_band_entries = n_band;
+        stats->n_sign_entries = n_sign;
+        stats->n_tiles = ntiles;
+        stats->n_active_tiles = n_active;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, P->ev[0], P->ev[1]) == hipSuccess) stats->ms_prep = ms;
+        if (hipEventElapsedTime(&ms, P->ev[1], P->ev[2]) == hipSuccess) stats->ms_bins = ms;
+        if (hipEventElapsedTime(&ms, P->ev[2], P->ev[3]) == hipSuccess) stats->ms_fill = ms;
+        if (hipEventElapsedTime(&ms, P->ev[3], P->ev[4]) == hipSuccess) stats->ms_main = ms;
+        (void)hipGetLastError();
+    }
+    return 0;
+}
+
+// ---- host-pointer entry points (what the Julia wrapper ccalls) ------------------------
+static int run_host(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
+                    double rho_t, const r2s_grid* grid, const r2s_params* params, int mode, double* dist,
+                    double* sign, double* sdf, double* xp, r2s_stats* stats)
+{
+    if (!X || !IEN || !rho_n || !grid) return fail(R2S_ERR_ARG, "null argument");
+    r2s_params prm;
+    if (params) prm = *params; else r2s_default_params(&prm);
+    r2s_plan* P = nullptr;
+    int rc = r2s_plan_create(prm.device, &P);
+    if (rc) return rc;
+    const int64_t ngp = grid->ngp;
+    double *dX = nullptr, *dR = nullptr, *dD = nullptr, *dS = nullptr, *dF = nullptr, *dP = nullptr;
+    int64_t* dI = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(dX); (void)hipFree(dR); (void)hipFree(dI); (void)hipFree(dD); (void)hipFree(dS);
+        (void)hipFree(dF); (void)hipFree(dP);
+        r2s_plan_destroy(P);
+    };
+#define HIP_TRY_C(expr)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            cleanup();                                                                        \
+            return fail(R2S_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
+        }                                                                                     \
+    } while (0)
+    HIP_TRY_C(hipMalloc((void**)&dX, sizeof(double) * 3 * (size_t)nnp));
+    HIP_TRY_C(hipMalloc((void**)&dR, sizeof(double) * (size_t)nnp));
+    HIP_TRY_C(hipMalloc((void**)&dI, sizeof(int64_t) * 8 * (size_t)nel));
+    HIP_TRY_C(hipMemcpy(dX, X, sizeof(double) * 3 * (size_t)nnp, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemcpy(dR, rho_n, sizeof(double) * (size_t)nnp, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemcpy(dI, IEN, sizeof(int64_t) * 8 * (size_t)nel, hipMemcpyHostToDevice));
+    if (mode & R2S_OUT_DIST) HIP_TRY_C(hipMalloc((void**)&dD, sizeof(double) * (size_t)ngp));
+    if (mode & R2S_OUT_SIGN) HIP_TRY_C(hipMalloc((void**)&dS, sizeof(double) * (size_t)ngp));
+    if (mode & R2S_OUT_SDF) HIP_TRY_C(hipMalloc((void**)&dF, sizeof(double) * (size_t)ngp));
+    if (mode & R2S_OUT_XP) HIP_TRY_C(hipMalloc((void**)&dP, sizeof(double) * 3 * (size_t)ngp));
+    rc = r2s_plan_run_dev(P, dX, nnp, dI, nel, dR, rho_t, grid, &prm, 0, grid->N[2] + 1, mode, dD, dS, dF, dP,
+                          nullptr, stats);
+    if (rc) { cleanup(); return rc; }
+    if (mode & R2S_OUT_DIST) HIP_TRY_C(hipMemcpy(dist, dD, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost));
+    if (mode & R2S_OUT_SIGN) HIP_TRY_C(hipMemcpy(sign, dS, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost));
+    if (mode & R2S_OUT_SDF) HIP_TRY_C(hipMemcpy(sdf, dF, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost));
+    if (mode & R2S_OUT_XP) HIP_TRY_C(hipMemcpy(xp, dP, sizeof(double) * 3 * (size_t)ngp, hipMemcpyDeviceToHost));
+    cleanup();
+    return 0;
+}
+
+int r2s_eval_distances(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
+                       double rho_t, const r2s_grid* grid, const r2s_params* params, double* dist_out,
+                       double* xp_out, r2s_stats* stats)
+{
+    if (!dist_out) return fail(R2S_ERR_ARG, "dist_out is null");
+    return run_host(X, nnp, IEN, nel, rho_n, rho_t, grid, params, R2S_OUT_DIST | (xp_out ? R2S_OUT_XP : 0),
+                    dist_out, nullptr, nullptr, xp_out, stats);
+}
+
+int r2s_sign_detection(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
+                       double rho_t, const r2s_grid* grid, const r2s_params* params, double* signs_out,
+                       r2s_stats* stats)
+{
+    if (!signs_out) return fail(R2S_ERR_ARG, "signs_out is null");
+    return run_host(X, nnp, IEN, nel, rho_n, rho_t, grid, params, R2S_OUT_SIGN, nullptr, signs_out, nullptr,
+                    nullptr, stats);
+}
+
+int r2s_sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n, double rho_t,
+            const r2s_grid* grid, const r2s_params* params, double* sdf_out, r2s_stats* stats)
+{
+    if (!sdf_out) return fail(R2S_ERR_ARG, "sdf_out is null");
+    return run_host(X, nnp, IEN, nel, rho_n, rho_t, grid, params, R2S_OUT_SDF, nullptr, nullptr, sdf_out,
+                    nullptr, stats);
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+"""Synthetic workloads named in BASELINE.md section 4 (configs 5 and NS).
+
+HEX8: n^3 cells on [-1,1]^3, interior nodes jittered by U(-0.15h, 0.15h) (seed 20240501),
+nodal density rho_n = clamp(0.5 + (0.7 - |x|)/(4h), 0, 1): the rho_t = 0.5 iso-surface is
+(close to) a sphere of radius 0.7.  Node numbering x-fastest; element node order is the
+reference's HEX8 order (bottom face CCW, then top; hex8_shape.jl:28-35).
+"""
+import numpy as np
+
+
+def hex_mesh(n, jitter=0.15, seed=20240501):
+    h = 2.0 / n
+    ax = -1.0 + h * np.arange(n + 1)
+    Z, Y, Xc = np.meshgrid(ax, ax, ax, indexing="ij")           # x fastest when flattened
+    X = np.stack([Xc.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    rng = np.random.default_rng(seed)
+    jit = rng.uniform(-jitter * h, jitter * h, X.shape)
+    idx = np.arange(n + 1)
+    interior = np.ones((n + 1,) * 3, dtype=bool)
+    interior[[0, -1], :, :] = False
+    interior[:, [0, -1], :] = False
+    interior[:, :, [0, -1]] = False
+    X = X + jit * interior.ravel()[:, None]
+    m = n + 1
+    k, j, i = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    base = (k * m * m + j * m + i).ravel()
+    off = np.array([0, 1, m + 1, m, m * m, m * m + 1, m * m + m + 1, m * m + m])
+    IEN = (base[:, None] + off[None, :] + 1).astype(np.int64)   # 1-based
+    r = np.linalg.norm(X, axis=1)
+    rho_n = np.clip(0.5 + (0.7 - r) / (4 * h), 0.0, 1.0)
+    del idx
+    return np.ascontiguousarray(X), IEN, rho_n
+
+
+def grid_n_max_for_points(npts):
+    """N_max such that Grid(..., N_max, 3) on [-1,1]^3 has `npts` points per axis
+    (N = N_max + 6 cells, +1 points; BASELINE.md: 505 -> 512)."""
+    return npts - 7

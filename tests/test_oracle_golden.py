@@ -1,0 +1,85 @@
+"""The oracle against the reference's own known answers.
+
+Known-answer values are the literals of reference test/HexSphereSdfTest.jl:26-29 and
+test/HexBlockSdfTest.jl:25-26.  The expected means encode the number of untouched (1e10)
+voxels, which match band factor 2.5, so those checks run with 2.5; the
+current source's 1.1 is checked against the integer counts established in the survey.
+"""
+import numpy as np
+import pytest
+
+from conftest import block_mesh, load_fixture
+
+
+def test_dense_in_nodes_sphere(oracle):
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    assert rn.max() == pytest.approx(1.0000000000000022, rel=1e-10, abs=1e-12)    # HexSphereSdfTest.jl:26,85
+    assert rn.mean() == pytest.approx(0.29490556408887564, rel=1e-10, abs=1e-12)  # :27,86
+
+
+def test_grid_integers(oracle):
+    X, IEN, _ = load_fixture("sphere")
+    g = oracle.grid_make(X.min(0), X.max(0), 10)
+    assert list(g.N) == [16, 16, 16] and g.ngp == 4913
+    Xb, IENb = block_mesh([2, 1, 1])
+    g = oracle.grid_make(Xb.min(0), Xb.max(0), 20)
+    assert list(g.N) == [26, 16, 16] and g.ngp == 7803
+
+
+@pytest.mark.parametrize("name,n_max,cell,N,ngp", [
+    ("beam_vfrac_03", 59, 1.0169491525423728, [66, 26, 10], 19899),
+    ("chapadlo", 58, 4.051724137931035, [25, 44, 64], 76050),
+])
+def test_auto_grid(oracle, name, n_max, cell, N, ngp):
+    X, IEN, _ = load_fixture(name)
+    g, med = oracle.auto_grid(X, IEN)
+    assert list(g.N) == N and g.ngp == ngp
+    assert g.cell == cell
+    assert int(np.floor((X.max(0) - X.min(0)).max() / med)) == n_max
+
+
+def _sdf(oracle, X, IEN, rn, g, bf):
+    dist, xp, st = oracle.eval_distances(X, IEN, rn, 0.5, g, bf)
+    s = oracle.sign_detection(X, IEN, rn, 0.5, g)
+    return dist, s, dist * s, st
+
+
+def test_sphere_known_answers(oracle):
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    g = oracle.grid_make(X.min(0), X.max(0), 10)
+    dist, s, sdf, st = _sdf(oracle, X, IEN, rn, g, 2.5)
+    assert (dist == 1e10).sum() == 1836                      # decoded from HexSphereSdfTest.jl:29
+    assert (sdf == 1e10).sum() == 0
+    assert sdf.max() == pytest.approx(0.8669785608800439, rel=1e-10, abs=1e-12)   # :28,137
+    assert sdf.mean() == pytest.approx(-3.7370242217627172e9, abs=1e5)            # :29,140
+    assert set(np.unique(s)) <= {-1.0, 1.0} and (dist >= 0).all()
+    # current source (band factor 1.1): integer count from the survey
+    dist11, _, _, _ = _sdf(oracle, X, IEN, rn, g, 1.1)
+    assert (dist11 == 1e10).sum() == 3205
+
+
+def test_block_known_answers(oracle):
+    X, IEN = block_mesh([2, 1, 1])
+    rn = np.array([0.0, 0.0, 0.5, 0.5, 0.5, 0.5, 1.0, 1.0, 0.0, 0.0, 0.5, 0.5])   # HexBlockSdfTest.jl:55
+    g = oracle.grid_make(X.min(0), X.max(0), 20)
+    dist, s, sdf, st = _sdf(oracle, X, IEN, rn, g, 2.5)
+    assert (dist == 1e10).sum() == 1147
+    assert sdf.max() == pytest.approx(0.4242640687119285, rel=1e-10, abs=1e-12)   # :25
+    assert sdf.mean() == pytest.approx(-1.4699474563515213e9, abs=1e5)            # :26
+    assert (sdf > 0).sum() > 0 and (sdf < 0).sum() > 0
+    dist11, _, _, _ = _sdf(oracle, X, IEN, rn, g, 1.1)
+    assert (dist11 == 1e10).sum() == 3747
+
+
+def test_sign_elementmajor_equals_literal(oracle):
+    """the element-major traversal used for larger grids == the literal O(ngp*nel) form"""
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    for n in (5, 10):
+        g = oracle.grid_make(X.min(0), X.max(0), n)
+        for rt in (0.1, 0.5, 0.9):
+            a = oracle.sign_detection(X, IEN, rn, rt, g)
+            b = oracle.sign_detection(X, IEN, rn, rt, g, bruteforce=True)
+            assert np.array_equal(a, b)

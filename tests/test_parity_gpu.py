@@ -1,0 +1,125 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): sentinel set and sign bit-exact, Float64 distances within
+1e-6 relative.  The kernels keep the oracle's operation order, so distances are also
+expected to agree far tighter than the bar; the achieved maximum is printed.
+"""
+import numpy as np
+import pytest
+
+from conftest import block_mesh, load_fixture
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def _compare(pkg, oracle, X, IEN, rn, rt, pg, og, bf, label):
+    mesh = pkg.Mesh(X, IEN)
+    st = {}
+    dist, xp = pkg.evalDistances(mesh, pg, rn, rt, band_factor=bf, stats=st)
+    sign = pkg.Sign_Detection(mesh, pg, rn, rt)
+    sdf = pkg.sdf_fused(mesh, pg, rn, rt, band_factor=bf)
+    odist, oxp, ost = oracle.eval_distances(X, IEN, rn, rt, og, bf)
+    osign = oracle.sign_detection(X, IEN, rn, rt, og)
+    sent = odist == 1e10
+    assert np.array_equal(dist == 1e10, sent), f"{label}: sentinel set differs"
+    assert np.array_equal(sign, osign), f"{label}: sign differs at {np.flatnonzero(sign != osign)[:10]}"
+    real = ~sent
+    rel = np.abs(dist[real] - odist[real]) / np.maximum(odist[real], 1e-300)
+    # |d| ~ 0 voxels: compare absolutely against the cell size
+    bad = (rel > RTOL) & (np.abs(dist[real] - odist[real]) > 1e-12 * og.cell)
+    assert not bad.any(), f"{label}: {bad.sum()} distances beyond {RTOL}, max rel {rel.max()}"
+    assert np.array_equal(sdf, dist * sign), f"{label}: fused sdf != dist*sign"
+    assert np.allclose(xp[real], oxp[real], rtol=0, atol=1e-9 * max(1.0, np.abs(X).max()))
+    assert np.array_equal(xp[sent], np.zeros_like(xp[sent]))
+    print(f"{label}: ngp {og.ngp} sentinels {int(sent.sum())} +1 signs {int((sign > 0).sum())} "
+          f"max rel err {rel.max() if rel.size else 0:.3e} bit-equal {int((dist[real] == odist[real]).sum())}/{int(real.sum())} "
+          f"items {st.get('n_items')} active tiles {st.get('n_active_tiles')}")
+
+
+@pytest.mark.parametrize("bf", [1.1, 2.5])
+@pytest.mark.parametrize("nmax", [10, 25])
+def test_sphere(pkg, oracle, bf, nmax):
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
+    _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, bf, f"sphere N{nmax} bf{bf}")
+
+
+def test_sphere_known_answers_on_gpu(pkg, oracle):
+    """reference test/HexSphereSdfTest.jl:28-29 evaluated with the HIP path"""
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    pg = pkg.Grid(X.min(0), X.max(0), 10, 3)
+    sdf = pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5, band_factor=2.5)
+    assert (np.abs(sdf) == 1e10).sum() == 1836
+    assert sdf.max() == pytest.approx(0.8669785608800439, rel=1e-10, abs=1e-12)
+    assert sdf.mean() == pytest.approx(-3.7370242217627172e9, abs=1e5)
+
+
+@pytest.mark.parametrize("rt", [0.1, 0.9])
+def test_sphere_edge_thresholds(pkg, oracle, rt):
+    """HexSphereSdfTest.jl:182-195: rho_t in {0.1, 0.9} on a 5-cell grid"""
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    pg = pkg.Grid(X.min(0), X.max(0), 5, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), 5, 3)
+    _compare(pkg, oracle, X, IEN, rn, rt, pg, og, 1.1, f"sphere rt{rt}")
+
+
+@pytest.mark.parametrize("bf", [1.1, 2.5])
+def test_block(pkg, oracle, bf):
+    X, IEN = block_mesh([2, 1, 1])
+    rn = np.array([0.0, 0.0, 0.5, 0.5, 0.5, 0.5, 1.0, 1.0, 0.0, 0.0, 0.5, 0.5])
+    pg = pkg.Grid(X.min(0), X.max(0), 20, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), 20, 3)
+    _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, bf, f"block bf{bf}")
+    if bf == 2.5:
+        sdf = pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5, band_factor=2.5)
+        assert sdf.max() == pytest.approx(0.4242640687119285, rel=1e-10, abs=1e-12)   # HexBlockSdfTest.jl:25
+        assert sdf.mean() == pytest.approx(-1.4699474563515213e9, abs=1e5)            # :26
+
+
+@pytest.mark.parametrize("name,rt", [("beam_vfrac_03", 0.5), ("beam_vfrac_04", 0.518555), ("chapadlo", 0.5)])
+def test_fixture_meshes_auto_grid(pkg, oracle, name, rt):
+    """BASELINE configs 2-4 at the reference's automatic grid (solid elements + boundary faces)"""
+    X, IEN, rho = load_fixture(name)
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
+    og, _ = oracle.auto_grid(X, IEN)
+    _compare(pkg, oracle, X, IEN, rn, rt, pg, og, 1.1, name)
+
+
+def test_synthetic_jittered_hex(pkg, oracle):
+    """north-star mesh family at a size the oracle finishes in seconds: 12^3 HEX8, 64^3 grid"""
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, rn = synthetic.hex_mesh(12)
+    nmax = synthetic.grid_n_max_for_points(64)
+    pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
+    assert pg.dims == (64, 64, 64)
+    _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, 1.1, "synthetic 12^3 / 64^3")
+
+
+def test_slabs_equal_full_volume(pkg, oracle):
+    """Z-slab runs (the multi-GPU partition) stitched together == one full-volume run"""
+    import torch
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, rn = synthetic.hex_mesh(8)
+    pg = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(40), 3)
+    dev = torch.device("cuda:0")
+    dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rn))
+    plan = pkg.DevicePlan(0)
+    nx, ny, nz = pg.dims
+    full = torch.empty(nz * ny * nx, dtype=torch.float64, device=dev)
+    plan.run(dX, dI, dR, 0.5, pg, sdf=full)
+    for parts in (2, 3, 8):
+        bounds = [round(nz * p / parts) for p in range(parts + 1)]
+        pieces = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            out = torch.empty((b - a) * ny * nx, dtype=torch.float64, device=dev)
+            plan.run(dX, dI, dR, 0.5, pg, k_begin=a, k_end=b, sdf=out)
+            pieces.append(out)
+        assert torch.equal(torch.cat(pieces), full), f"{parts} slabs differ from the full volume"
+    plan.close()
