@@ -67,8 +67,11 @@ typedef struct {
     int64_t n_band_entries; /* tile->item list entries                     */
     int64_t n_sign_entries; /* tile->element list entries                  */
     int64_t n_tiles;        /* 4x4x4 voxel tiles in the slab               */
-    int64_t n_active_tiles; /* tiles that ran the projection kernel        */
-    double ms_prep, ms_bins, ms_fill, ms_main; /* HIP-event times of the last call */
+    int64_t n_active_tiles; /* tiles that ran the distance kernel          */
+    int64_t n_active_sign_tiles; /* tiles that ran the sign kernel         */
+    /* HIP-event times of the last call, measured on the call's stream:
+     * mesh prep+items, tile bins, sentinel sweep, distance kernel, sign kernel */
+    double ms_prep, ms_bins, ms_fill, ms_main, ms_sign;
 } r2s_stats;
 
 int r2s_version(void);

@@ -210,7 +210,7 @@ static int lu_solve(int n, double *A /* n*n row-major, destroyed */, double *b)
 /* (10,10,10) like the reference's failure path (:106).                */
 /* ------------------------------------------------------------------ */
 #define INV_MAXIT 50
-#define INV_TOL 1e-13
+#define INV_TOL 1e-10
 static int inv_map_hex8(const double Xe[8][3], const double x[3], double xi[3])
 {
     xi[0] = xi[1] = xi[2] = 0.0;
@@ -219,11 +219,11 @@ static int inv_map_hex8(const double Xe[8][3], const double x[3], double xi[3])
         hex8_shape_d(xi, N, dN);
         for (int i = 0; i < 3; ++i) {
             double s = 0.0;
-            for (int k = 0; k < 8; ++k) s += Xe[k][i] * N[k];
+            for (int k = 0; k < 8; ++k) s = fma(Xe[k][i], N[k], s);
             R[i] = s - x[i];
             for (int j = 0; j < 3; ++j) {
                 double t = 0.0;
-                for (int k = 0; k < 8; ++k) t += Xe[k][i] * dN[k][j];
+                for (int k = 0; k < 8; ++k) t = fma(Xe[k][i], dN[k][j], t);
                 J[i][j] = t;
             }
         }
@@ -277,7 +277,7 @@ static int inv_map_hex8(const double Xe[8][3], const double x[3], double xi[3])
 /*   - backtracking on the L1 merit f + mu |c|.                         */
 /* ------------------------------------------------------------------ */
 #define ISO_MAXIT 60
-#define ISO_TOL 1e-10
+#define ISO_TOL 1e-8
 #define QP_PTOL 1e-12
 
 typedef struct {
@@ -293,11 +293,11 @@ static inline iso_fc iso_eval_fc(const double x[3], const double Xe[8][3], const
     double f = 0.0, rho = 0.0;
     for (int i = 0; i < 3; ++i) {
         double s = 0.0;
-        for (int k = 0; k < 8; ++k) s += Xe[k][i] * N[k];
+        for (int k = 0; k < 8; ++k) s = fma(Xe[k][i], N[k], s);
         double r = x[i] - s;
         f += r * r;
     }
-    for (int k = 0; k < 8; ++k) rho += re[k] * N[k];
+    for (int k = 0; k < 8; ++k) rho = fma(re[k], N[k], rho);
     o.f = f;
     o.c = rho - rt;
     return o;
@@ -399,20 +399,20 @@ int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, con
         double f = 0.0, rho = 0.0;
         for (int i = 0; i < 3; ++i) {
             double s = 0.0;
-            for (int k = 0; k < 8; ++k) s += Xe[k][i] * N[k];
+            for (int k = 0; k < 8; ++k) s = fma(Xe[k][i], N[k], s);
             r[i] = x[i] - s;
             f += r[i] * r[i];
             for (int j = 0; j < 3; ++j) {
                 double t = 0.0;
-                for (int k = 0; k < 8; ++k) t += Xe[k][i] * dN[k][j];
+                for (int k = 0; k < 8; ++k) t = fma(Xe[k][i], dN[k][j], t);
                 J[i][j] = t;
             }
         }
-        for (int k = 0; k < 8; ++k) rho += re[k] * N[k];
+        for (int k = 0; k < 8; ++k) rho = fma(re[k], N[k], rho);
         double c = rho - rt;
         for (int j = 0; j < 3; ++j) {
             double t = 0.0;
-            for (int k = 0; k < 8; ++k) t += re[k] * dN[k][j];
+            for (int k = 0; k < 8; ++k) t = fma(re[k], dN[k][j], t);
             a[j] = t;
             g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
         }
@@ -434,8 +434,8 @@ int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, con
         for (int q = 0; q < 3; ++q) {
             double pr = 0.0, rr = 0.0;
             for (int k = 0; k < 8; ++k) {
-                pr += (r[0] * Xe[k][0] + r[1] * Xe[k][1] + r[2] * Xe[k][2]) * m2[k][q];
-                rr += re[k] * m2[k][q];
+                pr = fma(r[0] * Xe[k][0] + r[1] * Xe[k][1] + r[2] * Xe[k][2], m2[k][q], pr);
+                rr = fma(re[k], m2[k][q], rr);
             }
             S[q] = -2.0 * pr + lam * rr;
         }
@@ -484,14 +484,25 @@ int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, con
                     d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
                     lam_new = l2;
                 } else {
+                    /* patterns with 0, 1, 2 fixed variables (3 fixed cannot meet the
+                     * equality); the first one satisfying KKT is the minimiser of the
+                     * convex QP; failing that (rounding), the feasible one of least value */
+                    static const int order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8,
+                                                  10, 11, 19, 20, 12, 15, 21, 24};
                     double bestq = INFINITY;
-                    for (int p = 0; p < 27; ++p) {
-                        if (qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt) && q < bestq) {
-                            bestq = q;
-                            found = 1;
-                            pat = p;
-                            d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
-                            lam_new = l2;
+                    const int convex = spd3(H, 0.0); /* early exit only for a convex QP */
+                    for (int ip = 0; ip < 19; ++ip) {
+                        const int p = order[ip];
+                        if (qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt)) {
+                            kkt = kkt && convex;
+                            if (kkt || q < bestq) {
+                                bestq = q;
+                                found = 1;
+                                pat = p;
+                                d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
+                                lam_new = l2;
+                            }
+                            if (kkt) break;
                         }
                     }
                 }

@@ -129,13 +129,13 @@ R2S_DEV bool inv_map_hex8(const ElemRec& E, const double x[3], double xi[3])
         for (int i = 0; i < 3; ++i) {
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s += E.X[k][i] * N[k];
+            for (int k = 0; k < 8; ++k) s = fma(E.X[k][i], N[k], s);
             R[i] = s - x[i];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 double t = 0.0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) t += E.X[k][i] * dN[k][j];
+                for (int k = 0; k < 8; ++k) t = fma(E.X[k][i], dN[k][j], t);
                 J[i][j] = t;
             }
         }
@@ -157,7 +157,7 @@ R2S_DEV bool inv_map_hex8(const ElemRec& E, const double x[3], double xi[3])
         double n2 = fmin(fmax(xi[2] + d2, -1.1), 1.1);
         double step = fmax(fabs(n0 - xi[0]), fmax(fabs(n1 - xi[1]), fabs(n2 - xi[2])));
         xi[0] = n0; xi[1] = n1; xi[2] = n2;
-        if (!(step > 1e-13)) {
+        if (!(step > 1e-10)) {
             if (step != step) break;
             return true;
         }
@@ -247,6 +247,20 @@ R2S_DEV bool qp_pattern(int pat, const double H[3][3], const double g[3], const 
     return true;
 }
 
+__constant__ int c_pat_order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8, 10, 11, 19, 20, 12, 15, 21, 24};
+
+R2S_DEV bool spd3(const double H[3][3])
+{
+    const double D0 = H[0][0];
+    if (!(D0 > 0.0)) return false;
+    const double l10 = H[1][0] / D0, l20 = H[2][0] / D0;
+    const double D1 = H[1][1] - l10 * H[1][0];
+    if (!(D1 > 0.0)) return false;
+    const double l21 = (H[2][1] - l20 * H[1][0]) / D1;
+    const double D2 = H[2][2] - l20 * H[2][0] - l21 * l21 * D1;
+    return D2 > 0.0;
+}
+
 R2S_DEV void iso_eval_fc(const ElemRec& E, const double x[3], double rt, const double xi[3], double& f,
                          double& c)
 {
@@ -257,18 +271,18 @@ R2S_DEV void iso_eval_fc(const ElemRec& E, const double x[3], double rt, const d
     for (int i = 0; i < 3; ++i) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += E.X[k][i] * N[k];
+        for (int k = 0; k < 8; ++k) s = fma(E.X[k][i], N[k], s);
         double r = x[i] - s;
         ff += r * r;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rho += E.r[k] * N[k];
+    for (int k = 0; k < 8; ++k) rho = fma(E.r[k], N[k], rho);
     f = ff;
     c = rho - rt;
 }
 
 #define R2S_ISO_MAXIT 60
-#define R2S_ISO_TOL 1e-10
+#define R2S_ISO_TOL 1e-8
 
 // returns iterations used (R2S_ISO_MAXIT+1 when not converged)
 R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, double xi[3])
@@ -284,25 +298,25 @@ R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, dou
         for (int i = 0; i < 3; ++i) {
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s += E.X[k][i] * N[k];
+            for (int k = 0; k < 8; ++k) s = fma(E.X[k][i], N[k], s);
             r[i] = x[i] - s;
             f += r[i] * r[i];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 double t = 0.0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) t += E.X[k][i] * dN[k][j];
+                for (int k = 0; k < 8; ++k) t = fma(E.X[k][i], dN[k][j], t);
                 J[i][j] = t;
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) rho += E.r[k] * N[k];
+        for (int k = 0; k < 8; ++k) rho = fma(E.r[k], N[k], rho);
         const double c = rho - rt;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t += E.r[k] * dN[k][j];
+            for (int k = 0; k < 8; ++k) t = fma(E.r[k], dN[k][j], t);
             a[j] = t;
             g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
         }
@@ -326,8 +340,8 @@ R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, dou
             double pr = 0.0, rr = 0.0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                pr += (r[0] * E.X[k][0] + r[1] * E.X[k][1] + r[2] * E.X[k][2]) * m2[k][q];
-                rr += E.r[k] * m2[k][q];
+                pr = fma(r[0] * E.X[k][0] + r[1] * E.X[k][1] + r[2] * E.X[k][2], m2[k][q], pr);
+                rr = fma(E.r[k], m2[k][q], rr);
             }
             S[q] = -2.0 * pr + lam * rr;
         }
@@ -382,14 +396,22 @@ R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, dou
                     d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
                     lam_new = o.lam;
                 } else {
+                    // patterns with 0, 1, 2 fixed variables; the first KKT pattern of a convex
+                    // QP is its minimiser, otherwise the feasible pattern of least value
                     double bestq = INFINITY;
-                    for (int p = 0; p < 27; ++p) {
-                        if (qp_pattern(p, H, gp, a, e, lo, hi, o) && o.q < bestq) {
-                            bestq = o.q;
-                            found = true;
-                            pat = p;
-                            d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
-                            lam_new = o.lam;
+                    const bool convex = spd3(H);
+                    for (int ip = 0; ip < 19; ++ip) {
+                        const int p = c_pat_order[ip];
+                        if (qp_pattern(p, H, gp, a, e, lo, hi, o)) {
+                            const bool kkt = o.kkt && convex;
+                            if (kkt || o.q < bestq) {
+                                bestq = o.q;
+                                found = true;
+                                pat = p;
+                                d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
+                                lam_new = o.lam;
+                            }
+                            if (kkt) break;
                         }
                     }
                 }

@@ -398,57 +398,56 @@ __global__ void band_bin_kernel(const BandItem* __restrict__ items, uint32_t nit
 
 template <bool FILL>
 __global__ void sign_bin_kernel(const ElemRec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s,
-                                uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
-                                uint32_t* __restrict__ entries)
+                                double rho_t, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                uint32_t* __restrict__ entries, uint8_t* __restrict__ hot)
 {
     uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nel) return;
     int lo[3], hi[3];
     if (!sign_tile_range(erec[el], g, s, lo, hi)) return;
+    // a voxel is only examined when some candidate reaches rho_t (SignDetection.jl:36):
+    // tiles whose lists hold no such element keep sign = -1 without running the kernel
+    const bool is_hot = !FILL && !(erec[el].rmax < rho_t);
     for (int tz = lo[2]; tz <= hi[2]; ++tz)
         for (int ty = lo[1]; ty <= hi[1]; ++ty)
             for (int tx = lo[0]; tx <= hi[0]; ++tx) {
                 const uint32_t t = ((uint32_t)tz * s.nty + ty) * s.ntx + tx;
                 const uint32_t pos = atomicAdd(&cnt[t], 1u);
                 if (FILL) entries[off[t] + pos] = el;
+                else if (is_hot) hot[t] = 1;
             }
 }
 
 // active tiles = tiles with a non-empty band list, or a sign list whose elements reach rho_t
 __global__ void active_tiles_kernel(const uint32_t* __restrict__ band_cnt,
-                                    const uint32_t* __restrict__ sign_cnt, uint32_t ntiles,
-                                    uint32_t* __restrict__ active, uint32_t* __restrict__ n_active)
+                                    const uint32_t* __restrict__ sign_cnt,
+                                    const uint8_t* __restrict__ hot, uint32_t ntiles,
+                                    uint32_t* __restrict__ active_band, uint32_t* __restrict__ active_sign,
+                                    uint32_t* __restrict__ counters)
 {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
-    if (band_cnt[t] | sign_cnt[t]) active[atomicAdd(n_active, 1u)] = t;
+    if (band_cnt[t]) active_band[atomicAdd(&counters[1], 1u)] = t;
+    if (sign_cnt[t] && hot[t]) active_sign[atomicAdd(&counters[2], 1u)] = t;
 }
 
 // one wavefront per active tile: rank-sort both lists ascending (the reference visits
 // elements 1..nel in order; the ordered gather needs the same order).
 __global__ void __launch_bounds__(256) bin_sort_kernel(const uint32_t* __restrict__ active, uint32_t n_active,
-                                                      const uint32_t* __restrict__ off_a,
-                                                      const uint32_t* __restrict__ in_a,
-                                                      uint32_t* __restrict__ out_a,
-                                                      const uint32_t* __restrict__ off_b,
-                                                      const uint32_t* __restrict__ in_b,
-                                                      uint32_t* __restrict__ out_b)
+                                                      const uint32_t* __restrict__ off,
+                                                      const uint32_t* __restrict__ in,
+                                                      uint32_t* __restrict__ out)
 {
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (w >= n_active) return;
     const uint32_t t = active[w];
-    for (int which = 0; which < 2; ++which) {
-        const uint32_t* off = which ? off_b : off_a;
-        const uint32_t* in = which ? in_b : in_a;
-        uint32_t* out = which ? out_b : out_a;
-        const uint32_t b = off[t], n = off[t + 1] - b;
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t v = in[b + i];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; ++j) rank += (in[b + j] < v) ? 1u : 0u;
-            out[b + rank] = v;
-        }
+    const uint32_t b = off[t], n = off[t + 1] - b;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t v = in[b + i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += (in[b + j] < v) ? 1u : 0u;
+        out[b + rank] = v;
     }
 }
 
@@ -486,6 +485,7 @@ struct MainArgs {
     double* sign;
     double* sdf;
     double* xp;
+    int sdf_mode;  // 1: sdf = dist*sign in one kernel; 2: dist pass stores -dist; 3: sign pass flips
 };
 
 template <bool DO_DIST, bool DO_SIGN>
@@ -553,7 +553,13 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
         const int64_t v = ((int64_t)kl * A.g.ny + j) * A.g.nx + i;
         if (A.dist) A.dist[v] = st.cur;
         if (A.sign) A.sign[v] = sg;
-        if (A.sdf) A.sdf[v] = st.cur * sg;
+        if (A.sdf) {
+            // fused output dist*sign (RhoToSDF.jl:171) in two passes: the distance pass stores
+            // dist * (-1), the sign pass negates where the sign is +1 (bit-identical products)
+            if (A.sdf_mode == 1) A.sdf[v] = st.cur * sg;
+            else if (A.sdf_mode == 2) A.sdf[v] = -st.cur;
+            else if (sg > 0.0) A.sdf[v] = -A.sdf[v];
+        }
         if (A.xp) {
             A.xp[3 * v] = st.xp[0];
             A.xp[3 * v + 1] = st.xp[1];
@@ -597,9 +603,9 @@ struct r2s_plan {
     int device = 0;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
-    DevBuf active, counters, scan_tmp[3];
-    uint32_t* h_pinned = nullptr;  // 8 words
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf active, active_sign, hot, counters, scan_tmp[3];
+    uint32_t* h_pinned = nullptr;  // 16 words
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static int scan_exclusive(r2s_plan* P, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st, int level = 0)
@@ -728,7 +734,7 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     r2s_plan* P = new r2s_plan();
     P->device = device;
     HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocDefault));
-    for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
+    for (int i = 0; i < 6; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
     *out = P;
     return 0;
 }
@@ -739,11 +745,12 @@ void r2s_plan_destroy(r2s_plan* P)
     (void)hipSetDevice(P->device);
     DevBuf* all[] = {&P->deg, &P->ine_ptr, &P->ine, &P->cursor, &P->erec, &P->cls, &P->fmask, &P->nitems,
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
-                     &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->counters,
+                     &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign,
+                     &P->hot, &P->counters,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
     for (DevBuf* b : all) b->release();
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 6; ++i)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
     delete P;
 }
@@ -810,8 +817,10 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     ENSURE(P->sign_cnt, sizeof(uint32_t) * (size_t)(ntiles + 1));
     ENSURE(P->sign_off, sizeof(uint32_t) * (size_t)(ntiles + 1));
     ENSURE(P->active, sizeof(uint32_t) * (size_t)ntiles);
+    ENSURE(P->active_sign, sizeof(uint32_t) * (size_t)ntiles);
+    ENSURE(P->hot, (size_t)ntiles + 1);
     ENSURE(P->counters, 64);
-    uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] n_active
+    uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] band tiles, [2] sign tiles
 
     HIP_TRY(hipEventRecord(P->ev[0], st));
     // ---- node -> element CSR ----
@@ -849,22 +858,24 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     // ---- tile bins ----
     HIP_TRY(hipMemsetAsync(P->band_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
     HIP_TRY(hipMemsetAsync(P->sign_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
+    HIP_TRY(hipMemsetAsync(P->hot.p, 0, (size_t)ntiles + 1, st));
     if (n_items)
         band_bin_kernel<false><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr);
     if (want_sign)
-        sign_bin_kernel<false><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr);
+        sign_bin_kernel<false><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, rho_t, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>());
     {
         int rc = scan_exclusive(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
         if (rc) return rc;
         rc = scan_exclusive(P, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
         if (rc) return rc;
     }
-    active_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), ntiles, P->active.as<uint32_t>(), counters + 1);
+    active_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), counters);
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[2], P->band_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[3], P->sign_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4];
+    const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4],
+                   n_active_sign = P->h_pinned[5];
     ENSURE(P->band_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
     ENSURE(P->band_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
     ENSURE(P->sign_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_sign, 1));
@@ -874,10 +885,11 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     if (n_items)
         band_bin_kernel<true><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>());
     if (want_sign)
-        sign_bin_kernel<true><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>());
+        sign_bin_kernel<true><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, rho_t, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), nullptr);
     if (n_active)
-        bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>(),
-                                                          P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>());
+        bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
+    if (n_active_sign)
+        bin_sort_kernel<<<(n_active_sign + 3) / 4, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>());
     HIP_TRY(hipEventRecord(P->ev[2], st));
 
     // ---- sentinel sweep ----
@@ -889,23 +901,34 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     HIP_TRY(hipEventRecord(P->ev[3], st));
 
     // ---- projection / sign kernel over the active tiles ----
-    if (n_active) {
+    {
         MainArgs A;
         A.g = g; A.s = s; A.rho_t = rho_t;
-        A.active = P->active.as<uint32_t>(); A.n_active = n_active;
         A.band_off = P->band_off.as<uint32_t>(); A.band_ent = P->band_ent.as<uint32_t>();
         A.sign_off = P->sign_off.as<uint32_t>(); A.sign_ent = P->sign_ent.as<uint32_t>();
         A.items = P->items.as<BandItem>(); A.erec = P->erec.as<ElemRec>();
         A.dist = (mode & R2S_OUT_DIST) ? d_dist : nullptr;
         A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
         A.sdf = (mode & R2S_OUT_SDF) ? d_sdf : nullptr;
-        A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
-        const unsigned grid_main = (n_active + 3) / 4;
-        if (want_dist && want_sign) sdf_tiles_kernel<true, true><<<grid_main, 256, 0, st>>>(A);
-        else if (want_dist) sdf_tiles_kernel<true, false><<<grid_main, 256, 0, st>>>(A);
-        else sdf_tiles_kernel<false, true><<<grid_main, 256, 0, st>>>(A);
+        // distance pass over the tiles that hold band work items
+        if (want_dist && n_active) {
+            A.active = P->active.as<uint32_t>(); A.n_active = n_active;
+            A.sign = nullptr;
+            A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
+            A.sdf_mode = 2;
+            sdf_tiles_kernel<true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+        }
+        HIP_TRY(hipEventRecord(P->ev[4], st));
+        // sign pass over the tiles whose candidate elements reach rho_t
+        if (want_sign && n_active_sign) {
+            A.active = P->active_sign.as<uint32_t>(); A.n_active = n_active_sign;
+            A.dist = nullptr; A.xp = nullptr;
+            A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
+            A.sdf_mode = 3;
+            sdf_tiles_kernel<false, true><<<(n_active_sign + 3) / 4, 256, 0, st>>>(A);
+        }
     }
-    HIP_TRY(hipEventRecord(P->ev[4], st));
+    HIP_TRY(hipEventRecord(P->ev[5], st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
 
@@ -916,11 +939,13 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
         stats->n_sign_entries = n_sign;
         stats->n_tiles = ntiles;
         stats->n_active_tiles = n_active;
+        stats->n_active_sign_tiles = n_active_sign;
         float ms = 0;
         if (hipEventElapsedTime(&ms, P->ev[0], P->ev[1]) == hipSuccess) stats->ms_prep = ms;
         if (hipEventElapsedTime(&ms, P->ev[1], P->ev[2]) == hipSuccess) stats->ms_bins = ms;
         if (hipEventElapsedTime(&ms, P->ev[2], P->ev[3]) == hipSuccess) stats->ms_fill = ms;
         if (hipEventElapsedTime(&ms, P->ev[3], P->ev[4]) == hipSuccess) stats->ms_main = ms;
+        if (hipEventElapsedTime(&ms, P->ev[4], P->ev[5]) == hipSuccess) stats->ms_sign = ms;
         (void)hipGetLastError();
     }
     return 0;

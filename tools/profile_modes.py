@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Stage timing of the hot path per output mode (dist / sign / fused) on the NS workload."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--grid", type=int, default=512)
+ap.add_argument("--mesh", type=int, default=46)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--modes", default="dist,sign,sdf")
+a = ap.parse_args()
+pkg = graft.build()
+import torch
+from rho2sdf_jl_amd import synthetic
+X, IEN, rn = synthetic.hex_mesh(a.mesh)
+g = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(a.grid), 3)
+dev = torch.device("cuda:0")
+dX, dI, dR = (torch.from_numpy(t).to(dev) for t in (X, IEN, rn))
+out = torch.empty(g.ngp, dtype=torch.float64, device=dev)
+plan = pkg.DevicePlan(0)
+for mode in a.modes.split(","):
+    for r in range(a.reps):
+        st = plan.run(dX, dI, dR, 0.5, g, **{mode: out})
+    print(mode, json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}))
