@@ -131,7 +131,7 @@ def main():
 
     if rank == 0:
         sts = [s for s in stats_acc if s]
-        avg = {k: float(np.mean([s[k] for s in sts])) for k in ("ms_prep", "ms_bins", "ms_fill", "ms_main", "ms_sign")}
+        avg = {k: float(np.mean([s[k] for s in sts])) for k in ("ms_prep", "ms_bins", "ms_fill", "ms_main", "ms_gather", "ms_sign")}
         st0 = sts[-1]
         nvox_rank = (k1 - k0) * plane
         mesh_bytes = X.nbytes + IEN.nbytes + rho_n.nbytes
@@ -147,7 +147,7 @@ def main():
                                    f"{nx}x{ny}x{nz} grid (N_max={n_max}), rho_t=0.5, band factor 1.1, "
                                    f"fused dist*sign, Z-slabs over {world} GPU(s)",
                        "elements": int(len(IEN)), "voxels": int(ngp), "parallelism": f"zslab{world}"},
-            "roofline": {"bound": "hbm", "kernel": "sdf_tiles_kernel<true,false> (distance pass)",
+            "roofline": {"bound": "hbm", "kernel": "iso_project_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["ms_main"],

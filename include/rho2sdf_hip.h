@@ -69,9 +69,11 @@ typedef struct {
     int64_t n_tiles;        /* 4x4x4 voxel tiles in the slab               */
     int64_t n_active_tiles; /* tiles that ran the distance kernel          */
     int64_t n_active_sign_tiles; /* tiles that ran the sign kernel         */
-    /* HIP-event times of the last call, measured on the call's stream:
-     * mesh prep+items, tile bins, sentinel sweep, distance kernel, sign kernel */
-    double ms_prep, ms_bins, ms_fill, ms_main, ms_sign;
+    int64_t n_iso_chunks;   /* 64-voxel chunks swept by iso_project_kernel    */
+    /* HIP-event times of the last call, measured on the call's stream: mesh prep+items,
+     * tile bins, sentinel sweep, iso_project_kernel (ms_main), ordered gather
+     * (sdf_tiles_kernel<dist>), sign kernel */
+    double ms_prep, ms_bins, ms_fill, ms_main, ms_gather, ms_sign;
 } r2s_stats;
 
 int r2s_version(void);

@@ -28,9 +28,10 @@ class R2SStats(ctypes.Structure):
     _fields_ = [("n_solid", ctypes.c_int64), ("n_iso", ctypes.c_int64), ("n_items", ctypes.c_int64),
                 ("n_band_entries", ctypes.c_int64), ("n_sign_entries", ctypes.c_int64),
                 ("n_tiles", ctypes.c_int64), ("n_active_tiles", ctypes.c_int64),
-                ("n_active_sign_tiles", ctypes.c_int64),
+                ("n_active_sign_tiles", ctypes.c_int64), ("n_iso_chunks", ctypes.c_int64),
                 ("ms_prep", ctypes.c_double), ("ms_bins", ctypes.c_double),
-                ("ms_fill", ctypes.c_double), ("ms_main", ctypes.c_double), ("ms_sign", ctypes.c_double)]
+                ("ms_fill", ctypes.c_double), ("ms_main", ctypes.c_double),
+                ("ms_gather", ctypes.c_double), ("ms_sign", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -36,7 +36,12 @@ struct alignas(16) BandItem {
     int32_t im;    // row of the barycentric system replaced by ones (TriangularMeshUtils.jl:19-21)
     int32_t p0, p1;  // partial-pivot row swaps of the 3x3 LU
     int32_t sing;  // LU hit a zero pivot
-    int32_t pad[4];
+    // iso items only: lattice box (voxels whose cell can lie in the cell box, clipped to the
+    // Z-slab) that the item-major projection kernel sweeps, and its result slots
+    int32_t lo[3];
+    int32_t dim[3];      // 0 in any axis = empty
+    uint32_t chunk_off;  // first 64-voxel chunk of this item in the result array
+    int32_t pad[1];
     double tri[3][3];  // vertices x1,x2,x3
     double n[3];       // unit normal
     double L[3];       // edge lengths
@@ -577,6 +582,21 @@ R2S_DEV void process_triangle(VoxState& s, const BandItem& T, const ElemRec& E, 
 }
 
 // iso-surface candidate of one voxel (process_isocontour_element!, :612-623)
+R2S_DEV double iso_candidate(const ElemRec& E, double rt, const double x[3], double xp[3])
+{
+    double xi[3], N[8];
+    iso_project_hex8(E, x, rt, xi);
+    hex8_shape(xi, N);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += E.X[k][i] * N[k];
+        xp[i] = t;
+    }
+    return norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]);
+}
+
 R2S_DEV void process_iso(VoxState& s, const ElemRec& E, double rt, const double x[3])
 {
     double xi[3], N[8], xp[3];

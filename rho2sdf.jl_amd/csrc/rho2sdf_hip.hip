@@ -232,7 +232,8 @@ __device__ __forceinline__ void mini_range(const GridDev& g, int ax, double mn, 
 // iso item - the reference's processing order inside one element (:584-624).
 __global__ void item_build_kernel(const ElemRec* __restrict__ erec, const uint8_t* __restrict__ cls,
                                   const uint8_t* __restrict__ fmask, const uint32_t* __restrict__ item_off,
-                                  int64_t nel, GridDev g, double delta, BandItem* __restrict__ items)
+                                  int64_t nel, GridDev g, SlabInfo sl, double delta,
+                                  BandItem* __restrict__ items, uint32_t* __restrict__ nchunks)
 {
     int64_t el = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nel) return;
@@ -316,7 +317,11 @@ __global__ void item_build_kernel(const ElemRec* __restrict__ erec, const uint8_
                 double mx = fmax(fmax(T.tri[0][ax], T.tri[1][ax]), T.tri[2][ax]);
                 mini_range(g, ax, mn, mx, delta, T.imin[ax], T.imax[ax]);
             }
-            T.pad[0] = T.pad[1] = T.pad[2] = T.pad[3] = 0;
+            T.lo[0] = T.lo[1] = T.lo[2] = 0;
+            T.dim[0] = T.dim[1] = T.dim[2] = 0;
+            T.chunk_off = 0;
+            T.pad[0] = 0;
+            nchunks[w] = 0;
             items[w++] = T;
         }
     }
@@ -326,7 +331,79 @@ __global__ void item_build_kernel(const ElemRec* __restrict__ erec, const uint8_
         T.el = (int32_t)el;
         T.kind = 0;
         for (int ax = 0; ax < 3; ++ax) mini_range(g, ax, E.mn[ax], E.mx[ax], delta, T.imin[ax], T.imax[ax]);
+        // lattice box swept by iso_project_kernel: voxels i with cell(i) in [imin,imax] have
+        // lattice index in [imin, imax+1]; Z clipped to the slab
+        const int nmax[3] = {g.nx - 1, g.ny - 1, g.nz - 1};
+        uint64_t vol = 1;
+        for (int ax = 0; ax < 3; ++ax) {
+            int a = T.imin[ax], b = T.imax[ax];
+            if (a > b || a > nmax[ax]) { a = 0; b = -1; }
+            else {
+                b = (b >= nmax[ax]) ? nmax[ax] : b + 1;
+                if (ax == 2) {
+                    if (a < sl.k0) a = sl.k0;
+                    if (b >= sl.k1) b = sl.k1 - 1;
+                }
+            }
+            T.lo[ax] = a;
+            T.dim[ax] = (b >= a) ? (b - a + 1) : 0;
+            vol *= (uint64_t)T.dim[ax];
+        }
+        nchunks[w] = (uint32_t)((vol + 63) / 64);
         items[w++] = T;
+    }
+}
+
+// writes the scanned chunk offsets back into the items
+__global__ void item_chunks_kernel(BandItem* __restrict__ items, const uint32_t* __restrict__ chunk_off,
+                                   uint32_t nitems)
+{
+    uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it < nitems) items[it].chunk_off = chunk_off[it];
+}
+
+// Item-major projection onto the iso-surface (process_isocontour_element!, :606-624): one
+// wavefront per 64-voxel chunk of an iso item's lattice box, element record in SGPRs, every
+// lane a different voxel of the same element.  Results go to `res` (distance) and, when
+// requested, `res_xp`; the ordered per-voxel gather (sdf_tiles_kernel) consumes them in the
+// reference's element order, so the strict-'<' update semantics are unchanged.
+__global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __restrict__ items, uint32_t nitems,
+                                                         const uint32_t* __restrict__ chunk_off,
+                                                         uint32_t nchunks, const ElemRec* __restrict__ erec,
+                                                         GridDev g, double rho_t, double* __restrict__ res,
+                                                         double* __restrict__ res_xp)
+{
+    const uint32_t c = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (c >= nchunks) return;
+    const int lane = threadIdx.x & 63;
+    // last item with chunk_off[it] <= c  (chunk_off has nitems+1 entries, non-decreasing)
+    uint32_t lo = 0, hi = nitems;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunk_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    const BandItem& T = items[lo];
+    const ElemRec& E = erec[T.el];
+    const uint32_t local = (c - chunk_off[lo]) * 64u + lane;
+    const uint32_t bx = T.dim[0], by = T.dim[1], bz = T.dim[2];
+    if (local >= bx * by * bz) return;
+    const int li = local % bx, lj = (local / bx) % by, lk = local / (bx * by);
+    double x[3];
+    x[0] = grid_coord(g, 0, T.lo[0] + li);
+    x[1] = grid_coord(g, 1, T.lo[1] + lj);
+    x[2] = grid_coord(g, 2, T.lo[2] + lk);
+    const int ci = (int)cell_of(g, 0, x[0]), cj = (int)cell_of(g, 1, x[1]), ck = (int)cell_of(g, 2, x[2]);
+    const bool in = ci >= T.imin[0] && ci <= T.imax[0] && cj >= T.imin[1] && cj <= T.imax[1] &&
+                    ck >= T.imin[2] && ck <= T.imax[2];
+    if (!in) return;
+    double xp[3];
+    const double d = iso_candidate(E, rho_t, x, xp);
+    const size_t slot = (size_t)chunk_off[lo] * 64u + local;
+    res[slot] = d;
+    if (res_xp) {
+        res_xp[3 * slot] = xp[0];
+        res_xp[3 * slot + 1] = xp[1];
+        res_xp[3 * slot + 2] = xp[2];
     }
 }
 
@@ -485,6 +562,8 @@ struct MainArgs {
     double* sign;
     double* sdf;
     double* xp;
+    const double* iso_res;     // per (iso item, box voxel) distances from iso_project_kernel
+    const double* iso_res_xp;  // projection points (only when xp is requested)
     int sdf_mode;  // 1: sdf = dist*sign in one kernel; 2: dist pass stores -dist; 3: sign pass flips
 };
 
@@ -518,8 +597,22 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                             cj <= T.imax[1] && ck >= T.imin[2] && ck <= T.imax[2];
             if (in) {
                 const ElemRec& E = A.erec[T.el];
-                if (T.kind == 0) process_iso(st, E, A.rho_t, x);
-                else process_triangle(st, T, E, A.rho_t, x);
+                if (T.kind == 0) {
+                    // WriteValue of the pre-computed iso candidate (sdfOnDensityField.jl:617-621)
+                    const size_t slot = (size_t)T.chunk_off * 64u +
+                                        ((size_t)(k - T.lo[2]) * T.dim[1] + (j - T.lo[1])) * T.dim[0] + (i - T.lo[0]);
+                    const double d = A.iso_res[slot];
+                    if (fabs(d) < st.cur) {
+                        st.cur = d;
+                        if (A.iso_res_xp) {
+                            st.xp[0] = A.iso_res_xp[3 * slot];
+                            st.xp[1] = A.iso_res_xp[3 * slot + 1];
+                            st.xp[2] = A.iso_res_xp[3 * slot + 2];
+                        }
+                    }
+                } else {
+                    process_triangle(st, T, E, A.rho_t, x);
+                }
             }
         }
     }
@@ -603,9 +696,9 @@ struct r2s_plan {
     int device = 0;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
-    DevBuf active, active_sign, hot, counters, scan_tmp[3];
+    DevBuf active, active_sign, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
     uint32_t* h_pinned = nullptr;  // 16 words
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static int scan_exclusive(r2s_plan* P, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st, int level = 0)
@@ -734,7 +827,7 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     r2s_plan* P = new r2s_plan();
     P->device = device;
     HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocDefault));
-    for (int i = 0; i < 6; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
+    for (int i = 0; i < 7; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
     *out = P;
     return 0;
 }
@@ -746,11 +839,11 @@ void r2s_plan_destroy(r2s_plan* P)
     DevBuf* all[] = {&P->deg, &P->ine_ptr, &P->ine, &P->cursor, &P->erec, &P->cls, &P->fmask, &P->nitems,
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
                      &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign,
-                     &P->hot, &P->counters,
+                     &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
     for (DevBuf* b : all) b->release();
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
     delete P;
 }
@@ -849,10 +942,18 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     if (P->h_pinned[1]) return fail(R2S_ERR_ARG, "IEN contains node ids outside 1..nnp");
     const uint32_t n_items = want_dist ? P->h_pinned[0] : 0;
     ENSURE(P->items, sizeof(BandItem) * (size_t)std::max<uint32_t>(n_items, 1));
-    if (n_items)
+    ENSURE(P->nchunks, sizeof(uint32_t) * (size_t)(n_items + 1));
+    ENSURE(P->chunk_off, sizeof(uint32_t) * (size_t)(n_items + 1));
+    if (n_items) {
+        HIP_TRY(hipMemsetAsync(P->nchunks.p, 0, sizeof(uint32_t) * (size_t)(n_items + 1), st));
         item_build_kernel<<<(unsigned)((nel + 63) / 64), 64, 0, st>>>(
             P->erec.as<ElemRec>(), P->cls.as<uint8_t>(), P->fmask.as<uint8_t>(), P->item_off.as<uint32_t>(), nel,
-            g, delta, P->items.as<BandItem>());
+            g, s, delta, P->items.as<BandItem>(), P->nchunks.as<uint32_t>());
+        int rc = scan_exclusive(P, P->nchunks.as<uint32_t>(), P->chunk_off.as<uint32_t>(), (int64_t)n_items + 1, st);
+        if (rc) return rc;
+        item_chunks_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(P->items.as<BandItem>(), P->chunk_off.as<uint32_t>(), n_items);
+        HIP_TRY(hipMemcpyAsync(&P->h_pinned[6], P->chunk_off.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipEventRecord(P->ev[1], st));
 
     // ---- tile bins ----
@@ -876,6 +977,9 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4],
                    n_active_sign = P->h_pinned[5];
+    const uint32_t n_chunks = n_items ? P->h_pinned[6] : 0;
+    ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_chunks, 1));
+    if (mode & R2S_OUT_XP) ENSURE(P->iso_res_xp, sizeof(double) * 192 * (size_t)std::max<uint32_t>(n_chunks, 1));
     ENSURE(P->band_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
     ENSURE(P->band_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
     ENSURE(P->sign_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_sign, 1));
@@ -910,7 +1014,14 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
         A.dist = (mode & R2S_OUT_DIST) ? d_dist : nullptr;
         A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
         A.sdf = (mode & R2S_OUT_SDF) ? d_sdf : nullptr;
-        // distance pass over the tiles that hold band work items
+        // item-major iso-surface projections, then the ordered gather over the band tiles
+        A.iso_res = P->iso_res.as<double>();
+        A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
+        if (want_dist && n_chunks)
+            iso_project_kernel<<<(n_chunks + 3) / 4, 256, 0, st>>>(
+                P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<ElemRec>(), g,
+                rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+        HIP_TRY(hipEventRecord(P->ev[6], st));
         if (want_dist && n_active) {
             A.active = P->active.as<uint32_t>(); A.n_active = n_active;
             A.sign = nullptr;
@@ -944,7 +1055,9 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
         if (hipEventElapsedTime(&ms, P->ev[0], P->ev[1]) == hipSuccess) stats->ms_prep = ms;
         if (hipEventElapsedTime(&ms, P->ev[1], P->ev[2]) == hipSuccess) stats->ms_bins = ms;
         if (hipEventElapsedTime(&ms, P->ev[2], P->ev[3]) == hipSuccess) stats->ms_fill = ms;
-        if (hipEventElapsedTime(&ms, P->ev[3], P->ev[4]) == hipSuccess) stats->ms_main = ms;
+        if (hipEventElapsedTime(&ms, P->ev[3], P->ev[6]) == hipSuccess) stats->ms_main = ms;
+        if (hipEventElapsedTime(&ms, P->ev[6], P->ev[4]) == hipSuccess) stats->ms_gather = ms;
+        stats->n_iso_chunks = n_chunks;
         if (hipEventElapsedTime(&ms, P->ev[4], P->ev[5]) == hipSuccess) stats->ms_sign = ms;
         (void)hipGetLastError();
     }
