@@ -206,17 +206,18 @@ R2S_DEV bool qp_pattern(int pat, const double H[3][3], const double g[3], const 
 #pragma unroll
         for (int j = 0; j < 3; ++j) M[i][j] = (s[i] || s[j]) ? ((i == j) ? 1.0 : 0.0) : H[i][j];
     }
-    double D0 = M[0][0];
-    double l10 = M[1][0] / D0, l20 = M[2][0] / D0;
-    double D1 = M[1][1] - l10 * M[1][0];
-    double l21 = (M[2][1] - l20 * M[1][0]) / D1;
-    double D2 = M[2][2] - l20 * M[2][0] - l21 * l21 * D1;
+    // pivots are inverted once and multiplied (3 divisions instead of 9)
+    double D0 = M[0][0], r0 = 1.0 / D0;
+    double l10 = M[1][0] * r0, l20 = M[2][0] * r0;
+    double D1 = M[1][1] - l10 * M[1][0], r1 = 1.0 / D1;
+    double l21 = (M[2][1] - l20 * M[1][0]) * r1;
+    double D2 = M[2][2] - l20 * M[2][0] - l21 * l21 * D1, r2 = 1.0 / D2;
     if (!(D0 > 0.0 && D1 > 0.0 && D2 > 0.0)) return false;
     double u[3], v[3];
     u[0] = aa[0]; u[1] = aa[1] - l10 * u[0]; u[2] = aa[2] - l20 * u[0] - l21 * u[1];
     v[0] = b[0];  v[1] = b[1] - l10 * v[0];  v[2] = b[2] - l20 * v[0] - l21 * v[1];
-    u[2] = u[2] / D2; u[1] = u[1] / D1 - l21 * u[2]; u[0] = u[0] / D0 - l10 * u[1] - l20 * u[2];
-    v[2] = v[2] / D2; v[1] = v[1] / D1 - l21 * v[2]; v[0] = v[0] / D0 - l10 * v[1] - l20 * v[2];
+    u[2] = u[2] * r2; u[1] = u[1] * r1 - l21 * u[2]; u[0] = u[0] * r0 - l10 * u[1] - l20 * u[2];
+    v[2] = v[2] * r2; v[1] = v[1] * r1 - l21 * v[2]; v[0] = v[0] * r0 - l10 * v[1] - l20 * v[2];
     double den = aa[0] * u[0] + aa[1] * u[1] + aa[2] * u[2];
     if (!(den > 0.0)) return false;
     double lam = (aa[0] * v[0] + aa[1] * v[1] + aa[2] * v[2] - ep) / den;

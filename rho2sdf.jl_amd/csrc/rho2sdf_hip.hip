@@ -340,6 +340,10 @@ __global__ void item_build_kernel(const ElemRec* __restrict__ erec, const uint8_
             if (a > b || a > nmax[ax]) { a = 0; b = -1; }
             else {
                 b = (b >= nmax[ax]) ? nmax[ax] : b + 1;
+                // cell(i) (Grid.jl:58) is monotone in i and equals i or i-1: trim the two ends
+                // to the lattice indices whose cell really lies in [imin,imax]
+                if ((int)cell_of(g, ax, grid_coord(g, ax, a)) < T.imin[ax]) a += 1;
+                if ((int)cell_of(g, ax, grid_coord(g, ax, b)) > T.imax[ax]) b -= 1;
                 if (ax == 2) {
                     if (a < sl.k0) a = sl.k0;
                     if (b >= sl.k1) b = sl.k1 - 1;
