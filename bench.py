@@ -29,12 +29,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_VOXEL = 8.0      # one Float64 store per voxel; + mesh bytes / ngp
 
 
-def slab_bounds(nz, world):
-    """equal Z-slabs, nz padded up to a multiple of `world`"""
-    per = (nz + world - 1) // world
-    return per, [(min(r * per, nz), min((r + 1) * per, nz)) for r in range(world)]
-
-
 def cpu_baseline(X, IEN, rho_n, rho_t, n_max, stride):
     """The oracle (CPU restatement, kind "port") on a bounded sample of the SAME workload:
     every `stride`-th Z plane of the same grid over the same mesh, one thread."""
@@ -93,21 +87,19 @@ def main():
     nx, ny, nz = grid.dims
     ngp = grid.ngp
     dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rho_n))
-    per, bounds = slab_bounds(nz, world)
-    k0, k1 = bounds[rank]
-    plane = nx * ny
-    gathered = torch.empty(world * per * plane, dtype=torch.float64, device=dev)
-    mine = gathered[rank * per * plane:(rank + 1) * per * plane]      # in-place all-gather
+    from rho2sdf_jl_amd import slabs
+    sg = slabs.SlabGather((nx, ny, nz), rank, world, dev)             # in-place all-gather buffer
+    k0, k1 = sg.k0, sg.k1
+    plane = sg.plane
+    gathered = sg.gathered
     plan = pkg.DevicePlan(local_rank)
     stats_acc = []
 
+    def compute_slab(a, b, out):
+        return plan.run(dX, dI, dR, rho_t, grid, k_begin=a, k_end=b, sdf=out)
+
     def step():
-        st = None
-        if k1 > k0:
-            st = plan.run(dX, dI, dR, rho_t, grid, k_begin=k0, k_end=k1, sdf=mine[:(k1 - k0) * plane])
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, mine)
-        return st
+        return slabs.run_step(sg, compute_slab)
 
     def sync():
         if world > 1:

@@ -130,6 +130,47 @@ int r2s_plan_run_dev(r2s_plan *plan, const double *dX, int64_t nnp, const int64_
                      double *d_dist, double *d_sign, double *d_sdf, double *d_xp, void *stream,
                      r2s_stats *stats);
 
+/* ---- pre-stage: mesh volume, nodal densities, volume-preserving threshold ------------- */
+
+/* calculate_mesh_volume(X, IEN, rho, HEX8) -> (V_domain, V_frac)     src/MeshGrid/MeshVolume.jl:4-42 */
+int r2s_mesh_volume(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int32_t elem_type,
+                    const double *rho_e, int32_t device, double *V_domain, double *V_frac);
+
+/* DenseInNodes(mesh, rho) -> rho_n[nnp]                              src/MeshGrid/NodalDensities.jl:89-218 */
+int r2s_dense_in_nodes(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int32_t elem_type,
+                       const double *rho_e, int32_t device, double *rho_n_out);
+
+/* find_threshold_for_volume(mesh, rho_n, tol=1e-4, maxit=60) with target = V_domain*V_frac
+ *                                                                    src/MeshGrid/Isocontour_volume.jl:77-154
+ * returns R2S_ERR_ARG ("outside the possible range", :93-95) like the reference's error(). */
+int r2s_find_threshold(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_n,
+                       double target_volume, double tol, int32_t maxit, int32_t device, double *rho_t_out,
+                       int32_t *iters_out);
+
+/* ---- post-processing ---------------------------------------------------------------- */
+
+/* remove_sdf_artifacts!(sdf, grid; threshold, min_component_ratio) -> nodes flipped
+ *                                                src/SignedDistances/SdfArtifactRemoval.jl:134-245 */
+int r2s_remove_artifacts(double *sdf_inout, const r2s_grid *grid, double threshold, double min_ratio,
+                         int32_t device, int64_t *n_flipped);
+int r2s_remove_artifacts_dev(double *d_sdf, const r2s_grid *grid, double threshold, double min_ratio,
+                             void *stream, int64_t *n_flipped);
+
+/* calculate_volume_from_sdf(sdf::Array{Float32,3}, grid; iso_threshold, detailed_quad_order)
+ *                                                src/SdfSmoothing/CalcVolumeFromSDF.jl:26-125
+ * sdf is (nx,ny,nz) x-fastest; edge = spacing of the (cubic-cell) grid. */
+int r2s_volume_from_sdf(const float *sdf, int64_t nx, int64_t ny, int64_t nz, float edge, float iso,
+                        int32_t quad_order, int32_t device, float *vol_out);
+
+/* RBFs_smoothing(mesh, dist, grid, is_interp, smooth, taskName, threshold=1e-3) -> fine_sdf
+ *                                                src/SdfSmoothing/RBFs4Smoothing.jl:321-377
+ * target_volume = mesh.V_frac*mesh.V_domain; fine_sdf_out has prod(N*smooth+1) Float32 values
+ * (x fastest); fine_grid is origin AABB_min + spacing (AABB_max[1]-AABB_min[1])/(N[1]*smooth) and is
+ * materialised by the caller.  Optional outputs: level shift `th`, CG iterations, coarse LSF. */
+int r2s_rbf_smooth(const double *sdf, const r2s_grid *grid, int32_t is_interp, int32_t smooth,
+                   double kernel_threshold, double target_volume, int32_t device, float *fine_sdf_out,
+                   float *level_shift_out, int32_t *cg_iters_out, float *lsf_out);
+
 #ifdef __cplusplus
 }
 #endif

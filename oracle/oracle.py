@@ -139,3 +139,78 @@ def iso_project_hex8(x, Xe, rho_e, rho_t):
 def set_k_sampling(stride=1, phase=0):
     """bench.py cpu_baseline: evaluate only planes k % stride == phase"""
     lib().orc_set_k_sampling(ctypes.c_int64(stride), ctypes.c_int64(phase))
+
+
+_fp = ctypes.POINTER(ctypes.c_float)
+
+
+def gauss_legendre(n):
+    x = np.zeros(n)
+    w = np.zeros(n)
+    lib().orc_gauss_legendre(ctypes.c_int(n), _d(x), _d(w))
+    return x, w
+
+
+def mesh_volume(X, IEN, rho_e):
+    """calculate_mesh_volume -> (V_domain, V_frac)"""
+    X, IEN, et = _mesh(X, IEN)
+    assert et == 0
+    rho_e = np.ascontiguousarray(rho_e, dtype=np.float64)
+    vd, vf = ctypes.c_double(), ctypes.c_double()
+    lib().orc_mesh_volume(_d(X), ctypes.c_int64(len(X)), _i(IEN), ctypes.c_int64(len(IEN)), _d(rho_e),
+                          ctypes.byref(vd), ctypes.byref(vf))
+    return vd.value, vf.value
+
+
+def isocontour_volume(X, IEN, rho_n, thr):
+    X, IEN, et = _mesh(X, IEN)
+    rho_n = np.ascontiguousarray(rho_n, dtype=np.float64)
+    f = lib().orc_isocontour_volume
+    f.restype = ctypes.c_double
+    return f(_d(X), _i(IEN), ctypes.c_int64(len(IEN)), _d(rho_n), ctypes.c_double(thr))
+
+
+def find_threshold(X, IEN, rho_n, target_volume, tol=1e-4, maxit=60):
+    X, IEN, et = _mesh(X, IEN)
+    rho_n = np.ascontiguousarray(rho_n, dtype=np.float64)
+    rt, it = ctypes.c_double(), ctypes.c_int()
+    rc = lib().orc_find_threshold(_d(X), ctypes.c_int64(len(X)), _i(IEN), ctypes.c_int64(len(IEN)), _d(rho_n),
+                                  ctypes.c_double(target_volume), ctypes.c_double(tol), ctypes.c_int(maxit),
+                                  ctypes.byref(rt), ctypes.byref(it))
+    if rc:
+        raise ValueError("Requested volume is outside the possible range")   # Isocontour_volume.jl:94
+    return rt.value, it.value
+
+
+def remove_artifacts(sdf, g, threshold=0.0, min_component_ratio=0.01):
+    """in place; returns the number of flipped nodes"""
+    assert sdf.dtype == np.float64 and sdf.flags.c_contiguous and sdf.size == g.ngp
+    f = lib().orc_remove_artifacts
+    f.restype = ctypes.c_int64
+    return int(f(_d(sdf), ctypes.byref(g), ctypes.c_double(threshold), ctypes.c_double(min_component_ratio)))
+
+
+def volume_from_sdf(sdf_f32, edge, iso=0.0, order=9):
+    """sdf_f32: (nz, ny, nx) float32 (x fastest) -> Float32 volume"""
+    a = np.ascontiguousarray(sdf_f32, dtype=np.float32)
+    nz, ny, nx = a.shape
+    f = lib().orc_volume_from_sdf
+    f.restype = ctypes.c_float
+    return float(f(a.ctypes.data_as(_fp), ctypes.c_int64(nx), ctypes.c_int64(ny), ctypes.c_int64(nz),
+                   ctypes.c_float(edge), ctypes.c_float(iso), ctypes.c_int(order)))
+
+
+def rbf_smoothing(sdf, g, is_interp, smooth, target_volume, kthr=1e-3):
+    """RBFs_smoothing -> (fine_sdf (nz',ny',nx') float32, th, cg_iterations, LSF on the coarse grid)"""
+    sdf = np.ascontiguousarray(sdf, dtype=np.float64)
+    dims = tuple(int(n) * smooth + 1 for n in g.N)
+    fine = np.empty(dims[2] * dims[1] * dims[0], dtype=np.float32)
+    lsf = np.empty(g.ngp, dtype=np.float32)
+    th, its = ctypes.c_float(), ctypes.c_int()
+    rc = lib().orc_rbf_smoothing(_d(sdf), ctypes.byref(g), ctypes.c_int(int(is_interp)), ctypes.c_int(smooth),
+                                 ctypes.c_double(kthr), ctypes.c_double(target_volume),
+                                 fine.ctypes.data_as(_fp), ctypes.byref(th), ctypes.byref(its),
+                                 lsf.ctypes.data_as(_fp))
+    if rc:
+        raise ValueError("every SDF value is a sentinel")
+    return fine.reshape(dims[2], dims[1], dims[0]), th.value, its.value, lsf.reshape(g.dims[2], g.dims[1], g.dims[0])

@@ -1208,3 +1208,480 @@ int orc_auto_grid(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel,
     if (median_edge) *median_edge = B;
     return orc_grid_make(mn, mx, n_new, 3, g);
 }
+
+/* ================================================================== */
+/* Gauss-Legendre tables (stands in for FastGaussQuadrature 1.1.0      */
+/* `gausslegendre(n)`; n = 3 uses the closed form that package returns)*/
+/* ================================================================== */
+void orc_gauss_legendre(int n, double *x, double *w)
+{
+    if (n == 3) {
+        x[0] = -sqrt(3.0 / 5.0); x[1] = 0.0; x[2] = sqrt(3.0 / 5.0);
+        w[0] = 5.0 / 9.0; w[1] = 8.0 / 9.0; w[2] = 5.0 / 9.0;
+        return;
+    }
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < n; ++i) {
+        double z = cos(pi * ((double)(n - 1 - i) + 0.75) / ((double)n + 0.5)); /* ascending */
+        double pp = 1.0;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 1; j <= n; ++j) {
+                double p3 = p2;
+                p2 = p1;
+                p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j;
+            }
+            pp = n * (z * p1 - p2) / (z * z - 1.0);
+            double dz = p1 / pp;
+            z -= dz;
+            if (fabs(dz) < 1e-16) break;
+        }
+        if ((n % 2) && i == n / 2) z = 0.0;
+        /* recompute derivative at the converged node */
+        {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 1; j <= n; ++j) {
+                double p3 = p2;
+                p2 = p1;
+                p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j;
+            }
+            pp = n * (z * p1 - p2) / (z * z - 1.0);
+        }
+        x[i] = z;
+        w[i] = 2.0 / ((1.0 - z * z) * pp * pp);
+    }
+    for (int i = 0; i < n / 2; ++i) { /* enforce exact symmetry like the reference tables */
+        double xa = 0.5 * (x[n - 1 - i] - x[i]), wa = 0.5 * (w[i] + w[n - 1 - i]);
+        x[i] = -xa; x[n - 1 - i] = xa; w[i] = wa; w[n - 1 - i] = wa;
+    }
+}
+
+static inline double det3(const double J[3][3])
+{
+    return J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) -
+           J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+           J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+}
+
+/* volume of one HEX8 restricted to {rho >= thr} by tensor Gauss quadrature
+ * (MeshVolume.jl:45-72 when check == 0; Isocontour_volume.jl:54-69 otherwise) */
+static double hex8_quad_volume(const double Xe[8][3], const double re[8], int n, const double *gp,
+                               const double *gw, int check, double thr)
+{
+    double vol = 0.0;
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                double xi[3] = {gp[i], gp[j], gp[k]}, N[8], dN[8][3], J[3][3];
+                hex8_shape_d(xi, N, dN);
+                if (check) {
+                    double v = 0.0;
+                    for (int a = 0; a < 8; ++a) v += N[a] * re[a];
+                    if (v < thr) continue;
+                }
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) {
+                        double s = 0.0;
+                        for (int a = 0; a < 8; ++a) s += Xe[a][r] * dN[a][c];
+                        J[r][c] = s;
+                    }
+                vol += gw[i] * gw[j] * gw[k] * fabs(det3(J));
+            }
+    return vol;
+}
+
+/* calculate_mesh_volume (src/MeshGrid/MeshVolume.jl:4-42), HEX8, single thread */
+int orc_mesh_volume(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_e,
+                    double *V_domain, double *V_frac)
+{
+    (void)nnp;
+    double gp[3], gw[3], dom = 0.0, to = 0.0;
+    orc_gauss_legendre(3, gp, gw);
+    for (int64_t e = 0; e < nel; ++e) {
+        double Xe[8][3], re[8] = {0};
+        for (int a = 0; a < 8; ++a)
+            for (int i = 0; i < 3; ++i) Xe[a][i] = X[3 * (IEN[e * 8 + a] - 1) + i];
+        double v = hex8_quad_volume(Xe, re, 3, gp, gw, 0, 0.0);
+        dom += v;
+        to += v * rho_e[e];
+    }
+    *V_domain = dom;
+    *V_frac = to / dom;
+    return 0;
+}
+
+/* calculate_isocontour_volume (src/MeshGrid/Isocontour_volume.jl:1-75) */
+double orc_isocontour_volume(const double *X, const int64_t *IEN, int64_t nel, const double *rho_n,
+                             double thr)
+{
+    double g15[15], w15[15], g3[3], w3[3], total = 0.0;
+    orc_gauss_legendre(15, g15, w15);
+    orc_gauss_legendre(3, g3, w3);
+    for (int64_t e = 0; e < nel; ++e) {
+        double Xe[8][3], re[8], mn = INFINITY, mx = -INFINITY;
+        for (int a = 0; a < 8; ++a) {
+            int64_t n = IEN[e * 8 + a] - 1;
+            for (int i = 0; i < 3; ++i) Xe[a][i] = X[3 * n + i];
+            re[a] = rho_n[n];
+            if (re[a] < mn) mn = re[a];
+            if (re[a] > mx) mx = re[a];
+        }
+        if (mx < thr) continue;
+        if (mn >= thr) total += hex8_quad_volume(Xe, re, 3, g3, w3, 0, thr);
+        else total += hex8_quad_volume(Xe, re, 15, g15, w15, 1, thr);
+    }
+    return total;
+}
+
+/* find_threshold_for_volume (Isocontour_volume.jl:77-154); returns -1 if out of range (:93-95) */
+int orc_find_threshold(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_n,
+                       double target_volume, double tol, int maxit, double *rho_t, int *iters)
+{
+    (void)nnp;
+    double lo = 0.0, hi = 1.0;
+    double vmin = orc_isocontour_volume(X, IEN, nel, rho_n, hi);
+    double vmax = orc_isocontour_volume(X, IEN, nel, rho_n, lo);
+    if (target_volume > vmax || target_volume < vmin) return -1;
+    int it = 0;
+    double best = 0.0, best_err = INFINITY;
+    while (it < maxit) {
+        double thr = (lo + hi) / 2;
+        double v = orc_isocontour_volume(X, IEN, nel, rho_n, thr);
+        double err = fabs(v - target_volume) / target_volume;
+        if (err < best_err) { best = thr; best_err = err; }
+        if (err < tol) break;
+        if (v > target_volume) lo = thr; else hi = thr;
+        it++;
+    }
+    *rho_t = best;
+    if (iters) *iters = it;
+    return 0;
+}
+
+/* ================================================================== */
+/* remove_sdf_artifacts! (src/SignedDistances/SdfArtifactRemoval.jl:134-245) */
+/* serial union-find semantics (analyze_sdf_components :271-285)       */
+/* ================================================================== */
+static int64_t uf_find(int64_t *p, int64_t x)
+{
+    int64_t r = x;
+    while (p[r] != r) r = p[r];
+    while (p[x] != r) { int64_t n = p[x]; p[x] = r; x = n; }
+    return r;
+}
+
+int64_t orc_remove_artifacts(double *sdf, const orc_grid *g, double threshold, double min_ratio)
+{
+    int64_t ngp = g->ngp, nx = g->N[0] + 1, ny = g->N[1] + 1, nz = g->N[2] + 1;
+    int64_t *par = (int64_t *)malloc(sizeof(int64_t) * (size_t)ngp);
+    int64_t *sz = (int64_t *)calloc((size_t)ngp, sizeof(int64_t));
+    int64_t interior = 0;
+    for (int64_t v = 0; v < ngp; ++v) { par[v] = v; interior += (sdf[v] >= threshold); }
+    if (interior == 0) { free(par); free(sz); return 0; }
+    for (int64_t k = 0; k < nz; ++k)
+        for (int64_t j = 0; j < ny; ++j)
+            for (int64_t i = 0; i < nx; ++i) {
+                int64_t v = (k * ny + j) * nx + i;
+                if (!(sdf[v] >= threshold)) continue;
+                int64_t nb[3] = {i + 1 < nx ? v + 1 : -1, j + 1 < ny ? v + nx : -1, k + 1 < nz ? v + nx * ny : -1};
+                for (int q = 0; q < 3; ++q)
+                    if (nb[q] >= 0 && sdf[nb[q]] >= threshold) {
+                        int64_t a = uf_find(par, v), b = uf_find(par, nb[q]);
+                        if (a != b) par[b > a ? b : a] = (b > a ? a : b);
+                    }
+            }
+    int64_t largest = 0, largest_root = -1;
+    for (int64_t v = 0; v < ngp; ++v)
+        if (sdf[v] >= threshold) sz[uf_find(par, v)]++;
+    for (int64_t v = 0; v < ngp; ++v)
+        if (sz[v] > largest) { largest = sz[v]; largest_root = v; }
+    double t = min_ratio * (double)largest;
+    int64_t min_size = (int64_t)nearbyint(t); /* Julia round(Int, x): ties to even (:206) */
+    if (min_size < 1) min_size = 1;
+    int64_t flipped = 0;
+    for (int64_t v = 0; v < ngp; ++v)
+        if (sdf[v] >= threshold) {
+            int64_t r = uf_find(par, v);
+            if (r != largest_root && sz[r] < min_size) { sdf[v] = -fabs(sdf[v]); flipped++; }
+        }
+    free(par); free(sz);
+    return flipped;
+}
+
+/* ================================================================== */
+/* calculate_volume_from_sdf (src/SdfSmoothing/CalcVolumeFromSDF.jl:26-125) */
+/* Float32 throughout; single thread = sequential k,j,i accumulation    */
+/* ================================================================== */
+float orc_volume_from_sdf(const float *sdf, int64_t nx, int64_t ny, int64_t nz, float edge, float iso,
+                          int order)
+{
+    double gpd[64], gwd[64];
+    float gp[64], gw[64];
+    orc_gauss_legendre(order, gpd, gwd);
+    for (int i = 0; i < order; ++i) { gp[i] = (float)gpd[i]; gw[i] = (float)gwd[i]; }
+    const float elvol = edge * edge * edge;
+    const float jac = elvol / 8.0f;
+    float total = 0.0f;
+#define S(i, j, k) sdf[((k) * ny + (j)) * nx + (i)]
+    for (int64_t k = 0; k < nz - 1; ++k)
+        for (int64_t j = 0; j < ny - 1; ++j)
+            for (int64_t i = 0; i < nx - 1; ++i) {
+                float c000 = S(i, j, k), c100 = S(i + 1, j, k), c010 = S(i, j + 1, k), c110 = S(i + 1, j + 1, k);
+                float c001 = S(i, j, k + 1), c101 = S(i + 1, j, k + 1), c011 = S(i, j + 1, k + 1),
+                      c111 = S(i + 1, j + 1, k + 1);
+                float mn = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111)));
+                float mx = fmaxf(fmaxf(fmaxf(c000, c100), fmaxf(c010, c110)), fmaxf(fmaxf(c001, c101), fmaxf(c011, c111)));
+                if (mx < iso) continue;
+                if (mn >= iso) { total += elvol; continue; }
+                float part = 0.0f;
+                for (int kq = 0; kq < order; ++kq) {
+                    float zeta = (gp[kq] + 1) / 2;
+                    for (int jq = 0; jq < order; ++jq) {
+                        float eta = (gp[jq] + 1) / 2;
+                        for (int iq = 0; iq < order; ++iq) {
+                            float xi = (gp[iq] + 1) / 2;
+                            float c00 = c000 * (1.0f - xi) + c100 * xi;
+                            float c01 = c001 * (1.0f - xi) + c101 * xi;
+                            float c10 = c010 * (1.0f - xi) + c110 * xi;
+                            float c11 = c011 * (1.0f - xi) + c111 * xi;
+                            float c0 = c00 * (1.0f - eta) + c10 * eta;
+                            float c1 = c01 * (1.0f - eta) + c11 * eta;
+                            float p = c0 * (1.0f - zeta) + c1 * zeta;
+                            if (p >= iso) part += gw[iq] * gw[jq] * gw[kq] * jac;
+                        }
+                    }
+                }
+                total += part;
+            }
+#undef S
+    return total;
+}
+
+/* ================================================================== */
+/* RBFs_smoothing (src/SdfSmoothing/RBFs4Smoothing.jl:321-377)         */
+/* Float32 values, Float64 sigma inside exp, as in the reference.      */
+/* KDTree/knn (NearestNeighbors 0.4.22) on a regular lattice = fixed   */
+/* stencil: neighbours are visited by increasing lattice distance      */
+/* (ties: dz,dy,dx) - the reference's tie order is unspecified (A16).  */
+/* ================================================================== */
+/* process_vector (:15-22); returns -1 if every value is a sentinel (A15) */
+int orc_process_vector(const double *v, int64_t n, float *out)
+{
+    float mx = -1.0f;
+    for (int64_t i = 0; i < n; ++i) {
+        float f = (float)v[i];
+        out[i] = f;
+        if (fabsf(f) < 1.0e9f && fabsf(f) > mx) mx = fabsf(f);
+    }
+    if (mx < 0.0f) return -1;
+    const float rtol = 3.4526698e-4f; /* sqrt(eps(Float32)) */
+    for (int64_t i = 0; i < n; ++i) {
+        float a = fabsf(out[i]);
+        float big = a > 1.0e10f ? a : 1.0e10f;
+        if (fabsf(a - 1.0e10f) <= rtol * big) out[i] = (out[i] > 0 ? 1.0f : (out[i] < 0 ? -1.0f : 0.0f)) * mx;
+    }
+    return 0;
+}
+
+typedef struct {
+    int n;
+    int off[512][3]; /* coarse offsets (dx,dy,dz) relative to the base coarse index */
+} rbf_stencil;
+
+/* neighbours of a target point with sub-index frac (0..s-1 per axis) in a lattice refined s times */
+static void rbf_build_stencil(int s, const int frac[3], rbf_stencil *st)
+{
+    int cand[512][4], n = 0;
+    for (int dz = -3; dz <= 4; ++dz)
+        for (int dy = -3; dy <= 4; ++dy)
+            for (int dx = -3; dx <= 4; ++dx) {
+                int ex = dx * s - frac[0], ey = dy * s - frac[1], ez = dz * s - frac[2];
+                int d2 = ex * ex + ey * ey + ez * ez;
+                if (d2 > 9 * s * s) continue; /* > 3 cells: far beyond the 2.63-cell support */
+                cand[n][0] = d2; cand[n][1] = dz; cand[n][2] = dy; cand[n][3] = dx;
+                n++;
+            }
+    for (int i = 1; i < n; ++i) { /* insertion sort by (d2, dz, dy, dx) */
+        int t[4] = {cand[i][0], cand[i][1], cand[i][2], cand[i][3]}, j = i - 1;
+        while (j >= 0 && (cand[j][0] > t[0] || (cand[j][0] == t[0] && (cand[j][1] > t[1] ||
+               (cand[j][1] == t[1] && (cand[j][2] > t[2] || (cand[j][2] == t[2] && cand[j][3] > t[3]))))))) {
+            for (int q = 0; q < 4; ++q) cand[j + 1][q] = cand[j][q];
+            j--;
+        }
+        for (int q = 0; q < 4; ++q) cand[j + 1][q] = t[q];
+    }
+    st->n = n;
+    for (int i = 0; i < n; ++i) { st->off[i][0] = cand[i][3]; st->off[i][1] = cand[i][2]; st->off[i][2] = cand[i][1]; }
+}
+
+/* create_grid (:36-46): Float32 `range(min, max, length)` */
+static void rbf_coarse_coords(double mn, double mx, int64_t n, float *c)
+{
+    double a = (double)(float)mn, b = (double)(float)mx;
+    for (int64_t i = 0; i < n; ++i) c[i] = (float)(a + (double)i * (b - a) / (double)(n - 1));
+    c[n - 1] = (float)mx;
+}
+
+typedef struct {
+    int64_t nx, ny, nz;
+    float *cx, *cy, *cz;
+    double sigma;
+    float max_distance;
+    double thr;
+} rbf_ctx;
+
+/* rbf_interpolation_kdtree (:219-248): targets tx/ty/tz, refined s times w.r.t. the coarse lattice */
+static void rbf_apply(const rbf_ctx *c, const float *w, int s, int64_t tnx, int64_t tny, int64_t tnz,
+                      const float *tx, const float *ty, const float *tz, float *out)
+{
+    rbf_stencil *st = (rbf_stencil *)malloc(sizeof(rbf_stencil) * (size_t)(s * s * s));
+    for (int fz = 0; fz < s; ++fz)
+        for (int fy = 0; fy < s; ++fy)
+            for (int fx = 0; fx < s; ++fx) {
+                int fr[3] = {fx, fy, fz};
+                rbf_build_stencil(s, fr, &st[(fz * s + fy) * s + fx]);
+            }
+    for (int64_t k = 0; k < tnz; ++k)
+        for (int64_t j = 0; j < tny; ++j)
+            for (int64_t i = 0; i < tnx; ++i) {
+                const rbf_stencil *S = &st[((k % s) * s + (j % s)) * s + (i % s)];
+                int64_t bi = i / s, bj = j / s, bk = k / s;
+                float acc = 0.0f;
+                for (int q = 0; q < S->n; ++q) {
+                    int64_t ci = bi + S->off[q][0], cj = bj + S->off[q][1], ck = bk + S->off[q][2];
+                    if (ci < 0 || cj < 0 || ck < 0 || ci >= c->nx || cj >= c->ny || ck >= c->nz) continue;
+                    float dx = tx[i] - c->cx[ci], dy = ty[j] - c->cy[cj], dz = tz[k] - c->cz[ck];
+                    float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+                    if (dist <= c->max_distance) {
+                        double t = (double)dist / c->sigma;
+                        acc = (float)((double)acc + (double)w[(ck * c->ny + cj) * c->nx + ci] * exp(-(t * t)));
+                    }
+                }
+                out[(k * tny + j) * tnx + i] = acc;
+            }
+    free(st);
+}
+
+/* y = K x with K from compute_sparse_kernel_matrix (:142-176): Float32 entries
+ * Float32(exp(-(r/sigma)^2)) kept if > threshold; SparseMatrixCSC * vector accumulates each
+ * row in ascending column (= linear index) order, in Float32 */
+static void rbf_matvec(const rbf_ctx *c, const float *x, float *y)
+{
+    for (int64_t k = 0; k < c->nz; ++k)
+        for (int64_t j = 0; j < c->ny; ++j)
+            for (int64_t i = 0; i < c->nx; ++i) {
+                float acc = 0.0f;
+                for (int64_t ck = k - 3; ck <= k + 3; ++ck)
+                    for (int64_t cj = j - 3; cj <= j + 3; ++cj)
+                        for (int64_t ci = i - 3; ci <= i + 3; ++ci) {
+                            if (ci < 0 || cj < 0 || ck < 0 || ci >= c->nx || cj >= c->ny || ck >= c->nz) continue;
+                            float dx = c->cx[i] - c->cx[ci], dy = c->cy[j] - c->cy[cj], dz = c->cz[k] - c->cz[ck];
+                            float r = sqrtf(dx * dx + dy * dy + dz * dz);
+                            double t = (double)r / c->sigma;
+                            double val = exp(-(t * t));
+                            if (val > c->thr) acc += (float)val * x[(ck * c->ny + cj) * c->nx + ci];
+                        }
+                y[(k * c->ny + j) * c->nx + i] = acc;
+            }
+}
+
+static float f32_dot(const float *a, const float *b, int64_t n)
+{
+    double s = 0.0; /* BLAS sdot/snrm2 stand-in: double accumulation, Float32 result */
+    for (int64_t i = 0; i < n; ++i) s += (double)a[i] * (double)b[i];
+    return (float)s;
+}
+
+/* IterativeSolvers.cg defaults (0.9.4): x0 = 0, reltol = sqrt(eps(Float32)), maxiter = n */
+static int rbf_cg(const rbf_ctx *c, const float *b, float *x, int64_t n)
+{
+    float *r = (float *)malloc(sizeof(float) * (size_t)n), *u = (float *)calloc((size_t)n, sizeof(float));
+    float *q = (float *)malloc(sizeof(float) * (size_t)n);
+    memcpy(r, b, sizeof(float) * (size_t)n);
+    memset(x, 0, sizeof(float) * (size_t)n);
+    float residual = sqrtf(f32_dot(r, r, n)), prev = 1.0f;
+    const float tol = 3.4526698e-4f * residual;
+    int it = 0;
+    while (!(residual <= tol) && it < n) {
+        float beta = (residual * residual) / (prev * prev);
+        for (int64_t i = 0; i < n; ++i) u[i] = r[i] + beta * u[i];
+        rbf_matvec(c, u, q);
+        float alpha = (residual * residual) / f32_dot(u, q, n);
+        for (int64_t i = 0; i < n; ++i) { x[i] += alpha * u[i]; r[i] -= alpha * q[i]; }
+        prev = residual;
+        residual = sqrtf(f32_dot(r, r, n));
+        it++;
+    }
+    free(r); free(u); free(q);
+    return it;
+}
+
+/* LS_Threshold (:265-300) */
+static float rbf_ls_threshold(const float *lsf, int64_t nx, int64_t ny, int64_t nz, float edge,
+                              double target_volume, int *iters)
+{
+    int64_t n = nx * ny * nz;
+    float lo = lsf[0], hi = lsf[0];
+    for (int64_t i = 1; i < n; ++i) { if (lsf[i] < lo) lo = lsf[i]; if (lsf[i] > hi) hi = lsf[i]; }
+    float *sh = (float *)malloc(sizeof(float) * (size_t)n);
+    double eps = 1.0;
+    float th = 0.0f;
+    int it = 0;
+    while (it < 40 && eps > 1.0e-4) {
+        th = (lo + hi) / 2;
+        for (int64_t i = 0; i < n; ++i) sh[i] = lsf[i] - th;
+        float vol = orc_volume_from_sdf(sh, nx, ny, nz, edge, 0.0f, 9);
+        eps = fabs(target_volume - (double)vol);
+        if ((double)vol > target_volume) lo = th; else hi = th;
+        it++;
+    }
+    free(sh);
+    if (iters) *iters = it;
+    return -th;
+}
+
+/* RBFs_smoothing (:321-377). fine_out has prod(N*smooth+1) entries. */
+int orc_rbf_smoothing(const double *sdf, const orc_grid *g, int is_interp, int smooth, double kthr,
+                      double target_volume, float *fine_out, float *th_out, int *cg_iters, float *lsf_out)
+{
+    rbf_ctx c;
+    c.nx = g->N[0] + 1; c.ny = g->N[1] + 1; c.nz = g->N[2] + 1;
+    int64_t n = c.nx * c.ny * c.nz;
+    float *dm = (float *)malloc(sizeof(float) * (size_t)n);
+    if (orc_process_vector(sdf, n, dm)) { free(dm); return -1; }
+    c.cx = (float *)malloc(sizeof(float) * (size_t)c.nx);
+    c.cy = (float *)malloc(sizeof(float) * (size_t)c.ny);
+    c.cz = (float *)malloc(sizeof(float) * (size_t)c.nz);
+    rbf_coarse_coords(g->amin[0], g->amax[0], c.nx, c.cx);
+    rbf_coarse_coords(g->amin[1], g->amax[1], c.ny, c.cy);
+    rbf_coarse_coords(g->amin[2], g->amax[2], c.nz, c.cz);
+    c.sigma = g->cell;                                        /* :346 */
+    c.thr = kthr;
+    c.max_distance = (float)sqrt(-log(kthr) * c.sigma * c.sigma); /* :221 */
+    float *w = (float *)malloc(sizeof(float) * (size_t)n);
+    int its = 0;
+    if (is_interp) its = rbf_cg(&c, dm, w, n);                /* :351-352 */
+    else memcpy(w, dm, sizeof(float) * (size_t)n);            /* :353 */
+    if (cg_iters) *cg_iters = its;
+    float *lsf = (float *)malloc(sizeof(float) * (size_t)n);
+    rbf_apply(&c, w, 1, c.nx, c.ny, c.nz, c.cx, c.cy, c.cz, lsf); /* :357 */
+    if (lsf_out) memcpy(lsf_out, lsf, sizeof(float) * (size_t)n);
+    /* calculate_volume_from_sdf takes the edge from the coarse grid (CalcVolumeFromSDF.jl:38-40) */
+    float ex = c.cx[1] - c.cx[0], ey = 0.0f, ez = 0.0f;
+    float edge = sqrtf(ex * ex + ey * ey + ez * ez);
+    float th = rbf_ls_threshold(lsf, c.nx, c.ny, c.nz, edge, target_volume, NULL); /* :359 */
+    if (th_out) *th_out = th;
+    /* fine grid (:60-74): uniform step dx from the x axis, explicit Float32 arithmetic */
+    int64_t fx = g->N[0] * smooth + 1, fy = g->N[1] * smooth + 1, fz = g->N[2] * smooth + 1;
+    float xmin = (float)g->amin[0], xmax = (float)g->amax[0], ymin = (float)g->amin[1], zmin = (float)g->amin[2];
+    float dx = (xmax - xmin) / (float)(fx - 1);
+    float *tx = (float *)malloc(sizeof(float) * (size_t)fx), *ty = (float *)malloc(sizeof(float) * (size_t)fy);
+    float *tz = (float *)malloc(sizeof(float) * (size_t)fz);
+    for (int64_t i = 0; i < fx; ++i) tx[i] = xmin + (float)i * dx;
+    for (int64_t i = 0; i < fy; ++i) ty[i] = ymin + (float)i * dx;
+    for (int64_t i = 0; i < fz; ++i) tz[i] = zmin + (float)i * dx;
+    rbf_apply(&c, w, smooth, fx, fy, fz, tx, ty, tz, fine_out); /* :363 */
+    for (int64_t i = 0; i < fx * fy * fz; ++i) fine_out[i] = fine_out[i] + th; /* :366 */
+    free(dm); free(w); free(lsf); free(tx); free(ty); free(tz); free(c.cx); free(c.cy); free(c.cz);
+    return 0;
+}

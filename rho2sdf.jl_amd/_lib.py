@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "librho2sdf_hip.so")
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)
+c_float_p = ctypes.POINTER(ctypes.c_float)
 
 
 class R2SGrid(ctypes.Structure):
@@ -58,6 +59,19 @@ SYMBOLS = [
      [_P, _P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_double, ctypes.POINTER(R2SGrid),
       ctypes.POINTER(R2SParams), ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P,
       ctypes.POINTER(R2SStats)]),
+    ("r2s_mesh_volume", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_int32, c_double_p, c_double_p]),
+    ("r2s_dense_in_nodes", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_int32, c_double_p]),
+    ("r2s_find_threshold", ctypes.c_int, _MESH + [c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
+                                                  ctypes.c_int32, c_double_p, ctypes.POINTER(ctypes.c_int32)]),
+    ("r2s_remove_artifacts", ctypes.c_int, [c_double_p, ctypes.POINTER(R2SGrid), ctypes.c_double, ctypes.c_double,
+                                            ctypes.c_int32, c_int64_p]),
+    ("r2s_remove_artifacts_dev", ctypes.c_int, [_P, ctypes.POINTER(R2SGrid), ctypes.c_double, ctypes.c_double, _P,
+                                                c_int64_p]),
+    ("r2s_volume_from_sdf", ctypes.c_int, [c_float_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_float,
+                                           ctypes.c_float, ctypes.c_int32, ctypes.c_int32, c_float_p]),
+    ("r2s_rbf_smooth", ctypes.c_int, [c_double_p, ctypes.POINTER(R2SGrid), ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.c_double, ctypes.c_double, ctypes.c_int32, c_float_p, c_float_p,
+                                      ctypes.POINTER(ctypes.c_int32), c_float_p]),
 ]
 
 OUT_DIST, OUT_SIGN, OUT_SDF, OUT_XP = 1, 2, 4, 8

@@ -184,3 +184,140 @@ class DevicePlan:
                                          ctypes.byref(grid.c), ctypes.byref(p), int(k_begin), k_end, mode,
                                          ptr[0], ptr[1], ptr[2], ptr[3], s, ctypes.byref(st)))
         return st.as_dict()
+
+
+# ---------------------------------------------------------------------------------------
+# pre-stage and post-processing (same thin marshalling; reference citations at each function)
+# ---------------------------------------------------------------------------------------
+def _f(a):
+    return a.ctypes.data_as(L.c_float_p)
+
+
+def calculate_mesh_volume(mesh, rho, *, device=-1):
+    """calculate_mesh_volume(X, IEN, rho, T) -> [V_domain, V_frac]   src/MeshGrid/MeshVolume.jl:4-42"""
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    vd, vf = ctypes.c_double(), ctypes.c_double()
+    L.check(L.lib().r2s_mesh_volume(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, mesh.element_type, _d(rho),
+                                    int(device), ctypes.byref(vd), ctypes.byref(vf)))
+    return vd.value, vf.value
+
+
+def DenseInNodes(mesh, rho, *, device=-1):
+    """DenseInNodes(mesh, rho) -> rho_n   src/MeshGrid/NodalDensities.jl:89-108"""
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    if rho.shape != (mesh.nel,):
+        raise L.R2SError("length of element densities does not match number of elements")
+    out = np.empty(mesh.nnp)
+    L.check(L.lib().r2s_dense_in_nodes(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, mesh.element_type, _d(rho),
+                                       int(device), _d(out)))
+    return out
+
+
+def find_threshold_for_volume(mesh, rho_n, target_volume, tolerance=1e-4, max_iterations=60, *, device=-1):
+    """find_threshold_for_volume(mesh, nodal_values, tol, maxit); target_volume = V_domain*V_frac
+    src/MeshGrid/Isocontour_volume.jl:77-154"""
+    r = _rho(mesh, rho_n)
+    rt = ctypes.c_double()
+    it = ctypes.c_int32()
+    L.check(L.lib().r2s_find_threshold(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(target_volume),
+                                       float(tolerance), int(max_iterations), int(device), ctypes.byref(rt),
+                                       ctypes.byref(it)))
+    return rt.value
+
+
+def remove_sdf_artifacts(sdf, grid, *, threshold=0.0, min_component_ratio=0.01, device=-1):
+    """remove_sdf_artifacts!(sdf, grid; threshold, min_component_ratio) -> nodes flipped (sdf modified in place)
+    src/SignedDistances/SdfArtifactRemoval.jl:134-245"""
+    if sdf.dtype != np.float64 or not sdf.flags.c_contiguous:
+        raise L.R2SError("sdf must be a contiguous float64 array (it is modified in place)")
+    if sdf.size != grid.ngp:   # SdfArtifactRemoval.jl:141-143
+        raise L.R2SError(f"SDF values length ({sdf.size}) doesn't match grid points ({grid.ngp})")
+    n = ctypes.c_int64()
+    L.check(L.lib().r2s_remove_artifacts(_d(sdf), ctypes.byref(grid.c), float(threshold), float(min_component_ratio),
+                                         int(device), ctypes.byref(n)))
+    return int(n.value)
+
+
+def calculate_volume_from_sdf(fine_sdf, edge, *, iso_threshold=0.0, detailed_quad_order=9, device=-1):
+    """calculate_volume_from_sdf(fine_sdf, fine_grid; iso_threshold, detailed_quad_order) -> Float32
+    src/SdfSmoothing/CalcVolumeFromSDF.jl:26-125; fine_sdf is (nz, ny, nx) float32, `edge` the grid spacing."""
+    a = np.ascontiguousarray(fine_sdf, dtype=np.float32)
+    nz, ny, nx = a.shape
+    v = ctypes.c_float()
+    L.check(L.lib().r2s_volume_from_sdf(_f(a), nx, ny, nz, float(edge), float(iso_threshold), int(detailed_quad_order),
+                                        int(device), ctypes.byref(v)))
+    return float(v.value)
+
+
+def RBFs_smoothing(sdf, grid, Is_interpolation, smooth, target_volume, threshold=1e-3, *, device=-1, info=None):
+    """RBFs_smoothing(mesh, dist, grid, Is_interpolation, smooth, taskName, threshold) -> fine_sdf
+    src/SdfSmoothing/RBFs4Smoothing.jl:321-377 (mesh only contributes V_frac*V_domain = target_volume).
+    Returns fine_sdf as (nz', ny', nx') float32; the fine grid is AABB_min + spacing*(i,j,k)."""
+    sdf = np.ascontiguousarray(sdf, dtype=np.float64)
+    dims = tuple(int(n) * int(smooth) + 1 for n in grid.c.N)
+    fine = np.empty(dims[2] * dims[1] * dims[0], dtype=np.float32)
+    lsf = np.empty(grid.ngp, dtype=np.float32)
+    th = ctypes.c_float()
+    its = ctypes.c_int32()
+    L.check(L.lib().r2s_rbf_smooth(_d(sdf), ctypes.byref(grid.c), int(bool(Is_interpolation)), int(smooth),
+                                   float(threshold), float(target_volume), int(device), _f(fine), ctypes.byref(th),
+                                   ctypes.byref(its), _f(lsf)))
+    if info is not None:
+        info.update(th=float(th.value), cg_iterations=int(its.value), lsf=lsf.reshape(grid.dims[2], grid.dims[1], grid.dims[0]))
+    return fine.reshape(dims[2], dims[1], dims[0])
+
+
+class Rho2sdfOptions:
+    """Rho2sdfOptions (src/RhoToSDF.jl:9-77): same fields, defaults and validation rules; file-export
+    switches are accepted and ignored here (file I/O stays in the Julia package)."""
+
+    def __init__(self, threshold_density=None, sdf_grid_setup="manual", export_input_data=False,
+                 export_nodal_densities=False, export_raw_sdf=False, rbf_interp=True, rbf_grid="same",
+                 remove_artifacts=True, artifact_min_component_ratio=0.01, export_analysis=False,
+                 element_type=None):
+        import warnings
+        if threshold_density is not None and not (0.0 <= threshold_density <= 1.0):
+            warnings.warn(f"Threshold density {threshold_density} is outside the valid range [0.0, 1.0]. "
+                          "Will use automatic calculation instead.")
+            threshold_density = None
+        if sdf_grid_setup not in ("manual", "automatic"):
+            warnings.warn(f"Invalid sdf_grid_setup: {sdf_grid_setup}. Using default manual instead.")
+            sdf_grid_setup = "manual"
+        if rbf_grid not in ("same", "fine"):
+            warnings.warn(f"Invalid rbf_grid: {rbf_grid}. Using default same instead.")
+            rbf_grid = "same"
+        self.threshold_density = threshold_density
+        self.sdf_grid_setup = sdf_grid_setup
+        self.rbf_interp = rbf_interp
+        self.rbf_grid = rbf_grid
+        self.remove_artifacts = remove_artifacts
+        self.artifact_min_component_ratio = artifact_min_component_ratio
+        self.element_type = element_type
+
+
+def rho2sdf(taskName, X, IEN, rho, *, options=None, sdf_grid=None, device=-1):
+    """rho2sdf(taskName, X, IEN, rho; options) -> (fine_sdf, fine_grid, sdf_grid, sdf_dists)
+    src/RhoToSDF.jl:116-242, computing stages only (no file export).  `sdf_grid` replaces the
+    interactive prompt of sdf_grid_setup = :manual (Grid_setup.jl:111-154 is out of scope).
+    fine_grid is returned as (origin, spacing, dims) instead of one heap vector per voxel."""
+    options = options or Rho2sdfOptions()
+    mesh = Mesh(X, IEN, options.element_type)
+    V_domain, V_frac = calculate_mesh_volume(mesh, rho, device=device)                      # :128
+    if sdf_grid is None:
+        if options.sdf_grid_setup != "automatic":
+            raise L.R2SError("sdf_grid_setup = :manual needs an explicit sdf_grid here")
+        sdf_grid = noninteractive_sdf_grid_setup(mesh)                                       # :141-145
+    rho_n = DenseInNodes(mesh, rho, device=device)                                           # :148
+    rho_t = options.threshold_density                                                        # :151-156
+    if rho_t is None:
+        rho_t = find_threshold_for_volume(mesh, rho_n, V_domain * V_frac, device=device)
+    sdf_dists = sdf_fused(mesh, sdf_grid, rho_n, rho_t, device=device)                       # :169-171
+    if options.remove_artifacts:                                                             # :174-208
+        remove_sdf_artifacts(sdf_dists, sdf_grid, threshold=0.0,
+                             min_component_ratio=options.artifact_min_component_ratio, device=device)
+    smooth = 1 if options.rbf_grid == "same" else 2                                          # :222
+    fine_sdf = RBFs_smoothing(sdf_dists, sdf_grid, options.rbf_interp, smooth, V_frac * V_domain, device=device)
+    xmin, xmax = np.float32(sdf_grid.AABB_min[0]), np.float32(sdf_grid.AABB_max[0])
+    spacing = (xmax - xmin) / np.float32(fine_sdf.shape[2] - 1)
+    fine_grid = (sdf_grid.AABB_min.astype(np.float32), float(spacing), fine_sdf.shape[::-1])
+    return fine_sdf, fine_grid, sdf_grid, sdf_dists

@@ -253,7 +253,7 @@ R2S_DEV bool qp_pattern(int pat, const double H[3][3], const double g[3], const 
     return true;
 }
 
-__constant__ int c_pat_order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8, 10, 11, 19, 20, 12, 15, 21, 24};
+static __constant__ int c_pat_order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8, 10, 11, 19, 20, 12, 15, 21, 24};
 
 R2S_DEV bool spd3(const double H[3][3])
 {

@@ -1,0 +1,706 @@
+// Post-processing stages of the hot path on gfx950:
+//   remove_sdf_artifacts!       (src/SignedDistances/SdfArtifactRemoval.jl:134-245)
+//   calculate_volume_from_sdf   (src/SdfSmoothing/CalcVolumeFromSDF.jl:26-125)
+//   RBFs_smoothing              (src/SdfSmoothing/RBFs4Smoothing.jl:321-377)
+// All grid sweeps, x-fastest, HBM-bound except the quadrature on cut cells.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "r2s_common.hpp"
+
+// ====================================================================================
+// connected components of {sdf >= threshold}, 6-connectivity: lock-free union-find with
+// the smallest linear index as root (the serial reference semantics, analyze_sdf_components
+// :271-285; the reference's threaded union-find is racy).
+// ====================================================================================
+#define NOLABEL 0xFFFFFFFFu
+
+__device__ __forceinline__ uint32_t uf_load(const uint32_t* L, uint32_t i)
+{
+    // parents are rewritten by other CUs during the kernel: bypass the per-CU L1
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t* L, uint32_t x)
+{
+    for (;;) {
+        const uint32_t p = uf_load(L, x);
+        if (p == x) return x;
+        x = p;
+    }
+}
+
+__device__ __forceinline__ void uf_union(uint32_t* L, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }   // link the larger root under the smaller
+        const uint32_t old = atomicCAS(&L[a], a, b);
+        if (old == a) return;                                // a was still a root
+    }
+}
+
+__global__ void ccl_init_kernel(const double* __restrict__ sdf, uint32_t n, double thr, uint32_t* __restrict__ L)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) L[v] = (sdf[v] >= thr) ? v : NOLABEL;
+}
+
+__global__ void ccl_union_kernel(uint32_t* __restrict__ L, int nx, int ny, int nz)
+{
+    const uint32_t n = (uint32_t)nx * ny * nz;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    if (uf_load(L, v) == NOLABEL) return;
+    const int i = v % nx, j = (v / nx) % ny, k = v / ((uint32_t)nx * ny);
+    if (i + 1 < nx && uf_load(L, v + 1) != NOLABEL) uf_union(L, v, v + 1);
+    if (j + 1 < ny && uf_load(L, v + nx) != NOLABEL) uf_union(L, v, v + nx);
+    if (k + 1 < nz && uf_load(L, v + (uint32_t)nx * ny) != NOLABEL) uf_union(L, v, v + (uint32_t)nx * ny);
+}
+
+__global__ void ccl_flatten_count_kernel(const uint32_t* __restrict__ L, uint32_t n, uint32_t* __restrict__ root,
+                                         uint32_t* __restrict__ size)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint32_t r = L[v];
+    if (r != NOLABEL) {
+        while (L[r] != r) r = L[r];
+        atomicAdd(&size[r], 1u);
+    }
+    root[v] = r;
+}
+
+// counters: [0] largest size, [1] smallest root having it, [2] flipped count, [3] interior count
+__global__ void ccl_max_kernel(const uint32_t* __restrict__ size, uint32_t n, uint32_t* __restrict__ counters)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n && size[v]) {
+        atomicMax(&counters[0], size[v]);
+        atomicAdd(&counters[3], size[v]);
+    }
+}
+__global__ void ccl_argmax_kernel(const uint32_t* __restrict__ size, uint32_t n, uint32_t* __restrict__ counters)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n && size[v] == counters[0] && size[v]) atomicMin(&counters[1], v);
+}
+__global__ void ccl_flip_kernel(double* __restrict__ sdf, const uint32_t* __restrict__ root,
+                                const uint32_t* __restrict__ size, uint32_t n, uint32_t largest_root,
+                                uint32_t min_size, uint32_t* __restrict__ counters)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t r = root[v];
+    if (r != NOLABEL && r != largest_root && size[r] < min_size) {   // SdfArtifactRemoval.jl:220
+        sdf[v] = -fabs(sdf[v]);                                       // :234
+        atomicAdd(&counters[2], 1u);
+    }
+}
+
+static int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, double min_ratio,
+                                hipStream_t st, int64_t* n_flipped)
+{
+    const int64_t n64 = g->ngp;
+    if (n64 <= 0 || n64 >= 0xFFFFFFFFll) return fail(R2S_ERR_ARG, "grid too large for 32-bit labels");
+    const uint32_t n = (uint32_t)n64;
+    const int nx = (int)g->N[0] + 1, ny = (int)g->N[1] + 1, nz = (int)g->N[2] + 1;
+    DevBuf L, root, size, cnt;
+    ENSURE(L, sizeof(uint32_t) * (size_t)n);
+    ENSURE(root, sizeof(uint32_t) * (size_t)n);
+    ENSURE(size, sizeof(uint32_t) * (size_t)n);
+    ENSURE(cnt, 64);
+    auto cleanup = [&]() { L.release(); root.release(); size.release(); cnt.release(); };
+    const unsigned nb = (n + 255) / 256;
+    uint32_t h[4] = {0, NOLABEL, 0, 0};
+    hipError_t e = hipMemcpyAsync(cnt.p, h, sizeof h, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(size.p, 0, sizeof(uint32_t) * (size_t)n, st);
+    if (e != hipSuccess) { cleanup(); return fail(R2S_ERR_HIP, "%s", hipGetErrorString(e)); }
+    ccl_init_kernel<<<nb, 256, 0, st>>>(d_sdf, n, threshold, L.as<uint32_t>());
+    ccl_union_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), nx, ny, nz);
+    ccl_flatten_count_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), n, root.as<uint32_t>(), size.as<uint32_t>());
+    ccl_max_kernel<<<nb, 256, 0, st>>>(size.as<uint32_t>(), n, cnt.as<uint32_t>());
+    ccl_argmax_kernel<<<nb, 256, 0, st>>>(size.as<uint32_t>(), n, cnt.as<uint32_t>());
+    e = hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { cleanup(); return fail(R2S_ERR_HIP, "%s", hipGetErrorString(e)); }
+    int64_t flipped = 0;
+    if (h[3] != 0) {   // interior_count == 0 -> nothing to do (:150-153)
+        // min_component_size = max(1, round(Int, ratio*largest)), Julia round = ties to even (:206)
+        long long ms = (long long)std::nearbyint(min_ratio * (double)h[0]);
+        if (ms < 1) ms = 1;
+        const uint32_t min_size = ms > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)ms;
+        ccl_flip_kernel<<<nb, 256, 0, st>>>(d_sdf, root.as<uint32_t>(), size.as<uint32_t>(), n, h[1], min_size,
+                                          cnt.as<uint32_t>());
+        e = hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { cleanup(); return fail(R2S_ERR_HIP, "%s", hipGetErrorString(e)); }
+        flipped = h[2];
+    }
+    cleanup();
+    if (n_flipped) *n_flipped = flipped;
+    return 0;
+}
+
+// ====================================================================================
+// Gauss-Legendre tables (FastGaussQuadrature.gausslegendre stand-in, host side)
+// ====================================================================================
+static void gauss_legendre(int n, double* x, double* w)
+{
+    if (n == 3) {
+        x[0] = -std::sqrt(3.0 / 5.0); x[1] = 0.0; x[2] = std::sqrt(3.0 / 5.0);
+        w[0] = 5.0 / 9.0; w[1] = 8.0 / 9.0; w[2] = 5.0 / 9.0;
+        return;
+    }
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < n; ++i) {
+        double z = std::cos(pi * ((double)(n - 1 - i) + 0.75) / ((double)n + 0.5));
+        double pp = 1.0;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 1; j <= n; ++j) {
+                const double p3 = p2;
+                p2 = p1;
+                p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j;
+            }
+            pp = n * (z * p1 - p2) / (z * z - 1.0);
+            const double dz = p1 / pp;
+            z -= dz;
+            if (std::fabs(dz) < 1e-16) break;
+        }
+        if ((n % 2) && i == n / 2) z = 0.0;
+        double p1 = 1.0, p2 = 0.0;
+        for (int j = 1; j <= n; ++j) {
+            const double p3 = p2;
+            p2 = p1;
+            p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j;
+        }
+        pp = n * (z * p1 - p2) / (z * z - 1.0);
+        x[i] = z;
+        w[i] = 2.0 / ((1.0 - z * z) * pp * pp);
+    }
+    for (int i = 0; i < n / 2; ++i) {
+        const double xa = 0.5 * (x[n - 1 - i] - x[i]), wa = 0.5 * (w[i] + w[n - 1 - i]);
+        x[i] = -xa; x[n - 1 - i] = xa; w[i] = wa; w[n - 1 - i] = wa;
+    }
+}
+extern "C" void r2s_internal_gauss_legendre(int n, double* x, double* w) { gauss_legendre(n, x, w); }
+
+// ====================================================================================
+// calculate_volume_from_sdf: 1 thread / cell; full cells add a^3, cut cells run the order^3
+// tensor quadrature of the trilinear interpolant (all Float32, same expressions).  Block
+// partial sums (Float32) are reduced by a second kernel in a fixed order (the reference's
+// Float32 atomics make its own sum order-dependent).
+// ====================================================================================
+struct QuadTab {
+    float gp[32];
+    float gw[32];
+    int order;
+};
+
+__global__ void __launch_bounds__(256) volume_cells_kernel(const float* __restrict__ sdf, int nx, int ny, int nz,
+                                                          float shift, float iso, float elvol, float jac,
+                                                          QuadTab q, float* __restrict__ partial)
+{
+    __shared__ float red[256];
+    const int64_t ncell = (int64_t)(nx - 1) * (ny - 1) * (nz - 1);
+    float acc = 0.0f;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(c % (nx - 1)), j = (int)((c / (nx - 1)) % (ny - 1)), k = (int)(c / ((int64_t)(nx - 1) * (ny - 1)));
+        const int64_t b = ((int64_t)k * ny + j) * nx + i, sy = nx, sz = (int64_t)nx * ny;
+        // `shifted_sdf .= sdf .- th` (RBFs4Smoothing.jl:286) folded into the loads
+        const float c000 = sdf[b] - shift, c100 = sdf[b + 1] - shift, c010 = sdf[b + sy] - shift,
+                    c110 = sdf[b + sy + 1] - shift, c001 = sdf[b + sz] - shift, c101 = sdf[b + sz + 1] - shift,
+                    c011 = sdf[b + sz + sy] - shift, c111 = sdf[b + sz + sy + 1] - shift;
+        const float mn = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111)));
+        const float mx = fmaxf(fmaxf(fmaxf(c000, c100), fmaxf(c010, c110)), fmaxf(fmaxf(c001, c101), fmaxf(c011, c111)));
+        if (mx < iso) continue;
+        if (mn >= iso) { acc += elvol; continue; }
+        float part = 0.0f;
+        for (int kq = 0; kq < q.order; ++kq) {
+            const float zeta = (q.gp[kq] + 1) / 2;
+            for (int jq = 0; jq < q.order; ++jq) {
+                const float eta = (q.gp[jq] + 1) / 2;
+                for (int iq = 0; iq < q.order; ++iq) {
+                    const float xi = (q.gp[iq] + 1) / 2;
+                    const float c00 = c000 * (1.0f - xi) + c100 * xi;
+                    const float c01 = c001 * (1.0f - xi) + c101 * xi;
+                    const float c10 = c010 * (1.0f - xi) + c110 * xi;
+                    const float c11 = c011 * (1.0f - xi) + c111 * xi;
+                    const float c0 = c00 * (1.0f - eta) + c10 * eta;
+                    const float c1 = c01 * (1.0f - eta) + c11 * eta;
+                    const float p = c0 * (1.0f - zeta) + c1 * zeta;
+                    if (p >= iso) part += q.gw[iq] * q.gw[jq] * q.gw[kq] * jac;
+                }
+            }
+        }
+        acc += part;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) sum_f32_kernel(const float* __restrict__ in, int n, float* __restrict__ out)
+{
+    __shared__ float red[256];
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += in[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+struct VolumeWork {
+    DevBuf partial, result;
+    QuadTab q;
+    int nblocks = 2048;
+    int init(int order)
+    {
+        if (order < 1 || order > 32) return fail(R2S_ERR_ARG, "quadrature order %d not in 1..32", order);
+        double x[32], w[32];
+        gauss_legendre(order, x, w);
+        for (int i = 0; i < order; ++i) { q.gp[i] = (float)x[i]; q.gw[i] = (float)w[i]; }   // CalcVolumeFromSDF.jl:43-44
+        q.order = order;
+        ENSURE(partial, sizeof(float) * (size_t)nblocks);
+        ENSURE(result, 64);
+        return 0;
+    }
+    // volume of {sdf - shift >= iso}; synchronises the stream
+    int run(const float* d_sdf, int nx, int ny, int nz, float edge, float shift, float iso, hipStream_t st, float* out)
+    {
+        const float elvol = edge * edge * edge;       // element_edge_length^3 (:40)
+        const float jac = elvol / 8.0f;               // :51
+        volume_cells_kernel<<<nblocks, 256, 0, st>>>(d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>());
+        sum_f32_kernel<<<1, 256, 0, st>>>(partial.as<float>(), nblocks, result.as<float>());
+        HIP_TRY(hipMemcpyAsync(out, result.p, sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
+    void release() { partial.release(); result.release(); }
+};
+
+// ====================================================================================
+// RBF smoothing.  KDTree inrange/knn on a regular lattice = fixed stencil; neighbours are
+// visited by increasing lattice distance (ties dz,dy,dx), distances from the reference's
+// Float32 coordinates, Float64 sigma inside exp, Float32 accumulation (RBFs4Smoothing.jl:238-243).
+// ====================================================================================
+struct Stencil {
+    int n;
+    signed char off[512][3];
+};
+
+static void build_stencil(int s, const int frac[3], Stencil* st)
+{
+    int cand[512][4], n = 0;
+    for (int dz = -3; dz <= 4; ++dz)
+        for (int dy = -3; dy <= 4; ++dy)
+            for (int dx = -3; dx <= 4; ++dx) {
+                const int ex = dx * s - frac[0], ey = dy * s - frac[1], ez = dz * s - frac[2];
+                const int d2 = ex * ex + ey * ey + ez * ez;
+                if (d2 > 9 * s * s) continue;
+                cand[n][0] = d2; cand[n][1] = dz; cand[n][2] = dy; cand[n][3] = dx;
+                n++;
+            }
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) {
+        for (int q = 0; q < 4; ++q)
+            if (cand[a][q] != cand[b][q]) return cand[a][q] < cand[b][q];
+        return false;
+    });
+    st->n = n;
+    for (int i = 0; i < n; ++i) {
+        st->off[i][0] = (signed char)cand[idx[i]][3];
+        st->off[i][1] = (signed char)cand[idx[i]][2];
+        st->off[i][2] = (signed char)cand[idx[i]][1];
+    }
+}
+
+struct RbfGeom {
+    int nx, ny, nz;          // coarse lattice
+    const float *cx, *cy, *cz;
+    double sigma;
+    float max_distance;
+    double thr;
+};
+
+// rbf_interpolation_kdtree (:219-248): 1 thread / target point
+__global__ void __launch_bounds__(256) rbf_apply_kernel(RbfGeom G, const float* __restrict__ w, int s, int tnx, int tny,
+                                                       int tnz, const float* __restrict__ tx,
+                                                       const float* __restrict__ ty, const float* __restrict__ tz,
+                                                       const Stencil* __restrict__ stencils, float add,
+                                                       float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nt = (int64_t)tnx * tny * tnz;
+    if (t >= nt) return;
+    const int i = (int)(t % tnx), j = (int)((t / tnx) % tny), k = (int)(t / ((int64_t)tnx * tny));
+    const Stencil& S = stencils[((k % s) * s + (j % s)) * s + (i % s)];
+    const int bi = i / s, bj = j / s, bk = k / s;
+    const float px = tx[i], py = ty[j], pz = tz[k];
+    float acc = 0.0f;
+    for (int q = 0; q < S.n; ++q) {
+        const int ci = bi + S.off[q][0], cj = bj + S.off[q][1], ck = bk + S.off[q][2];
+        if (ci < 0 || cj < 0 || ck < 0 || ci >= G.nx || cj >= G.ny || ck >= G.nz) continue;
+        const float dx = px - G.cx[ci], dy = py - G.cy[cj], dz = pz - G.cz[ck];
+        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (dist <= G.max_distance) {
+            const double u = (double)dist / G.sigma;
+            acc = (float)((double)acc + (double)w[((int64_t)ck * G.ny + cj) * G.nx + ci] * exp(-(u * u)));
+        }
+    }
+    out[t] = acc + add;
+}
+
+// y = K x, K = compute_sparse_kernel_matrix (:142-176); row accumulation in ascending linear index
+__global__ void __launch_bounds__(256) rbf_matvec_kernel(RbfGeom G, const float* __restrict__ x, float* __restrict__ y)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
+    if (t >= n) return;
+    const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
+    const float px = G.cx[i], py = G.cy[j], pz = G.cz[k];
+    float acc = 0.0f;
+    for (int ck = k - 3; ck <= k + 3; ++ck)
+        for (int cj = j - 3; cj <= j + 3; ++cj)
+            for (int ci = i - 3; ci <= i + 3; ++ci) {
+                if (ci < 0 || cj < 0 || ck < 0 || ci >= G.nx || cj >= G.ny || ck >= G.nz) continue;
+                const float dx = px - G.cx[ci], dy = py - G.cy[cj], dz = pz - G.cz[ck];
+                const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+                const double u = (double)r / G.sigma;
+                const double val = exp(-(u * u));
+                if (val > G.thr) acc += (float)val * x[((int64_t)ck * G.ny + cj) * G.nx + ci];
+            }
+    y[t] = acc;
+}
+
+// process_vector (:15-22), pass 1: max |v| over |v| < 1e9 (as Float32 bits, all non-negative)
+__global__ void pv_max_kernel(const double* __restrict__ v, int64_t n, float* __restrict__ f, uint32_t* __restrict__ maxbits,
+                              uint32_t* __restrict__ any)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = (float)v[i];
+    f[i] = x;
+    const float a = fabsf(x);
+    if (a < 1.0e9f) {
+        atomicMax(maxbits, __float_as_uint(a));
+        *any = 1u;
+    }
+}
+__global__ void pv_replace_kernel(float* __restrict__ f, int64_t n, const uint32_t* __restrict__ maxbits)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float mx = __uint_as_float(*maxbits);
+    const float x = f[i], a = fabsf(x);
+    const float rtol = 3.4526698e-4f;   // sqrt(eps(Float32)): isapprox default
+    const float big = a > 1.0e10f ? a : 1.0e10f;
+    if (fabsf(a - 1.0e10f) <= rtol * big) f[i] = (x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f)) * mx;
+}
+
+// Float32 vectors, dot products accumulated in Float64 (BLAS sdot/snrm2 stand-in)
+__global__ void __launch_bounds__(256) dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                 double* __restrict__ partial)
+{
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += (double)a[i] * (double)b[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(256) sum_f64_kernel(const double* __restrict__ in, int n, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += in[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+__global__ void cg_update_u_kernel(float* __restrict__ u, const float* __restrict__ r, float beta, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) u[i] = r[i] + beta * u[i];
+}
+__global__ void cg_update_xr_kernel(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ u,
+                                    const float* __restrict__ q, float alpha, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        x[i] += alpha * u[i];
+        r[i] -= alpha * q[i];
+    }
+}
+__global__ void minmax_kernel(const float* __restrict__ v, int64_t n, int* __restrict__ mm)
+{
+    // order-preserving int encoding of floats
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b = __float_as_int(v[i]);
+    b = b >= 0 ? b : (b ^ 0x7FFFFFFF);
+    atomicMin(&mm[0], b);
+    atomicMax(&mm[1], b);
+}
+
+static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
+{
+    // create_grid (:36-46): Float32 range(min, max, length)
+    c.resize(n);
+    const double a = (double)(float)mn, b = (double)(float)mx;
+    for (int i = 0; i < n; ++i) c[i] = (float)(a + (double)i * (b - a) / (double)(n - 1));
+    c[n - 1] = (float)mx;
+}
+
+static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, int smooth, double kthr,
+                           double target_volume, float* fine_out, float* th_out, int* cg_iters, float* lsf_out)
+{
+    if (!sdf || !g || !fine_out) return fail(R2S_ERR_ARG, "null argument");
+    if (smooth < 1 || smooth > 4) return fail(R2S_ERR_ARG, "smooth must be 1..4");
+    if (!(kthr > 0.0 && kthr < 1.0)) return fail(R2S_ERR_ARG, "kernel threshold must be in (0,1)");
+    const int nx = (int)g->N[0] + 1, ny = (int)g->N[1] + 1, nz = (int)g->N[2] + 1;
+    const int64_t n = (int64_t)nx * ny * nz;
+    const int fx = (int)g->N[0] * smooth + 1, fy = (int)g->N[1] * smooth + 1, fz = (int)g->N[2] * smooth + 1;
+    const int64_t nf = (int64_t)fx * fy * fz;
+    hipStream_t st = nullptr;
+    DevBuf d_sdf, d_f, d_w, d_lsf, d_fine, d_cx, d_cy, d_cz, d_tx, d_ty, d_tz, d_st, d_cnt, d_r, d_u, d_q, d_part, d_sum;
+    VolumeWork vw;
+    auto cleanup = [&]() {
+        DevBuf* all[] = {&d_sdf, &d_f, &d_w, &d_lsf, &d_fine, &d_cx, &d_cy, &d_cz, &d_tx, &d_ty, &d_tz, &d_st, &d_cnt,
+                         &d_r, &d_u, &d_q, &d_part, &d_sum};
+        for (DevBuf* b : all) b->release();
+        vw.release();
+    };
+#define TRY_C(expr)                                                                   \
+    do {                                                                              \
+        int rc_ = (expr);                                                             \
+        if (rc_) { cleanup(); return rc_; }                                           \
+    } while (0)
+#define HIP_C(expr)                                                                   \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) { cleanup(); return fail(R2S_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
+    } while (0)
+#define ENSURE_C(buf, bytes)                                                          \
+    do {                                                                              \
+        if ((buf).ensure(bytes)) { cleanup(); return fail(R2S_ERR_NOMEM, "hipMalloc of %zu bytes failed", (size_t)(bytes)); } \
+    } while (0)
+    ENSURE_C(d_sdf, sizeof(double) * (size_t)n);
+    ENSURE_C(d_f, sizeof(float) * (size_t)n);
+    ENSURE_C(d_w, sizeof(float) * (size_t)n);
+    ENSURE_C(d_lsf, sizeof(float) * (size_t)n);
+    ENSURE_C(d_fine, sizeof(float) * (size_t)nf);
+    ENSURE_C(d_cnt, 64);
+    HIP_C(hipMemcpy(d_sdf.p, sdf, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    // ---- process_vector ----
+    HIP_C(hipMemset(d_cnt.p, 0, 64));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    pv_max_kernel<<<nb, 256, 0, st>>>(d_sdf.as<double>(), n, d_f.as<float>(), d_cnt.as<uint32_t>(), d_cnt.as<uint32_t>() + 1);
+    uint32_t hc[2];
+    HIP_C(hipMemcpy(hc, d_cnt.p, 8, hipMemcpyDeviceToHost));
+    if (!hc[1]) { cleanup(); return fail(R2S_ERR_ARG, "every SDF value is a sentinel: nothing to smooth"); }   // A15
+    pv_replace_kernel<<<nb, 256, 0, st>>>(d_f.as<float>(), n, d_cnt.as<uint32_t>());
+    // ---- geometry ----
+    std::vector<float> cx, cy, cz, tx(fx), ty(fy), tz(fz);
+    coarse_coords(g->aabb_min[0], g->aabb_max[0], nx, cx);
+    coarse_coords(g->aabb_min[1], g->aabb_max[1], ny, cy);
+    coarse_coords(g->aabb_min[2], g->aabb_max[2], nz, cz);
+    {
+        // create_smooth_grid (:60-74): one step dx (from the x axis) for all three axes
+        const float xmin = (float)g->aabb_min[0], xmax = (float)g->aabb_max[0], ymin = (float)g->aabb_min[1],
+                    zmin = (float)g->aabb_min[2];
+        const float dx = (xmax - xmin) / (float)(fx - 1);
+        for (int i = 0; i < fx; ++i) tx[i] = xmin + (float)i * dx;
+        for (int i = 0; i < fy; ++i) ty[i] = ymin + (float)i * dx;
+        for (int i = 0; i < fz; ++i) tz[i] = zmin + (float)i * dx;
+    }
+    auto up = [&](DevBuf& b, const std::vector<float>& v) -> int {
+        if (b.ensure(sizeof(float) * v.size())) return fail(R2S_ERR_NOMEM, "hipMalloc failed");
+        if (hipMemcpy(b.p, v.data(), sizeof(float) * v.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(R2S_ERR_HIP, "hipMemcpy failed");
+        return 0;
+    };
+    TRY_C(up(d_cx, cx)); TRY_C(up(d_cy, cy)); TRY_C(up(d_cz, cz));
+    TRY_C(up(d_tx, tx)); TRY_C(up(d_ty, ty)); TRY_C(up(d_tz, tz));
+    // stencils for smooth = 1 (one class) and for the fine grid (smooth^3 classes)
+    std::vector<Stencil> sts(1 + (size_t)smooth * smooth * smooth);
+    {
+        int fr0[3] = {0, 0, 0};
+        build_stencil(1, fr0, &sts[0]);
+        for (int a = 0; a < smooth; ++a)
+            for (int b = 0; b < smooth; ++b)
+                for (int c = 0; c < smooth; ++c) {
+                    int fr[3] = {c, b, a};
+                    build_stencil(smooth, fr, &sts[1 + (a * smooth + b) * smooth + c]);
+                }
+    }
+    ENSURE_C(d_st, sizeof(Stencil) * sts.size());
+    HIP_C(hipMemcpy(d_st.p, sts.data(), sizeof(Stencil) * sts.size(), hipMemcpyHostToDevice));
+    RbfGeom G;
+    G.nx = nx; G.ny = ny; G.nz = nz;
+    G.cx = d_cx.as<float>(); G.cy = d_cy.as<float>(); G.cz = d_cz.as<float>();
+    G.sigma = g->cell_size;                                                    // :346
+    G.thr = kthr;
+    G.max_distance = (float)std::sqrt(-std::log(kthr) * G.sigma * G.sigma);     // :221
+    // ---- weights ----
+    int its = 0;
+    if (is_interp) {   // compute_rbf_weights (:191-202): cg(K, b), IterativeSolvers 0.9.4 defaults
+        ENSURE_C(d_r, sizeof(float) * (size_t)n);
+        ENSURE_C(d_u, sizeof(float) * (size_t)n);
+        ENSURE_C(d_q, sizeof(float) * (size_t)n);
+        ENSURE_C(d_part, sizeof(double) * 1024);
+        ENSURE_C(d_sum, 64);
+        auto dot = [&](const float* a, const float* b, float* out) -> int {
+            dot_kernel<<<1024, 256, 0, st>>>(a, b, n, d_part.as<double>());
+            sum_f64_kernel<<<1, 256, 0, st>>>(d_part.as<double>(), 1024, d_sum.as<double>());
+            double h;
+            HIP_TRY(hipMemcpy(&h, d_sum.p, 8, hipMemcpyDeviceToHost));
+            *out = (float)h;
+            return 0;
+        };
+        HIP_C(hipMemcpy(d_r.p, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice));
+        HIP_C(hipMemset(d_u.p, 0, sizeof(float) * (size_t)n));
+        HIP_C(hipMemset(d_w.p, 0, sizeof(float) * (size_t)n));
+        float rr;
+        TRY_C(dot(d_r.as<float>(), d_r.as<float>(), &rr));
+        float residual = std::sqrt(rr), prev = 1.0f;
+        const float tol = 3.4526698e-4f * residual;   // reltol = sqrt(eps(Float32)), abstol = 0
+        while (!(residual <= tol) && its < n) {
+            const float beta = (residual * residual) / (prev * prev);
+            cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
+            rbf_matvec_kernel<<<nb, 256, 0, st>>>(G, d_u.as<float>(), d_q.as<float>());
+            float uq;
+            TRY_C(dot(d_u.as<float>(), d_q.as<float>(), &uq));
+            const float alpha = (residual * residual) / uq;
+            cg_update_xr_kernel<<<nb, 256, 0, st>>>(d_w.as<float>(), d_r.as<float>(), d_u.as<float>(), d_q.as<float>(), alpha, n);
+            prev = residual;
+            TRY_C(dot(d_r.as<float>(), d_r.as<float>(), &rr));
+            residual = std::sqrt(rr);
+            its++;
+        }
+    } else {
+        HIP_C(hipMemcpy(d_w.p, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice));   // :353
+    }
+    if (cg_iters) *cg_iters = its;
+    // ---- LSF on the coarse grid (:357) and the volume-preserving level (:359, :265-300) ----
+    rbf_apply_kernel<<<nb, 256, 0, st>>>(G, d_w.as<float>(), 1, nx, ny, nz, d_cx.as<float>(), d_cy.as<float>(),
+                                        d_cz.as<float>(), d_st.as<Stencil>(), 0.0f, d_lsf.as<float>());
+    if (lsf_out) HIP_C(hipMemcpy(lsf_out, d_lsf.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    int mmh[2] = {0x7FFFFFFF, (int)0x80000000};
+    HIP_C(hipMemcpy(d_cnt.p, mmh, 8, hipMemcpyHostToDevice));
+    minmax_kernel<<<nb, 256, 0, st>>>(d_lsf.as<float>(), n, d_cnt.as<int>());
+    HIP_C(hipMemcpy(mmh, d_cnt.p, 8, hipMemcpyDeviceToHost));
+    auto dec = [](int b) { b = b >= 0 ? b : (b ^ 0x7FFFFFFF); float f; memcpy(&f, &b, 4); return f; };
+    float lo = dec(mmh[0]), hi = dec(mmh[1]);
+    TRY_C(vw.init(9));
+    const float edge = std::sqrt((cx[1] - cx[0]) * (cx[1] - cx[0]));   // norm(fine_grid[2,1,1] - fine_grid[1,1,1])
+    double eps = 1.0;
+    float th = 0.0f;
+    int it = 0;
+    while (it < 40 && eps > 1.0e-4) {
+        th = (lo + hi) / 2;
+        float vol;
+        TRY_C(vw.run(d_lsf.as<float>(), nx, ny, nz, edge, th, 0.0f, st, &vol));
+        eps = std::fabs(target_volume - (double)vol);
+        if ((double)vol > target_volume) lo = th; else hi = th;
+        it++;
+    }
+    th = -th;
+    if (th_out) *th_out = th;
+    // ---- fine grid (:363-366) ----
+    const unsigned nbf = (unsigned)((nf + 255) / 256);
+    rbf_apply_kernel<<<nbf, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
+                                         d_tz.as<float>(), d_st.as<Stencil>() + 1, th, d_fine.as<float>());
+    HIP_C(hipGetLastError());
+    HIP_C(hipMemcpy(fine_out, d_fine.p, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost));
+    cleanup();
+    return 0;
+}
+
+extern "C" {
+
+int r2s_remove_artifacts(double* sdf_inout, const r2s_grid* grid, double threshold, double min_ratio, int32_t device,
+                         int64_t* n_flipped)
+{
+    if (!sdf_inout || !grid) return fail(R2S_ERR_ARG, "null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf d;
+    ENSURE(d, sizeof(double) * (size_t)grid->ngp);
+    hipError_t e = hipMemcpy(d.p, sdf_inout, sizeof(double) * (size_t)grid->ngp, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { d.release(); return fail(R2S_ERR_HIP, "%s", hipGetErrorString(e)); }
+    rc = remove_artifacts_dev(d.as<double>(), grid, threshold, min_ratio, nullptr, n_flipped);
+    if (!rc) {
+        e = hipMemcpy(sdf_inout, d.p, sizeof(double) * (size_t)grid->ngp, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(R2S_ERR_HIP, "%s", hipGetErrorString(e));
+    }
+    d.release();
+    return rc;
+}
+
+int r2s_remove_artifacts_dev(double* d_sdf, const r2s_grid* grid, double threshold, double min_ratio, void* stream,
+                             int64_t* n_flipped)
+{
+    if (!d_sdf || !grid) return fail(R2S_ERR_ARG, "null argument");
+    return remove_artifacts_dev(d_sdf, grid, threshold, min_ratio, (hipStream_t)stream, n_flipped);
+}
+
+int r2s_volume_from_sdf(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float edge, float iso,
+                        int32_t quad_order, int32_t device, float* vol_out)
+{
+    if (!sdf || !vol_out || nx < 2 || ny < 2 || nz < 2) return fail(R2S_ERR_ARG, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    VolumeWork vw;
+    DevBuf d;
+    rc = vw.init(quad_order);
+    if (rc) return rc;
+    const size_t bytes = sizeof(float) * (size_t)(nx * ny * nz);
+    if (d.ensure(bytes)) { vw.release(); return fail(R2S_ERR_NOMEM, "hipMalloc failed"); }
+    hipError_t e = hipMemcpy(d.p, sdf, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(R2S_ERR_HIP, "%s", hipGetErrorString(e));
+    if (!rc) rc = vw.run(d.as<float>(), (int)nx, (int)ny, (int)nz, edge, 0.0f, iso, nullptr, vol_out);
+    d.release();
+    vw.release();
+    return rc;
+}
+
+int r2s_rbf_smooth(const double* sdf, const r2s_grid* grid, int32_t is_interp, int32_t smooth, double kernel_threshold,
+                   double target_volume, int32_t device, float* fine_sdf_out, float* level_shift_out,
+                   int32_t* cg_iters_out, float* lsf_out)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    int its = 0;
+    rc = rbf_smooth_host(sdf, grid, is_interp, smooth, kernel_threshold, target_volume, fine_sdf_out, level_shift_out,
+                         &its, lsf_out);
+    if (cg_iters_out) *cg_iters_out = its;
+    return rc;
+}
+
+}  // extern "C"

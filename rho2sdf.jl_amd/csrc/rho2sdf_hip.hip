@@ -21,31 +21,10 @@
 #include <vector>
 
 #include "../../include/rho2sdf_hip.h"
+#include "r2s_common.hpp"
 #include "r2s_device_math.hpp"
 
 using namespace r2s;
-
-// ------------------------------------------------------------------------------------
-// error handling
-// ------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-static int fail(int code, const char* fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
-#define HIP_TRY(expr)                                                                      \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess)                                                              \
-            return fail(R2S_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                               \
-    } while (0)
 
 // ------------------------------------------------------------------------------------
 // element topology (src/ElementTypes/ElementTypes.jl:15-78), 0-based
@@ -668,34 +647,6 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
 // ------------------------------------------------------------------------------------
 // plan: device workspace that survives across calls
 // ------------------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes)
-    {
-        if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) {
-            (void)hipGetLastError();
-            if (hipMalloc(&p, bytes) != hipSuccess) return -1;
-            want = bytes;
-        }
-        cap = want;
-        return 0;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T>
-    T* as() { return reinterpret_cast<T*>(p); }
-};
-
 struct r2s_plan {
     int device = 0;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
@@ -720,17 +671,6 @@ static int scan_exclusive(r2s_plan* P, const uint32_t* in, uint32_t* out, int64_
     int rc = scan_exclusive(P, sums, sums, nb, st, level + 1);
     if (rc) return rc;
     scan_add_kernel<<<(unsigned)nb, SCAN_BLOCK, 0, st>>>(out, sums, n);
-    return 0;
-}
-
-static int check_device(int device)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
-        (void)hipGetLastError();
-        return fail(R2S_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    }
-    if (device >= n) return fail(R2S_ERR_ARG, "device %d out of range (%d devices)", device, n);
     return 0;
 }
 
@@ -852,10 +792,6 @@ void r2s_plan_destroy(r2s_plan* P)
     delete P;
 }
 
-#define ENSURE(buf, bytes)                                                       \
-    do {                                                                         \
-        if ((buf).ensure(bytes)) return fail(R2S_ERR_NOMEM, "hipMalloc of %zu bytes failed", (size_t)(bytes)); \
-    } while (0)
 
 int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* dIEN, int64_t nel,
                      const double* d_rho_n, double rho_t, const r2s_grid* grid, const r2s_params* params,

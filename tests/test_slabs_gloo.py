@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: world_size 2 and 3 over gloo.  The slab computation is the oracle's full
+volume sliced per rank (the kernels need a GPU; the partition / padding / all-gather / trim
+logic under test is exactly what bench.py runs over RCCL)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_fixture
+
+
+def _worker(rank, world, port, ref_path, dims):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.load_package()
+    from rho2sdf_jl_amd import slabs
+    ref = torch.from_numpy(np.load(ref_path))
+    sg = slabs.SlabGather(dims, rank, world, torch.device("cpu"))
+    plane = dims[0] * dims[1]
+
+    def compute_slab(k0, k1, out):
+        out.copy_(ref[k0 * plane:k1 * plane])
+
+    slabs.run_step(sg, compute_slab)
+    ok = torch.equal(sg.volume().reshape(-1), ref)
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.destroy_process_group()
+    if flag.item() != 1:
+        raise SystemExit(3)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_zslab_allgather(oracle, tmp_path, world):
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    g = oracle.grid_make(X.min(0), X.max(0), 10)          # 17 planes: not divisible by 2 or 3
+    d, _, _ = oracle.eval_distances(X, IEN, rn, 0.5, g, 1.1, want_xp=False)
+    sdf = d * oracle.sign_detection(X, IEN, rn, 0.5, g)
+    ref_path = str(tmp_path / "ref.npy")
+    np.save(ref_path, sdf)
+    port = 29500 + (os.getpid() % 500) + world
+    mp.spawn(_worker, args=(world, port, ref_path, g.dims), nprocs=world, join=True)
+
+
+def test_slab_bounds():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.load_package()
+    from rho2sdf_jl_amd import slabs
+    per, b = slabs.slab_bounds(512, 8)
+    assert per == 64 and b[0] == (0, 64) and b[7] == (448, 512)
+    per, b = slabs.slab_bounds(257, 4)                    # chapadlo config: 257 planes -> 260
+    assert per == 65 and b[3] == (195, 257)
+    per, b = slabs.slab_bounds(5, 8)
+    assert per == 1 and b[4] == (4, 5) and b[5] == (5, 5) and b[7] == (5, 5)

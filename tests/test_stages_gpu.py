@@ -1,0 +1,138 @@
+"""GPU parity of the pre-stage and post-processing kernels against the oracle (through the C ABI)."""
+import numpy as np
+import pytest
+
+from conftest import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["sphere", "beam_vfrac_03", "chapadlo"])
+def test_mesh_volume_and_nodal_densities(pkg, oracle, name):
+    X, IEN, rho = load_fixture(name)
+    mesh = pkg.Mesh(X, IEN)
+    vd, vf = pkg.calculate_mesh_volume(mesh, rho)
+    ovd, ovf = oracle.mesh_volume(X, IEN, rho)
+    assert vd == pytest.approx(ovd, rel=1e-12) and vf == pytest.approx(ovf, rel=1e-12)   # summation order only
+    rn = pkg.DenseInNodes(mesh, rho)
+    orn = oracle.dense_in_nodes(X, IEN, rho)
+    assert np.abs(rn - orn).max() <= 1e-12, np.abs(rn - orn).max()
+    print(name, "V", vd, vf, "rho_n max|diff|", np.abs(rn - orn).max(), "bit-equal", int((rn == orn).sum()), "/", rn.size)
+    if name == "sphere":   # reference known answers, HexSphereSdfTest.jl:26-27
+        assert rn.max() == pytest.approx(1.0000000000000022, rel=1e-10, abs=1e-12)
+        assert rn.mean() == pytest.approx(0.29490556408887564, rel=1e-10, abs=1e-12)
+
+
+@pytest.mark.parametrize("name", ["beam_vfrac_03", "beam_vfrac_04"])
+def test_find_threshold(pkg, oracle, name):
+    X, IEN, rho = load_fixture(name)
+    mesh = pkg.Mesh(X, IEN)
+    vd, vf = oracle.mesh_volume(X, IEN, rho)
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    rt = pkg.find_threshold_for_volume(mesh, rn, vd * vf)
+    ort, _ = oracle.find_threshold(X, IEN, rn, vd * vf)
+    assert rt == ort
+    if name == "beam_vfrac_04":
+        assert float(f"{rt:.6g}") == 0.518555          # reference literal, runtests.jl:198
+    with pytest.raises(pkg._lib.R2SError, match="outside the possible range"):
+        pkg.find_threshold_for_volume(mesh, rn, vd * 2.0)
+
+
+def _analytic(kind, n):
+    ax = np.linspace(-1.0, 1.0, n + 1).astype(np.float32)
+    Z, Y, X = np.meshgrid(ax, ax, ax, indexing="ij")
+    if kind == "sphere":
+        s = np.float32(0.5) - np.sqrt(X * X + Y * Y + Z * Z)
+    else:
+        s = np.float32(0.5) - np.maximum(np.maximum(np.abs(X), np.abs(Y)), np.abs(Z))
+    return s.astype(np.float32), np.float32(ax[1] - ax[0])
+
+
+@pytest.mark.parametrize("kind,exact", [("sphere", 4.0 / 3.0 * np.pi * 0.125), ("cube", 1.0)])
+def test_volume_from_sdf(pkg, oracle, kind, exact):
+    """reference convergence tests (ConvergenceTests/*.jl) on the HIP kernel + oracle parity"""
+    bounds = {"sphere": (0.10, 0.05, 0.02), "cube": (0.05, 0.02, 0.01)}[kind]
+    for n, b in zip((16, 32, 64), bounds):
+        sdf, edge = _analytic(kind, n)
+        v = pkg.calculate_volume_from_sdf(sdf, edge, detailed_quad_order=20)
+        assert abs(v - exact) / exact < b
+        ov = oracle.volume_from_sdf(sdf, edge, order=20)
+        assert v == pytest.approx(ov, rel=2e-5)        # Float32 summation order
+    sdf, edge = _analytic(kind, 32)
+    assert pkg.calculate_volume_from_sdf(sdf, edge) == pytest.approx(oracle.volume_from_sdf(sdf, edge, order=9), rel=2e-5)
+
+
+def _raw_sdf(oracle, name, rt):
+    X, IEN, rho = load_fixture(name)
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    g, _ = oracle.auto_grid(X, IEN)
+    d, _, _ = oracle.eval_distances(X, IEN, rn, rt, g, 1.1, want_xp=False)
+    return X, IEN, rho, g, d * oracle.sign_detection(X, IEN, rn, rt, g)
+
+
+def test_remove_artifacts(pkg, oracle):
+    X, IEN, rho, og, sdf = _raw_sdf(oracle, "chapadlo", 0.5)
+    pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
+    rng = np.random.default_rng(5)
+    noisy = sdf.copy()
+    idx = rng.choice(sdf.size, 400, replace=False)       # sprinkle interior specks
+    noisy[idx] = np.abs(noisy[idx])
+    for ratio in (0.01, 0.2):
+        a, b = noisy.copy(), noisy.copy()
+        na = pkg.remove_sdf_artifacts(a, pg, min_component_ratio=ratio)
+        nb = oracle.remove_artifacts(b, og, 0.0, ratio)
+        assert na == nb and np.array_equal(a, b)
+        print("artifacts ratio", ratio, "flipped", na)
+    c = -np.abs(sdf)
+    assert pkg.remove_sdf_artifacts(c, pg) == 0
+    with pytest.raises(pkg._lib.R2SError, match="doesn't match grid points"):
+        pkg.remove_sdf_artifacts(np.zeros(7), pg)
+
+
+@pytest.mark.parametrize("interp,smooth", [(False, 1), (True, 1), (True, 2)])
+def test_rbf_smoothing(pkg, oracle, interp, smooth):
+    """BASELINE configs 2/3: beam, approximation and interpolation, :same and :fine grids"""
+    X, IEN, rho, og, sdf = _raw_sdf(oracle, "beam_vfrac_04", 0.518555)
+    oracle.remove_artifacts(sdf, og)
+    vd, vf = oracle.mesh_volume(X, IEN, rho)
+    pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
+    info = {}
+    fine = pkg.RBFs_smoothing(sdf, pg, interp, smooth, vd * vf, info=info)
+    ofine, oth, oits, olsf = oracle.rbf_smoothing(sdf, og, interp, smooth, vd * vf)
+    assert fine.shape == ofine.shape
+    scale = np.abs(olsf).max()
+    # Float32 pipeline: exp() differs by <= 1 ulp(f64) between libm and the device, CG dot products are
+    # reduced in a different order -> compare at Float32 round-off of the field magnitude
+    tol = 5e-5 if interp else 2e-6
+    assert np.abs(info["lsf"] - olsf).max() <= tol * scale, np.abs(info["lsf"] - olsf).max() / scale
+    assert abs(info["cg_iterations"] - oits) <= 1
+    # the level shift is only defined to the 1e-4 volume tolerance of the bisection
+    assert abs(info["th"] - oth) <= 1e-3 * scale
+    assert np.abs((fine - np.float32(info["th"])) - (ofine - np.float32(oth))).max() <= tol * scale
+    print("rbf", interp, smooth, "th", info["th"], oth, "cg", info["cg_iterations"], oits,
+          "max|dLSF|/scale", np.abs(info["lsf"] - olsf).max() / scale)
+
+
+def test_rho2sdf_end_to_end(pkg, oracle):
+    """the reference's default smoke test (runtests.jl:186-207): beam, threshold 0.518555, automatic grid,
+    rbf_interp = true, rbf_grid = :same - all stages on the GPU, compared stage by stage with the oracle"""
+    X, IEN, rho = load_fixture("beam_vfrac_04")
+    opts = pkg.Rho2sdfOptions(threshold_density=0.518555, sdf_grid_setup="automatic", rbf_interp=True, rbf_grid="same")
+    fine_sdf, fine_grid, sdf_grid, sdf_dists = pkg.rho2sdf("beam", X, IEN, rho, options=opts)
+    og, _ = oracle.auto_grid(X, IEN)
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    d, _, _ = oracle.eval_distances(X, IEN, rn, 0.518555, og, 1.1, want_xp=False)
+    ref = d * oracle.sign_detection(X, IEN, rn, 0.518555, og)
+    oracle.remove_artifacts(ref, og)
+    assert np.array_equal(np.abs(ref) == 1e10, np.abs(sdf_dists) == 1e10)
+    assert np.array_equal(np.sign(ref), np.sign(sdf_dists))
+    real = np.abs(ref) < 1e9
+    assert np.allclose(sdf_dists[real], ref[real], rtol=1e-6, atol=1e-12)
+    vd, vf = oracle.mesh_volume(X, IEN, rho)
+    ofine, oth, _, olsf = oracle.rbf_smoothing(ref, og, True, 1, vd * vf)
+    assert fine_sdf.shape == ofine.shape == (11, 27, 67)
+    assert np.abs(fine_sdf - ofine).max() <= 2e-3 * np.abs(olsf).max()
+    # automatic threshold path (options.threshold_density = nothing)
+    opts2 = pkg.Rho2sdfOptions(sdf_grid_setup="automatic", rbf_interp=False)
+    out = pkg.rho2sdf("beam", X, IEN, rho, options=opts2)
+    assert out[0].shape == (11, 27, 67)
