@@ -641,6 +641,7 @@ typedef struct {
     double *dist; /* running |dist_local| (sdfOnDensityField.jl:183: -1e10 -> abs) */
     double *xp;   /* [ngp][3] */
     double delta;
+    int elem_type;
     /* statistics */
     int64_t n_iso_solves, n_iso_fail, n_tri_tests, n_invmap;
 } dist_ctx;
@@ -694,6 +695,15 @@ static int projected_on_full_segment_hex8(dist_ctx *c, const double Xe[8][3], co
         }
     }
     return 0;
+}
+
+static int projected_on_full_segment_tet4(dist_ctx *c, const double Xe[8][3], const double re[8],
+                                          double rt, const double xp[3], const double x[3], int64_t v);
+static inline int projected_on_full_segment(dist_ctx *c, const double Xe[8][3], const double re[8],
+                                            double rt, const double xp[3], const double x[3], int64_t v)
+{
+    return c->elem_type == 0 ? projected_on_full_segment_hex8(c, Xe, re, rt, xp, x, v)
+                             : projected_on_full_segment_tet4(c, Xe, re, rt, xp, x, v);
 }
 
 /* barycentricCoordinates (src/SignedDistances/TriangularMeshUtils.jl:1-24) */
@@ -756,7 +766,7 @@ static void process_triangle(dist_ctx *c, const double Xt[3][3], int is_solid,
                     for (int i = 0; i < 3; ++i) dv[i] = x[i] - xp[i];
                     double d = norm3(dv);
                     if (is_solid) ok = write_value(c, v, d, xp);
-                    else ok = projected_on_full_segment_hex8(c, Xe, re, rt, xp, x, v);
+                    else ok = projected_on_full_segment(c, Xe, re, rt, xp, x, v);
                 } else {
                     for (int j = 0; j < 3; ++j) {
                         double L = norm3(Et[j]);
@@ -768,7 +778,7 @@ static void process_triangle(dist_ctx *c, const double Xt[3][3], int is_solid,
                             for (int i = 0; i < 3; ++i) dv[i] = x[i] - xp[i];
                             double d = norm3(dv);
                             if (is_solid) ok = write_value(c, v, d, xp);
-                            else ok = projected_on_full_segment_hex8(c, Xe, re, rt, xp, x, v);
+                            else ok = projected_on_full_segment(c, Xe, re, rt, xp, x, v);
                             if (ok) break;
                         }
                     }
@@ -784,7 +794,7 @@ static void process_triangle(dist_ctx *c, const double Xt[3][3], int is_solid,
                         if (dd[j] < dd[idx] || (dd[j] != dd[j] && dd[idx] == dd[idx])) idx = j;
                     for (int i = 0; i < 3; ++i) xp[i] = Xt[idx][i];
                     if (is_solid) write_value(c, v, dd[idx], xp);
-                    else projected_on_full_segment_hex8(c, Xe, re, rt, xp, x, v);
+                    else projected_on_full_segment(c, Xe, re, rt, xp, x, v);
                 }
             }
         }
@@ -826,11 +836,18 @@ void orc_set_k_sampling(int64_t stride, int64_t phase)
     g_kphase = phase;
 }
 
+int orc_eval_distances_tet4(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_n,
+                            double rho_t, const orc_grid *g, double band_factor, double *dist_out,
+                            double *xp_out, orc_stats *stats);
+int orc_sign_detection_tet4(const double *X, const int64_t *IEN, int64_t nel, const double *rho_n, double rho_t,
+                            const orc_grid *g, double *signs);
+
 int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int elem_type,
                        const double *rho_n, double rho_t, const orc_grid *g, double band_factor,
                        double *dist_out, double *xp_out, orc_stats *stats)
 {
-    if (elem_type != 0) return -2; /* TET4: see orc_eval_distances_tet4 */
+    if (elem_type != 0)
+        return orc_eval_distances_tet4(X, nnp, IEN, nel, rho_n, rho_t, g, band_factor, dist_out, xp_out, stats);
     orc_mesh m;
     if (mesh_init(&m, X, nnp, IEN, nel, elem_type)) return -1;
     int64_t ngp = g->ngp;
@@ -999,7 +1016,7 @@ int orc_sign_detection(const double *X, int64_t nnp, const int64_t *IEN, int64_t
                        const double *rho_n, double rho_t, const orc_grid *g, double *signs)
 {
     (void)nnp;
-    if (elem_type != 0) return -2;
+    if (elem_type != 0) return orc_sign_detection_tet4(X, IEN, nel, rho_n, rho_t, g, signs);
     int64_t ngp = g->ngp, nx = g->N[0] + 1, ny = g->N[1] + 1;
     double *cmax = (double *)malloc(sizeof(double) * (size_t)ngp);
     double *mloc = (double *)malloc(sizeof(double) * (size_t)ngp);
@@ -1683,5 +1700,314 @@ int orc_rbf_smoothing(const double *sdf, const orc_grid *g, int is_interp, int s
     rbf_apply(&c, w, smooth, fx, fy, fz, tx, ty, tz, fine_out); /* :363 */
     for (int64_t i = 0; i < fx * fy * fz; ++i) fine_out[i] = fine_out[i] + th; /* :366 */
     free(dm); free(w); free(lsf); free(tx); free(ty); free(tz); free(c.cx); free(c.cy); free(c.cz);
+    return 0;
+}
+
+/* ================================================================== */
+/* TET4                                                                */
+/* ================================================================== */
+/* shape_functions(TET4, lambda) (ShapeFunctions.jl:18-28): N = [l1,l2,l3, 1 - sum(l)] */
+static inline void tet4_shape(const double l[3], double N[4])
+{
+    N[0] = l[0]; N[1] = l[1]; N[2] = l[2];
+    N[3] = 1.0 - ((l[0] + l[1]) + l[2]);
+}
+
+/* find_local_coordinates, TET4 (FindLocalCoordinates.jl:110-149): 3x3 solve for (l2,l3,l4),
+ * l1 = 1 - sum; valid <=> all four >= 0 and their left-to-right sum <= 1.0 (ElementTypes.jl:104-106);
+ * returns [l1,l2,l3] or (10,10,10) */
+static int find_local_tet4(const double Xe[8][3], const double x[3], double loc[3])
+{
+    double A[9], b[3];
+    for (int i = 0; i < 3; ++i) {
+        A[3 * i + 0] = Xe[1][i] - Xe[0][i];
+        A[3 * i + 1] = Xe[2][i] - Xe[0][i];
+        A[3 * i + 2] = Xe[3][i] - Xe[0][i];
+        b[i] = x[i] - Xe[0][i];
+    }
+    if (lu_solve(3, A, b)) { loc[0] = loc[1] = loc[2] = 10.0; return 0; }
+    double l1 = 1.0 - ((b[0] + b[1]) + b[2]);
+    double l[4] = {l1, b[0], b[1], b[2]};
+    int ok = l[0] >= 0.0 && l[1] >= 0.0 && l[2] >= 0.0 && l[3] >= 0.0 && (((l[0] + l[1]) + l[2]) + l[3]) <= 1.0;
+    if (!ok) { loc[0] = loc[1] = loc[2] = 10.0; return 0; }
+    loc[0] = l1; loc[1] = b[0]; loc[2] = b[1];
+    return 1;
+}
+
+/* IsProjectedOnFullSegment, TET4 branch (sdfOnDensityField.jl:92-113) */
+static int projected_on_full_segment_tet4(dist_ctx *c, const double Xe[8][3], const double re[8],
+                                          double rt, const double xp[3], const double x[3], int64_t v)
+{
+    double loc[3], N[4];
+    find_local_tet4(Xe, xp, loc);
+    c->n_invmap++;
+    double sum = (loc[0] + loc[1]) + loc[2];
+    int valid = loc[0] >= 0.0 && loc[1] >= 0.0 && loc[2] >= 0.0 && sum <= 1.0 && sum <= 1.001; /* :98 */
+    if (valid) {
+        tet4_shape(loc, N);
+        double rho = 0.0;
+        for (int k = 0; k < 4; ++k) rho += N[k] * re[k];
+        if (rho >= rt) {
+            double dv[3] = {x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]};
+            write_value(c, v, norm3(dv), xp);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* compute_coords_on_iso, TET4 (ComputeCoordsOnIso.jl:90-181): closest point of the planar polygon
+ * {p in tet : rho(p) = rho_t} (affine map, linear density => convex QP with a unique minimiser; the
+ * reference solves it with SLSQP from the centroid).  Solved in closed form: project x onto the
+ * iso-plane; if the foot lies in the tetrahedron that is the answer, otherwise the nearest point of
+ * the polygon's edges (one segment per tetrahedron face crossed by the plane).  Returns natural
+ * coordinates (l1,l2,l3). */
+static void iso_project_tet4(const double x[3], const double Xe[8][3], const double re[8], double rt,
+                             double lam[3])
+{
+    double A[3][3], Ai[3][3];
+    for (int i = 0; i < 3; ++i) { A[i][0] = Xe[1][i] - Xe[0][i]; A[i][1] = Xe[2][i] - Xe[0][i]; A[i][2] = Xe[3][i] - Xe[0][i]; }
+    double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    Ai[0][0] = c00 / det; Ai[1][0] = c01 / det; Ai[2][0] = c02 / det;
+    Ai[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+    Ai[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
+    Ai[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+    Ai[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
+    Ai[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+    Ai[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+    double dr[3] = {re[1] - re[0], re[2] - re[0], re[3] - re[0]}, gr[3];
+    for (int i = 0; i < 3; ++i) gr[i] = Ai[0][i] * dr[0] + Ai[1][i] * dr[1] + Ai[2][i] * dr[2]; /* physical gradient */
+    double g2 = gr[0] * gr[0] + gr[1] * gr[1] + gr[2] * gr[2];
+    double d0[3] = {x[0] - Xe[0][0], x[1] - Xe[0][1], x[2] - Xe[0][2]};
+    double rho_x = re[0] + (gr[0] * d0[0] + gr[1] * d0[1] + gr[2] * d0[2]);
+    double tq = (rho_x - rt) / g2;
+    double best[3] = {0, 0, 0}, bestd = INFINITY;
+    {
+        double q[3] = {x[0] - tq * gr[0], x[1] - tq * gr[1], x[2] - tq * gr[2]};
+        double dq[3] = {q[0] - Xe[0][0], q[1] - Xe[0][1], q[2] - Xe[0][2]}, l[4];
+        for (int i = 0; i < 3; ++i) l[i + 1] = Ai[i][0] * dq[0] + Ai[i][1] * dq[1] + Ai[i][2] * dq[2];
+        l[0] = 1.0 - ((l[1] + l[2]) + l[3]);
+        if (l[0] >= 0.0 && l[1] >= 0.0 && l[2] >= 0.0 && l[3] >= 0.0) {
+            best[0] = q[0]; best[1] = q[1]; best[2] = q[2];
+            bestd = 0.0; /* the foot of the perpendicular: nothing on the polygon is closer */
+        }
+    }
+    if (bestd != 0.0) {
+        for (int f = 0; f < 4; ++f) {
+            const int *fn = TET_ISN[f];
+            double P[3][3];
+            int np = 0;
+            for (int e = 0; e < 3; ++e) {
+                int a = fn[e], b = fn[(e + 1) % 3];
+                double ra = re[a] - rt, rb = re[b] - rt;
+                if (ra * rb <= 0.0 && re[a] != re[b]) {
+                    double t = (rt - re[a]) / (re[b] - re[a]);
+                    for (int i = 0; i < 3; ++i) P[np][i] = Xe[a][i] + t * (Xe[b][i] - Xe[a][i]);
+                    np++;
+                }
+            }
+            if (np < 2) continue;
+            /* segment between the two crossings that are farthest apart (np == 3 only if it grazes a vertex) */
+            int ia = 0, ib = 1;
+            if (np == 3) {
+                double d01 = 0, d02 = 0, d12 = 0;
+                for (int i = 0; i < 3; ++i) {
+                    d01 += (P[0][i] - P[1][i]) * (P[0][i] - P[1][i]);
+                    d02 += (P[0][i] - P[2][i]) * (P[0][i] - P[2][i]);
+                    d12 += (P[1][i] - P[2][i]) * (P[1][i] - P[2][i]);
+                }
+                if (d02 >= d01 && d02 >= d12) { ia = 0; ib = 2; }
+                else if (d12 >= d01 && d12 >= d02) { ia = 1; ib = 2; }
+            }
+            double ab[3], ax[3], ab2 = 0.0, dot = 0.0;
+            for (int i = 0; i < 3; ++i) { ab[i] = P[ib][i] - P[ia][i]; ax[i] = x[i] - P[ia][i]; ab2 += ab[i] * ab[i]; dot += ax[i] * ab[i]; }
+            double s = ab2 > 0.0 ? dot / ab2 : 0.0;
+            s = fmin(fmax(s, 0.0), 1.0);
+            double p[3], dd = 0.0;
+            for (int i = 0; i < 3; ++i) { p[i] = P[ia][i] + s * ab[i]; dd += (x[i] - p[i]) * (x[i] - p[i]); }
+            if (dd < bestd) { bestd = dd; best[0] = p[0]; best[1] = p[1]; best[2] = p[2]; }
+        }
+    }
+    if (bestd == INFINITY) { lam[0] = lam[1] = lam[2] = 0.25; return; } /* no polygon: the SLSQP start */
+    double db[3] = {best[0] - Xe[0][0], best[1] - Xe[0][1], best[2] - Xe[0][2]}, l234[3];
+    for (int i = 0; i < 3; ++i) l234[i] = Ai[i][0] * db[0] + Ai[i][1] * db[1] + Ai[i][2] * db[2];
+    lam[0] = 1.0 - ((l234[0] + l234[1]) + l234[2]);
+    lam[1] = l234[0];
+    lam[2] = l234[1];
+}
+
+int orc_iso_project_tet4(const double x[3], const double *Xe4 /* 4*3 */, const double re4[4], double rt, double lam[3])
+{
+    double Xe[8][3] = {{0}}, re[8] = {0};
+    for (int a = 0; a < 4; ++a) { for (int i = 0; i < 3; ++i) Xe[a][i] = Xe4[3 * a + i]; re[a] = re4[a]; }
+    iso_project_tet4(x, Xe, re, rt, lam);
+    return 0;
+}
+
+int orc_eval_distances_tet4(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_n,
+                            double rho_t, const orc_grid *g, double band_factor, double *dist_out,
+                            double *xp_out, orc_stats *stats)
+{
+    orc_mesh m;
+    if (mesh_init(&m, X, nnp, IEN, nel, 1)) return -1;
+    int64_t ngp = g->ngp;
+    dist_ctx c;
+    memset(&c, 0, sizeof c);
+    c.g = g;
+    c.elem_type = 1;
+    c.delta = band_factor * g->cell;
+    c.head = (int64_t *)malloc(sizeof(int64_t) * (size_t)ngp);
+    c.next = (int64_t *)malloc(sizeof(int64_t) * (size_t)ngp);
+    c.dist = dist_out;
+    c.xp = xp_out;
+    for (int64_t i = 0; i < ngp; ++i) { c.head[i] = -1; c.next[i] = -1; c.dist[i] = BIG; }
+    if (xp_out) memset(xp_out, 0, sizeof(double) * 3 * (size_t)ngp);
+    {
+        int64_t v = 0;
+        for (int64_t k = 0; k <= g->N[2]; ++k)
+          for (int64_t j = 0; j <= g->N[1]; ++j)
+            for (int64_t i = 0; i <= g->N[0]; ++i, ++v) {
+                double p[3];
+                if (k % g_kstride != g_kphase) continue;
+                grid_point(g, i, j, k, p);
+                double I1 = cell_of(g, 0, p[0]), I2 = cell_of(g, 1, p[1]), I3 = cell_of(g, 2, p[2]);
+                int64_t Ia = (int64_t)(I3 * (double)(g->N[0] + 1) * (double)(g->N[1] + 1) + I2 * (double)(g->N[0] + 1) + I1);
+                c.next[v] = c.head[Ia];
+                c.head[Ia] = v;
+            }
+    }
+    int64_t n_solid = 0, n_iso = 0;
+    for (int64_t el = 0; el < nel; ++el) {
+        double Xe[8][3] = {{0}}, re[8] = {0}, rmin = INFINITY, rmax = -INFINITY;
+        for (int a = 0; a < 4; ++a) {
+            int64_t n = IEN[el * 4 + a] - 1;
+            for (int i = 0; i < 3; ++i) Xe[a][i] = X[3 * n + i];
+            re[a] = rho_n[n];
+            if (re[a] < rmin) rmin = re[a];
+            if (re[a] > rmax) rmax = re[a];
+        }
+        if (rmin >= rho_t) {
+            n_solid++;
+            process_boundary_faces(&c, &m, el, 1, Xe, re, rho_t);
+        } else if (rmax > rho_t) {
+            n_iso++;
+            process_boundary_faces(&c, &m, el, 0, Xe, re, rho_t);
+            int64_t Imin[3], Imax[3];
+            mini_aabb(g, Xe, 4, c.delta, Imin, Imax);
+            for (int64_t I3 = Imin[2]; I3 <= Imax[2]; ++I3)
+              for (int64_t I2 = Imin[1]; I2 <= Imax[1]; ++I2)
+                for (int64_t I1 = Imin[0]; I1 <= Imax[0]; ++I1) {
+                    int64_t ii = I3 * (g->N[0] + 1) * (g->N[1] + 1) + I2 * (g->N[0] + 1) + I1;
+                    for (int64_t v = c.head[ii]; v != -1; v = c.next[v]) {
+                        int64_t vi = v % (g->N[0] + 1), vj = (v / (g->N[0] + 1)) % (g->N[1] + 1);
+                        int64_t vk = v / ((g->N[0] + 1) * (g->N[1] + 1));
+                        double x[3], lam[3], N[4], xp[3], dv[3];
+                        grid_point(g, vi, vj, vk, x);
+                        iso_project_tet4(x, Xe, re, rho_t, lam);
+                        c.n_iso_solves++;
+                        tet4_shape(lam, N);
+                        for (int i = 0; i < 3; ++i) {
+                            double s = 0.0;
+                            for (int k = 0; k < 4; ++k) s += Xe[k][i] * N[k];
+                            xp[i] = s;
+                            dv[i] = x[i] - s;
+                        }
+                        write_value(&c, v, norm3(dv), xp);
+                    }
+                }
+        }
+    }
+    if (stats) {
+        stats->n_solid = n_solid; stats->n_iso = n_iso; stats->n_iso_solves = c.n_iso_solves;
+        stats->n_iso_fail = 0; stats->n_tri_tests = c.n_tri_tests; stats->n_invmap = c.n_invmap;
+    }
+    free(c.head); free(c.next);
+    mesh_free(&m);
+    return 0;
+}
+
+/* is_point_in_tetrahedron (SignDetection.jl:220-242), tolerance 1e-10 */
+static int point_in_tet(const double Xe[8][3], const double mn[3], const double mx[3], const double p[3])
+{
+    const double tol = 1e-10;
+    for (int i = 0; i < 3; ++i)
+        if (p[i] < mn[i] - tol || p[i] > mx[i] + tol) return 0;
+    double T[16], b[4] = {p[0], p[1], p[2], 1.0};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) T[4 * r + c] = Xe[c][r];
+    for (int c = 0; c < 4; ++c) T[12 + c] = 1.0;
+    if (lu_solve(4, T, b)) return 0;
+    for (int i = 0; i < 4; ++i)
+        if (!(b[i] >= -tol) || !(b[i] <= 1.0 + tol)) return 0;
+    return 1;
+}
+
+/* Sign_Detection_TET4 (SignDetection.jl:88-165) with the tetrahedra binned as in
+ * create_grid_tetrahedra_mapping_TET4 (:168-217), single thread = ascending element order per bin */
+int orc_sign_detection_tet4(const double *X, const int64_t *IEN, int64_t nel, const double *rho_n, double rho_t,
+                            const orc_grid *g, double *signs)
+{
+    int64_t ngp = g->ngp, nx = g->N[0] + 1, ny = g->N[1] + 1, nz = g->N[2] + 1;
+    int64_t dims[3] = {nx, ny, nz};
+    unsigned char *done = (unsigned char *)calloc((size_t)ngp, 1);
+    int64_t *gidx = (int64_t *)malloc(sizeof(int64_t) * 3 * (size_t)ngp);
+    {
+        int64_t v = 0;
+        for (int64_t k = 0; k < nz; ++k)
+          for (int64_t j = 0; j < ny; ++j)
+            for (int64_t i = 0; i < nx; ++i, ++v) {
+                double x[3];
+                grid_point(g, i, j, k, x);
+                signs[v] = -1.0;
+                for (int ax = 0; ax < 3; ++ax) { /* point_to_grid_index (:258-268) */
+                    double f = floor((x[ax] - g->amin[ax]) / g->cell) + 1.0;
+                    if (f > (double)dims[ax]) f = (double)dims[ax];
+                    if (f < 1.0) f = 1.0;
+                    gidx[3 * v + ax] = (int64_t)f;
+                }
+            }
+    }
+    for (int64_t el = 0; el < nel; ++el) {
+        double Xe[8][3] = {{0}}, re[8] = {0}, mn[3], mx[3];
+        for (int a = 0; a < 4; ++a) {
+            int64_t n = IEN[el * 4 + a] - 1;
+            for (int i = 0; i < 3; ++i) {
+                Xe[a][i] = X[3 * n + i];
+                if (a == 0 || Xe[a][i] < mn[i]) mn[i] = Xe[a][i];
+                if (a == 0 || Xe[a][i] > mx[i]) mx[i] = Xe[a][i];
+            }
+            re[a] = rho_n[n];
+        }
+        int64_t lo[3], hi[3]; /* 1-based bin ranges (:191-192) */
+        for (int ax = 0; ax < 3; ++ax) {
+            double a = floor((mn[ax] - g->amin[ax]) / g->cell) - 1.0;
+            double b = ceil((mx[ax] - g->amin[ax]) / g->cell) + 1.0;
+            if (a < 1.0) a = 1.0;
+            if (b > (double)dims[ax]) b = (double)dims[ax];
+            lo[ax] = (int64_t)a; hi[ax] = (int64_t)b;
+        }
+        /* voxels whose bin index lies in the range: lattice index = bin-1 or bin (rounding), scan one wider */
+        for (int64_t k = (lo[2] - 2 < 0 ? 0 : lo[2] - 2); k <= hi[2] && k < nz; ++k) {
+            if (k % g_kstride != g_kphase) continue;
+            for (int64_t j = (lo[1] - 2 < 0 ? 0 : lo[1] - 2); j <= hi[1] && j < ny; ++j)
+                for (int64_t i = (lo[0] - 2 < 0 ? 0 : lo[0] - 2); i <= hi[0] && i < nx; ++i) {
+                    int64_t v = (k * ny + j) * nx + i;
+                    if (done[v]) continue;
+                    const int64_t *gi = gidx + 3 * v;
+                    if (gi[0] < lo[0] || gi[0] > hi[0] || gi[1] < lo[1] || gi[1] > hi[1] || gi[2] < lo[2] || gi[2] > hi[2]) continue;
+                    double x[3], loc[3], N[4];
+                    grid_point(g, i, j, k, x);
+                    if (!point_in_tet(Xe, mn, mx, x)) continue;
+                    if (!find_local_tet4(Xe, x, loc)) continue;
+                    tet4_shape(loc, N);
+                    double rho = 0.0;
+                    for (int q = 0; q < 4; ++q) rho += N[q] * re[q];
+                    if (rho >= rho_t) { signs[v] = 1.0; done[v] = 1; }
+                }
+        }
+    }
+    free(done); free(gidx);
     return 0;
 }

@@ -515,14 +515,16 @@ R2S_DEV bool projected_on_full_segment(VoxState& s, const ElemRec& E, double rt,
     return false;
 }
 
-R2S_DEV bool tri_candidate(VoxState& s, bool solid, const ElemRec& E, double rt, const double xp[3],
+template <class Rec>
+R2S_DEV bool tri_candidate(VoxState& s, bool solid, const Rec& E, double rt, const double xp[3],
                            const double x[3], double d)
 {
     return solid ? write_value(s, d, xp) : projected_on_full_segment(s, E, rt, xp, x);
 }
 
 // process_triangle_projection! for one voxel (sdfOnDensityField.jl:675-813)
-R2S_DEV void process_triangle(VoxState& s, const BandItem& T, const ElemRec& E, double rt,
+template <class Rec>
+R2S_DEV void process_triangle(VoxState& s, const BandItem& T, const Rec& E, double rt,
                               const double x[3])
 {
     const bool solid = (T.kind == 1);
@@ -629,6 +631,229 @@ R2S_DEV void sign_visit(const ElemRec& E, double rt, const double x[3], double& 
         if (m < 0.95) done = true;
         else max_local = m;
     }
+}
+
+// =====================================================================================
+// TET4
+// =====================================================================================
+// One pre-gathered TET4 element with the factorisations its per-voxel tests need.
+struct alignas(16) TetRec {
+    double X[4][3];
+    double r[4];
+    double mn[3];
+    double mx[3];
+    double rmax;
+    double rmin;
+    double lu3[3][3];  // partial-pivot LU of [x2-x1, x3-x1, x4-x1]   (FindLocalCoordinates.jl:124-129)
+    double lu4[4][4];  // partial-pivot LU of [v1 v2 v3 v4; 1 1 1 1]  (SignDetection.jl:236-239)
+    int32_t p3[2];     // row swaps of lu3 (column c swapped with row p3[c])
+    int32_t p4[3];     // row swaps of lu4
+    int32_t sing3, sing4;
+    int32_t blo[3], bhi[3];  // 1-based bin range of create_grid_tetrahedra_mapping_TET4 (:191-192)
+    int32_t pad;
+};
+
+__device__ const int c_tet_isn[4][3] = {{0, 2, 1}, {0, 1, 3}, {1, 2, 3}, {0, 3, 2}};
+
+// shape_functions(TET4, l) (ShapeFunctions.jl:18-28)
+R2S_DEV void tet4_shape(const double l[3], double N[4])
+{
+    N[0] = l[0]; N[1] = l[1]; N[2] = l[2];
+    N[3] = 1.0 - ((l[0] + l[1]) + l[2]);
+}
+
+// find_local_coordinates, TET4 (FindLocalCoordinates.jl:110-149)
+R2S_DEV bool find_local_tet4(const TetRec& E, const double x[3], double loc[3])
+{
+    double b0 = x[0] - E.X[0][0], b1 = x[1] - E.X[0][1], b2 = x[2] - E.X[0][2];
+    if (E.p3[0] == 1) { double t = b0; b0 = b1; b1 = t; }
+    else if (E.p3[0] == 2) { double t = b0; b0 = b2; b2 = t; }
+    if (E.p3[1] == 2) { double t = b1; b1 = b2; b2 = t; }
+    b1 -= E.lu3[1][0] * b0;
+    b2 -= E.lu3[2][0] * b0;
+    b2 -= E.lu3[2][1] * b1;
+    const double l4 = b2 / E.lu3[2][2];
+    const double l3 = (b1 - E.lu3[1][2] * l4) / E.lu3[1][1];
+    const double l2 = (b0 - E.lu3[0][1] * l3 - E.lu3[0][2] * l4) / E.lu3[0][0];
+    const double l1 = 1.0 - ((l2 + l3) + l4);
+    // validate_local_coords(TET4, [l1,l2,l3,l4]) (ElementTypes.jl:104-106)
+    const bool ok = !E.sing3 && l1 >= 0.0 && l2 >= 0.0 && l3 >= 0.0 && l4 >= 0.0 && (((l1 + l2) + l3) + l4) <= 1.0;
+    if (!ok) { loc[0] = loc[1] = loc[2] = 10.0; return false; }
+    loc[0] = l1; loc[1] = l2; loc[2] = l3;
+    return true;
+}
+
+// IsProjectedOnFullSegment, TET4 branch (sdfOnDensityField.jl:92-113)
+R2S_DEV bool projected_on_full_segment(VoxState& s, const TetRec& E, double rt, const double xp[3], const double x[3])
+{
+    double loc[3], N[4];
+    find_local_tet4(E, xp, loc);
+    const double sum = (loc[0] + loc[1]) + loc[2];
+    const bool valid = loc[0] >= 0.0 && loc[1] >= 0.0 && loc[2] >= 0.0 && sum <= 1.0 && sum <= 1.001;
+    if (valid) {
+        tet4_shape(loc, N);
+        double rho = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rho += N[k] * E.r[k];
+        if (rho >= rt) {
+            write_value(s, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), xp);
+            return true;
+        }
+    }
+    return false;
+}
+
+// compute_coords_on_iso, TET4 (ComputeCoordsOnIso.jl:90-181): closest point of the planar polygon
+// {p in tet : rho(p) = rho_t}, closed form (see the oracle / DESIGN.md); natural coordinates out.
+R2S_DEV void iso_project_tet4(const TetRec& E, const double x[3], double rt, double lam[3])
+{
+    double A[3][3], Ai[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        A[i][0] = E.X[1][i] - E.X[0][i];
+        A[i][1] = E.X[2][i] - E.X[0][i];
+        A[i][2] = E.X[3][i] - E.X[0][i];
+    }
+    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    const double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    Ai[0][0] = c00 / det; Ai[1][0] = c01 / det; Ai[2][0] = c02 / det;
+    Ai[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+    Ai[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
+    Ai[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+    Ai[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
+    Ai[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+    Ai[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+    const double dr[3] = {E.r[1] - E.r[0], E.r[2] - E.r[0], E.r[3] - E.r[0]};
+    double gr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gr[i] = Ai[0][i] * dr[0] + Ai[1][i] * dr[1] + Ai[2][i] * dr[2];
+    const double g2 = gr[0] * gr[0] + gr[1] * gr[1] + gr[2] * gr[2];
+    const double d0[3] = {x[0] - E.X[0][0], x[1] - E.X[0][1], x[2] - E.X[0][2]};
+    const double rho_x = E.r[0] + (gr[0] * d0[0] + gr[1] * d0[1] + gr[2] * d0[2]);
+    const double tq = (rho_x - rt) / g2;
+    double best[3] = {0, 0, 0}, bestd = INFINITY;
+    {
+        const double q[3] = {x[0] - tq * gr[0], x[1] - tq * gr[1], x[2] - tq * gr[2]};
+        const double dq[3] = {q[0] - E.X[0][0], q[1] - E.X[0][1], q[2] - E.X[0][2]};
+        double l[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) l[i + 1] = Ai[i][0] * dq[0] + Ai[i][1] * dq[1] + Ai[i][2] * dq[2];
+        l[0] = 1.0 - ((l[1] + l[2]) + l[3]);
+        if (l[0] >= 0.0 && l[1] >= 0.0 && l[2] >= 0.0 && l[3] >= 0.0) {
+            best[0] = q[0]; best[1] = q[1]; best[2] = q[2];
+            bestd = 0.0;
+        }
+    }
+    if (bestd != 0.0) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            double P[3][3];
+            int np = 0;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int a = c_tet_isn[f][e], b = c_tet_isn[f][(e + 1) % 3];
+                const double ra = E.r[a] - rt, rb = E.r[b] - rt;
+                if (ra * rb <= 0.0 && E.r[a] != E.r[b]) {
+                    const double t = (rt - E.r[a]) / (E.r[b] - E.r[a]);
+                    const double px = E.X[a][0] + t * (E.X[b][0] - E.X[a][0]);
+                    const double py = E.X[a][1] + t * (E.X[b][1] - E.X[a][1]);
+                    const double pz = E.X[a][2] + t * (E.X[b][2] - E.X[a][2]);
+                    if (np == 0) { P[0][0] = px; P[0][1] = py; P[0][2] = pz; }
+                    else if (np == 1) { P[1][0] = px; P[1][1] = py; P[1][2] = pz; }
+                    else { P[2][0] = px; P[2][1] = py; P[2][2] = pz; }
+                    np++;
+                }
+            }
+            if (np >= 2) {
+                double a3[3] = {P[0][0], P[0][1], P[0][2]}, b3[3] = {P[1][0], P[1][1], P[1][2]};
+                if (np == 3) {
+                    double d01 = 0, d02 = 0, d12 = 0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        d01 += (P[0][i] - P[1][i]) * (P[0][i] - P[1][i]);
+                        d02 += (P[0][i] - P[2][i]) * (P[0][i] - P[2][i]);
+                        d12 += (P[1][i] - P[2][i]) * (P[1][i] - P[2][i]);
+                    }
+                    if (d02 >= d01 && d02 >= d12) { b3[0] = P[2][0]; b3[1] = P[2][1]; b3[2] = P[2][2]; }
+                    else if (d12 >= d01 && d12 >= d02) {
+                        a3[0] = P[1][0]; a3[1] = P[1][1]; a3[2] = P[1][2];
+                        b3[0] = P[2][0]; b3[1] = P[2][1]; b3[2] = P[2][2];
+                    }
+                }
+                double ab[3], ab2 = 0.0, dot = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    ab[i] = b3[i] - a3[i];
+                    const double ax = x[i] - a3[i];
+                    ab2 += ab[i] * ab[i];
+                    dot += ax * ab[i];
+                }
+                double s = ab2 > 0.0 ? dot / ab2 : 0.0;
+                s = fmin(fmax(s, 0.0), 1.0);
+                double p[3], dd = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    p[i] = a3[i] + s * ab[i];
+                    dd += (x[i] - p[i]) * (x[i] - p[i]);
+                }
+                if (dd < bestd) { bestd = dd; best[0] = p[0]; best[1] = p[1]; best[2] = p[2]; }
+            }
+        }
+    }
+    if (bestd == INFINITY) { lam[0] = lam[1] = lam[2] = 0.25; return; }
+    const double db[3] = {best[0] - E.X[0][0], best[1] - E.X[0][1], best[2] - E.X[0][2]};
+    double l234[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) l234[i] = Ai[i][0] * db[0] + Ai[i][1] * db[1] + Ai[i][2] * db[2];
+    lam[0] = 1.0 - ((l234[0] + l234[1]) + l234[2]);
+    lam[1] = l234[0];
+    lam[2] = l234[1];
+}
+
+R2S_DEV double iso_candidate(const TetRec& E, double rt, const double x[3], double xp[3])
+{
+    double lam[3], N[4];
+    iso_project_tet4(E, x, rt, lam);
+    tet4_shape(lam, N);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += E.X[k][i] * N[k];
+        xp[i] = t;
+    }
+    return norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]);
+}
+
+// is_point_in_tetrahedron (SignDetection.jl:220-242), tolerance 1e-10
+R2S_DEV bool point_in_tet(const TetRec& E, const double p[3])
+{
+    const double tol = 1e-10;
+    if (p[0] < E.mn[0] - tol || p[0] > E.mx[0] + tol || p[1] < E.mn[1] - tol || p[1] > E.mx[1] + tol ||
+        p[2] < E.mn[2] - tol || p[2] > E.mx[2] + tol)
+        return false;
+    if (E.sing4) return false;
+    double b0 = p[0], b1 = p[1], b2 = p[2], b3 = 1.0;
+    // row swaps of the factorisation, in order
+    if (E.p4[0] == 1) { double t = b0; b0 = b1; b1 = t; }
+    else if (E.p4[0] == 2) { double t = b0; b0 = b2; b2 = t; }
+    else if (E.p4[0] == 3) { double t = b0; b0 = b3; b3 = t; }
+    if (E.p4[1] == 2) { double t = b1; b1 = b2; b2 = t; }
+    else if (E.p4[1] == 3) { double t = b1; b1 = b3; b3 = t; }
+    if (E.p4[2] == 3) { double t = b2; b2 = b3; b3 = t; }
+    b1 -= E.lu4[1][0] * b0;
+    b2 -= E.lu4[2][0] * b0;
+    b3 -= E.lu4[3][0] * b0;
+    b2 -= E.lu4[2][1] * b1;
+    b3 -= E.lu4[3][1] * b1;
+    b3 -= E.lu4[3][2] * b2;
+    const double l3 = b3 / E.lu4[3][3];
+    const double l2 = (b2 - E.lu4[2][3] * l3) / E.lu4[2][2];
+    const double l1 = (b1 - E.lu4[1][2] * l2 - E.lu4[1][3] * l3) / E.lu4[1][1];
+    const double l0 = (b0 - E.lu4[0][1] * l1 - E.lu4[0][2] * l2 - E.lu4[0][3] * l3) / E.lu4[0][0];
+    return l0 >= -tol && l0 <= 1.0 + tol && l1 >= -tol && l1 <= 1.0 + tol && l2 >= -tol && l2 <= 1.0 + tol &&
+           l3 >= -tol && l3 <= 1.0 + tol;
 }
 
 }  // namespace r2s

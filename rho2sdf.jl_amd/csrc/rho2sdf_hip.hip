@@ -24,6 +24,8 @@
 #include "r2s_common.hpp"
 #include "r2s_device_math.hpp"
 
+#include <type_traits>
+
 using namespace r2s;
 
 // ------------------------------------------------------------------------------------
@@ -127,22 +129,88 @@ struct SlabInfo {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// n x n LU with partial pivoting, same operation order as the oracle's lu_solve (stands in for
+// LAPACK getrf behind Julia's `\`); piv[c] = row swapped with row c.  Prep kernels only.
+template <int N>
+__device__ void lu_factor(double A[N][N], int32_t* piv, int32_t& sing)
+{
+    sing = 0;
+    for (int c = 0; c < N; ++c) {
+        int p = c;
+        double best = fabs(A[c][c]);
+        for (int r = c + 1; r < N; ++r)
+            if (fabs(A[r][c]) > best) { best = fabs(A[r][c]); p = r; }
+        if (best == 0.0) sing = 1;
+        if (c < N - 1) piv[c] = p;
+        if (p != c)
+            for (int k = 0; k < N; ++k) { const double t = A[c][k]; A[c][k] = A[p][k]; A[p][k] = t; }
+        for (int r = c + 1; r < N; ++r) {
+            const double l = A[r][c] / A[c][c];
+            A[r][c] = l;
+            for (int k = c + 1; k < N; ++k) A[r][k] -= l * A[c][k];
+        }
+    }
+}
+
+// element-type traits: record type, topology (src/ElementTypes/ElementTypes.jl:15-78) and the
+// per-element precomputation the per-voxel tests need
+struct HexT {
+    using Rec = ElemRec;
+    static constexpr int NEN = 8, NES = 6, NSN = 4;
+    static __device__ __forceinline__ int face(int sg, int a) { return c_hex_isn[sg][a]; }
+    static __device__ __forceinline__ void finish(Rec&, const GridDev&) {}
+};
+struct TetT {
+    using Rec = TetRec;
+    static constexpr int NEN = 4, NES = 4, NSN = 3;
+    static __device__ __forceinline__ int face(int sg, int a) { return c_tet_isn[sg][a]; }
+    static __device__ void finish(Rec& R, const GridDev& g)
+    {
+        double A[3][3], T[4][4];
+        for (int i = 0; i < 3; ++i) {   // FindLocalCoordinates.jl:124: hcat(x2-x1, x3-x1, x4-x1)
+            A[i][0] = R.X[1][i] - R.X[0][i];
+            A[i][1] = R.X[2][i] - R.X[0][i];
+            A[i][2] = R.X[3][i] - R.X[0][i];
+        }
+        lu_factor<3>(A, R.p3, R.sing3);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R.lu3[r][c] = A[r][c];
+        for (int r = 0; r < 3; ++r)     // SignDetection.jl:236: [v1 v2 v3 v4; 1 1 1 1]
+            for (int c = 0; c < 4; ++c) T[r][c] = R.X[c][r];
+        for (int c = 0; c < 4; ++c) T[3][c] = 1.0;
+        lu_factor<4>(T, R.p4, R.sing4);
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) R.lu4[r][c] = T[r][c];
+        const int dims[3] = {g.nx, g.ny, g.nz};
+        for (int ax = 0; ax < 3; ++ax) {   // SignDetection.jl:191-192 (1-based bin indices)
+            double a = floor((R.mn[ax] - g.amin[ax]) / g.cell) - 1.0;
+            double b = ceil((R.mx[ax] - g.amin[ax]) / g.cell) + 1.0;
+            if (a < 1.0) a = 1.0;
+            if (b > (double)dims[ax]) b = (double)dims[ax];
+            R.blo[ax] = (int32_t)fmin(a, 2.0e9);
+            R.bhi[ax] = (int32_t)fmax(b, -2.0e9);
+        }
+        R.pad = 0;
+    }
+};
+
 // 1 thread / element: gather record, classify (sdfOnDensityField.jl:197-201,312), boundary
 // faces (:511-519), work-item count, lattice range of the element AABB for the sign bins.
+template <class ET>
 __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __restrict__ IEN,
                                  const double* __restrict__ rho_n, int64_t nel, double rho_t,
                                  const uint32_t* __restrict__ ine_ptr, const uint32_t* __restrict__ ine,
-                                 ElemRec* __restrict__ erec, uint8_t* __restrict__ cls,
+                                 GridDev g, typename ET::Rec* __restrict__ erec, uint8_t* __restrict__ cls,
                                  uint8_t* __restrict__ fmask, uint32_t* __restrict__ nitems)
 {
     int64_t el = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nel) return;
-    int64_t nd[8];
-    ElemRec R;
+    int64_t nd[ET::NEN];
+    typename ET::Rec R;
     double rmin = INFINITY, rmax = -INFINITY;
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        nd[a] = IEN[el * 8 + a] - 1;
+    for (int a = 0; a < ET::NEN; ++a) {
+        nd[a] = IEN[el * ET::NEN + a] - 1;
 #pragma unroll
         for (int i = 0; i < 3; ++i) R.X[a][i] = X[3 * nd[a] + i];
         R.r[a] = rho_n[nd[a]];
@@ -153,7 +221,7 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
     for (int i = 0; i < 3; ++i) {
         double mn = R.X[0][i], mx = R.X[0][i];
 #pragma unroll
-        for (int a = 1; a < 8; ++a) {
+        for (int a = 1; a < ET::NEN; ++a) {
             if (R.X[a][i] < mn) mn = R.X[a][i];
             if (R.X[a][i] > mx) mx = R.X[a][i];
         }
@@ -162,20 +230,21 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
     }
     R.rmax = rmax;
     R.rmin = rmin;
+    ET::finish(R, g);
     erec[el] = R;
     int c = CLS_SKIP;
     if (rmin >= rho_t) c = CLS_SOLID;
     else if (rmax > rho_t) c = CLS_ISO;
     uint32_t fm = 0, cnt = 0;
     if (c != CLS_SKIP) {
-        for (int sg = 0; sg < 6; ++sg) {
-            const int64_t n0 = nd[c_hex_isn[sg][0]];
+        for (int sg = 0; sg < ET::NES; ++sg) {
+            const int64_t n0 = nd[ET::face(sg, 0)];
             int common = 0;
             for (uint32_t p = ine_ptr[n0]; p < ine_ptr[n0 + 1]; ++p) {
                 const uint32_t e = ine[p];
                 bool all = true;
-                for (int a = 1; a < 4 && all; ++a) {
-                    const int64_t na = nd[c_hex_isn[sg][a]];
+                for (int a = 1; a < ET::NSN && all; ++a) {
+                    const int64_t na = nd[ET::face(sg, a)];
                     bool found = false;
                     for (uint32_t q = ine_ptr[na]; q < ine_ptr[na + 1]; ++q)
                         if (ine[q] == e) { found = true; break; }
@@ -183,7 +252,7 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
                 }
                 common += all ? 1 : 0;
             }
-            if (common == 1) { fm |= (1u << sg); cnt += 4; }
+            if (common == 1) { fm |= (1u << sg); cnt += ET::NSN; }
         }
         if (c == CLS_ISO) cnt += 1;
     }
@@ -209,7 +278,8 @@ __device__ __forceinline__ void mini_range(const GridDev& g, int ax, double mn, 
 
 // 1 thread / element with items: writes its triangles (face order sg, fan order a) and then the
 // iso item - the reference's processing order inside one element (:584-624).
-__global__ void item_build_kernel(const ElemRec* __restrict__ erec, const uint8_t* __restrict__ cls,
+template <class ET>
+__global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, const uint8_t* __restrict__ cls,
                                   const uint8_t* __restrict__ fmask, const uint32_t* __restrict__ item_off,
                                   int64_t nel, GridDev g, SlabInfo sl, double delta,
                                   BandItem* __restrict__ items, uint32_t* __restrict__ nchunks)
@@ -218,18 +288,22 @@ __global__ void item_build_kernel(const ElemRec* __restrict__ erec, const uint8_
     if (el >= nel) return;
     const int c = cls[el];
     if (c == CLS_SKIP) return;
-    const ElemRec& E = erec[el];
+    const typename ET::Rec& E = erec[el];
     uint32_t w = item_off[el];
     const uint32_t fm = fmask[el];
-    for (int sg = 0; sg < 6; ++sg) {
+    for (int sg = 0; sg < ET::NES; ++sg) {
         if (!(fm & (1u << sg))) continue;
         double Xs[4][3], Xc[3];
-        for (int a = 0; a < 4; ++a)
-            for (int i = 0; i < 3; ++i) Xs[a][i] = E.X[c_hex_isn[sg][a]][i];
-        for (int i = 0; i < 3; ++i) Xc[i] = (((Xs[0][i] + Xs[1][i]) + Xs[2][i]) + Xs[3][i]) / 4.0;
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < ET::NSN; ++a)
+            for (int i = 0; i < 3; ++i) Xs[a][i] = E.X[ET::face(sg, a)][i];
+        for (int i = 0; i < 3; ++i) {   // Xc = vec(mean(Xs, dims = 2)) (sdfOnDensityField.jl:521)
+            double s = Xs[0][i];
+            for (int a = 1; a < ET::NSN; ++a) s += Xs[a][i];
+            Xc[i] = s / (double)ET::NSN;
+        }
+        for (int a = 0; a < ET::NSN; ++a) {
             BandItem T;
-            const int b = (a + 1) & 3;
+            const int b = (a + 1) % ET::NSN;
             for (int i = 0; i < 3; ++i) { T.tri[0][i] = Xs[a][i]; T.tri[1][i] = Xs[b][i]; T.tri[2][i] = Xc[i]; }
             double Et[3][3];
             for (int i = 0; i < 3; ++i) {
@@ -350,9 +424,10 @@ __global__ void item_chunks_kernel(BandItem* __restrict__ items, const uint32_t*
 // lane a different voxel of the same element.  Results go to `res` (distance) and, when
 // requested, `res_xp`; the ordered per-voxel gather (sdf_tiles_kernel) consumes them in the
 // reference's element order, so the strict-'<' update semantics are unchanged.
+template <class Rec>
 __global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __restrict__ items, uint32_t nitems,
                                                          const uint32_t* __restrict__ chunk_off,
-                                                         uint32_t nchunks, const ElemRec* __restrict__ erec,
+                                                         uint32_t nchunks, const Rec* __restrict__ erec,
                                                          GridDev g, double rho_t, double* __restrict__ res,
                                                          double* __restrict__ res_xp)
 {
@@ -366,7 +441,7 @@ __global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __rest
         if (chunk_off[mid] <= c) lo = mid; else hi = mid;
     }
     const BandItem& T = items[lo];
-    const ElemRec& E = erec[T.el];
+    const Rec& E = erec[T.el];
     const uint32_t local = (c - chunk_off[lo]) * 64u + lane;
     const uint32_t bx = T.dim[0], by = T.dim[1], bz = T.dim[2];
     if (local >= bx * by * bz) return;
@@ -438,6 +513,30 @@ __device__ __forceinline__ bool sign_tile_range(const ElemRec& E, const GridDev&
     return true;
 }
 
+// TET4: voxels whose bin index (SignDetection.jl:258-268) lies in [blo,bhi]; the bin index of
+// lattice point i is i or i+1 (1-based), so the lattice range is [blo-1, bhi]
+__device__ __forceinline__ bool sign_tile_range(const TetRec& E, const GridDev& g, const SlabInfo& s,
+                                                int lo[3], int hi[3])
+{
+    const int nmax[3] = {g.nx - 1, g.ny - 1, g.nz - 1};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        if (E.blo[ax] > E.bhi[ax]) return false;
+        int a = E.blo[ax] - 2, b = E.bhi[ax];
+        if (a < 0) a = 0;
+        if (b > nmax[ax]) b = nmax[ax];
+        if (a > b) return false;
+        if (ax == 2) {
+            if (b < s.k0 || a >= s.k1) return false;
+            a = (a < s.k0 ? s.k0 : a) - s.k0;
+            b = (b >= s.k1 ? s.k1 - 1 : b) - s.k0;
+        }
+        lo[ax] = a >> 2;
+        hi[ax] = b >> 2;
+    }
+    return true;
+}
+
 template <bool FILL>
 __global__ void band_bin_kernel(const BandItem* __restrict__ items, uint32_t nitems, GridDev g, SlabInfo s,
                                 uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
@@ -456,8 +555,8 @@ __global__ void band_bin_kernel(const BandItem* __restrict__ items, uint32_t nit
             }
 }
 
-template <bool FILL>
-__global__ void sign_bin_kernel(const ElemRec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s,
+template <class Rec, bool FILL>
+__global__ void sign_bin_kernel(const Rec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s,
                                 double rho_t, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                 uint32_t* __restrict__ entries, uint8_t* __restrict__ hot)
 {
@@ -540,7 +639,7 @@ struct MainArgs {
     const uint32_t* sign_off;
     const uint32_t* sign_ent;
     const BandItem* items;
-    const ElemRec* erec;
+    const void* erec;   // ElemRec[] or TetRec[]
     double* dist;
     double* sign;
     double* sdf;
@@ -550,9 +649,10 @@ struct MainArgs {
     int sdf_mode;  // 1: sdf = dist*sign in one kernel; 2: dist pass stores -dist; 3: sign pass flips
 };
 
-template <bool DO_DIST, bool DO_SIGN>
+template <class Rec, bool DO_DIST, bool DO_SIGN>
 __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
 {
+    const Rec* __restrict__ erec = static_cast<const Rec*>(A.erec);
     // wave-uniform tile id: everything derived from it lives in SGPRs / scalar loads
     const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (w >= A.n_active) return;
@@ -579,7 +679,7 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
             const bool in = valid && ci >= T.imin[0] && ci <= T.imax[0] && cj >= T.imin[1] &&
                             cj <= T.imax[1] && ck >= T.imin[2] && ck <= T.imax[2];
             if (in) {
-                const ElemRec& E = A.erec[T.el];
+                const Rec& E = erec[T.el];
                 if (T.kind == 0) {
                     // WriteValue of the pre-computed iso candidate (sdfOnDensityField.jl:617-621)
                     const size_t slot = (size_t)T.chunk_off * 64u +
@@ -602,26 +702,57 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
     double sg = -1.0;
     if (DO_SIGN) {
         const uint32_t b = A.sign_off[t], e = A.sign_off[t + 1];
-        bool any = false;
-        double cmax = -INFINITY;
-        for (uint32_t p = b; p < e; ++p) {
-            const ElemRec& E = A.erec[A.sign_ent[p]];
-            const bool in = E.mn[0] <= x[0] && E.mn[1] <= x[1] && E.mn[2] <= x[2] && x[0] <= E.mx[0] &&
-                            x[1] <= E.mx[1] && x[2] <= E.mx[2];
-            if (in) {
-                any = true;
-                if (E.rmax > cmax) cmax = E.rmax;
-            }
-        }
-        bool go = valid && any && !(cmax < A.rho_t);  // SignDetection.jl:36
-        double max_local = 10.0;
-        bool done = false;
-        if (__any(go)) {
+        if constexpr (std::is_same<Rec, ElemRec>::value) {
+            // Sign_Detection_HEX8 (SignDetection.jl:27-70)
+            bool any = false;
+            double cmax = -INFINITY;
             for (uint32_t p = b; p < e; ++p) {
-                const ElemRec& E = A.erec[A.sign_ent[p]];
-                const bool in = go && !done && E.mn[0] <= x[0] && E.mn[1] <= x[1] && E.mn[2] <= x[2] &&
-                                x[0] <= E.mx[0] && x[1] <= E.mx[1] && x[2] <= E.mx[2];
-                if (in) sign_visit(E, A.rho_t, x, max_local, sg, done);
+                const ElemRec& E = erec[A.sign_ent[p]];
+                const bool in = E.mn[0] <= x[0] && E.mn[1] <= x[1] && E.mn[2] <= x[2] && x[0] <= E.mx[0] &&
+                                x[1] <= E.mx[1] && x[2] <= E.mx[2];
+                if (in) {
+                    any = true;
+                    if (E.rmax > cmax) cmax = E.rmax;
+                }
+            }
+            bool go = valid && any && !(cmax < A.rho_t);  // SignDetection.jl:36
+            double max_local = 10.0;
+            bool done = false;
+            if (__any(go)) {
+                for (uint32_t p = b; p < e; ++p) {
+                    const ElemRec& E = erec[A.sign_ent[p]];
+                    const bool in = go && !done && E.mn[0] <= x[0] && E.mn[1] <= x[1] && E.mn[2] <= x[2] &&
+                                    x[0] <= E.mx[0] && x[1] <= E.mx[1] && x[2] <= E.mx[2];
+                    if (in) sign_visit(E, A.rho_t, x, max_local, sg, done);
+                }
+            }
+        } else {
+            // Sign_Detection_TET4 (SignDetection.jl:116-151): bin index of the point (:258-268),
+            // candidates of that bin in ascending element order, first hit with rho >= rho_t wins
+            const int dims[3] = {A.g.nx, A.g.ny, A.g.nz};
+            int gi[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double f = floor((x[ax] - A.g.amin[ax]) / A.g.cell) + 1.0;
+                if (f > (double)dims[ax]) f = (double)dims[ax];
+                if (f < 1.0) f = 1.0;
+                gi[ax] = (int)f;
+            }
+            bool done = false;
+            for (uint32_t p = b; p < e; ++p) {
+                const TetRec& E = erec[A.sign_ent[p]];
+                const bool in = valid && !done && gi[0] >= E.blo[0] && gi[0] <= E.bhi[0] && gi[1] >= E.blo[1] &&
+                                gi[1] <= E.bhi[1] && gi[2] >= E.blo[2] && gi[2] <= E.bhi[2];
+                if (in && point_in_tet(E, x)) {
+                    double loc[3], N[4];
+                    if (find_local_tet4(E, x, loc)) {
+                        tet4_shape(loc, N);
+                        double rho = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rho += N[q] * E.r[q];
+                        if (rho >= A.rho_t) { sg = 1.0; done = true; }
+                    }
+                }
             }
         }
     }
@@ -793,7 +924,10 @@ void r2s_plan_destroy(r2s_plan* P)
 }
 
 
-int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* dIEN, int64_t nel,
+}  // extern "C"
+
+template <class ET>
+static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* dIEN, int64_t nel,
                      const double* d_rho_n, double rho_t, const r2s_grid* grid, const r2s_params* params,
                      int64_t k_begin, int64_t k_end, int32_t mode, double* d_dist, double* d_sign,
                      double* d_sdf, double* d_xp, void* stream, r2s_stats* stats)
@@ -801,9 +935,8 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     if (!P || !dX || !dIEN || !d_rho_n || !grid) return fail(R2S_ERR_ARG, "r2s_plan_run_dev: null argument");
     r2s_params prm;
     if (params) prm = *params; else r2s_default_params(&prm);
-    if (prm.elem_type != R2S_HEX8) return fail(R2S_ERR_UNSUPPORTED, "element type %d not supported yet (HEX8 only)", prm.elem_type);
     if (nnp <= 0 || nel <= 0) return fail(R2S_ERR_ARG, "empty mesh");
-    if (nel * 8 >= (int64_t)1 << 31) return fail(R2S_ERR_ARG, "mesh too large");
+    if (nel * ET::NEN >= (int64_t)1 << 31) return fail(R2S_ERR_ARG, "mesh too large");
     for (int i = 0; i < 3; ++i)
         if (grid->N[i] < 1 || grid->N[i] > 100000) return fail(R2S_ERR_ARG, "bad grid dimension");
     if (k_begin < 0 || k_end > grid->N[2] + 1 || k_begin >= k_end) return fail(R2S_ERR_ARG, "bad slab [%lld,%lld)", (long long)k_begin, (long long)k_end);
@@ -839,8 +972,8 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     ENSURE(P->deg, sizeof(uint32_t) * (size_t)(nnp + 1));
     ENSURE(P->ine_ptr, sizeof(uint32_t) * (size_t)(nnp + 1));
     ENSURE(P->cursor, sizeof(uint32_t) * (size_t)(nnp + 1));
-    ENSURE(P->ine, sizeof(uint32_t) * (size_t)(nel * 8));
-    ENSURE(P->erec, sizeof(ElemRec) * (size_t)nel);
+    ENSURE(P->ine, sizeof(uint32_t) * (size_t)(nel * ET::NEN));
+    ENSURE(P->erec, sizeof(typename ET::Rec) * (size_t)nel);
     ENSURE(P->cls, (size_t)nel);
     ENSURE(P->fmask, (size_t)nel);
     ENSURE(P->nitems, sizeof(uint32_t) * (size_t)(nel + 1));
@@ -861,16 +994,16 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     HIP_TRY(hipMemsetAsync(P->cursor.p, 0, sizeof(uint32_t) * (size_t)(nnp + 1), st));
     HIP_TRY(hipMemsetAsync(counters, 0, 64, st));
     {
-        const int64_t n = nel * 8;
-        node_degree_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, 8, nnp, P->deg.as<uint32_t>(), (int*)counters);
+        const int64_t n = nel * ET::NEN;
+        node_degree_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, ET::NEN, nnp, P->deg.as<uint32_t>(), (int*)counters);
         int rc = scan_exclusive(P, P->deg.as<uint32_t>(), P->ine_ptr.as<uint32_t>(), nnp + 1, st);
         if (rc) return rc;
-        ine_fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, 8, nnp, P->ine_ptr.as<uint32_t>(), P->cursor.as<uint32_t>(), P->ine.as<uint32_t>());
+        ine_fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, ET::NEN, nnp, P->ine_ptr.as<uint32_t>(), P->cursor.as<uint32_t>(), P->ine.as<uint32_t>());
     }
     // ---- element records, classes, item counts ----
     HIP_TRY(hipMemsetAsync(P->nitems.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
-    elem_prep_kernel<<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
-        dX, dIEN, d_rho_n, nel, rho_t, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), P->erec.as<ElemRec>(),
+    elem_prep_kernel<ET><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
+        dX, dIEN, d_rho_n, nel, rho_t, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), g, P->erec.as<typename ET::Rec>(),
         P->cls.as<uint8_t>(), P->fmask.as<uint8_t>(), P->nitems.as<uint32_t>());
     {
         int rc = scan_exclusive(P, P->nitems.as<uint32_t>(), P->item_off.as<uint32_t>(), nel + 1, st);
@@ -886,8 +1019,8 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     ENSURE(P->chunk_off, sizeof(uint32_t) * (size_t)(n_items + 1));
     if (n_items) {
         HIP_TRY(hipMemsetAsync(P->nchunks.p, 0, sizeof(uint32_t) * (size_t)(n_items + 1), st));
-        item_build_kernel<<<(unsigned)((nel + 63) / 64), 64, 0, st>>>(
-            P->erec.as<ElemRec>(), P->cls.as<uint8_t>(), P->fmask.as<uint8_t>(), P->item_off.as<uint32_t>(), nel,
+        item_build_kernel<ET><<<(unsigned)((nel + 63) / 64), 64, 0, st>>>(
+            P->erec.as<typename ET::Rec>(), P->cls.as<uint8_t>(), P->fmask.as<uint8_t>(), P->item_off.as<uint32_t>(), nel,
             g, s, delta, P->items.as<BandItem>(), P->nchunks.as<uint32_t>());
         int rc = scan_exclusive(P, P->nchunks.as<uint32_t>(), P->chunk_off.as<uint32_t>(), (int64_t)n_items + 1, st);
         if (rc) return rc;
@@ -903,7 +1036,7 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     if (n_items)
         band_bin_kernel<false><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr);
     if (want_sign)
-        sign_bin_kernel<false><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, rho_t, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>());
+        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>());
     {
         int rc = scan_exclusive(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
         if (rc) return rc;
@@ -929,7 +1062,7 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     if (n_items)
         band_bin_kernel<true><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>());
     if (want_sign)
-        sign_bin_kernel<true><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, rho_t, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), nullptr);
+        sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), nullptr);
     if (n_active)
         bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
     if (n_active_sign)
@@ -950,7 +1083,7 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
         A.g = g; A.s = s; A.rho_t = rho_t;
         A.band_off = P->band_off.as<uint32_t>(); A.band_ent = P->band_ent.as<uint32_t>();
         A.sign_off = P->sign_off.as<uint32_t>(); A.sign_ent = P->sign_ent.as<uint32_t>();
-        A.items = P->items.as<BandItem>(); A.erec = P->erec.as<ElemRec>();
+        A.items = P->items.as<BandItem>(); A.erec = P->erec.as<typename ET::Rec>();
         A.dist = (mode & R2S_OUT_DIST) ? d_dist : nullptr;
         A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
         A.sdf = (mode & R2S_OUT_SDF) ? d_sdf : nullptr;
@@ -958,8 +1091,8 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
         A.iso_res = P->iso_res.as<double>();
         A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
         if (want_dist && n_chunks)
-            iso_project_kernel<<<(n_chunks + 3) / 4, 256, 0, st>>>(
-                P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<ElemRec>(), g,
+            iso_project_kernel<typename ET::Rec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
+                P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
                 rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
         HIP_TRY(hipEventRecord(P->ev[6], st));
         if (want_dist && n_active) {
@@ -967,7 +1100,7 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
             A.sign = nullptr;
             A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
             A.sdf_mode = 2;
-            sdf_tiles_kernel<true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+            sdf_tiles_kernel<typename ET::Rec, true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
         }
         HIP_TRY(hipEventRecord(P->ev[4], st));
         // sign pass over the tiles whose candidate elements reach rho_t
@@ -976,7 +1109,7 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
             A.dist = nullptr; A.xp = nullptr;
             A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
             A.sdf_mode = 3;
-            sdf_tiles_kernel<false, true><<<(n_active_sign + 3) / 4, 256, 0, st>>>(A);
+            sdf_tiles_kernel<typename ET::Rec, false, true><<<(n_active_sign + 3) / 4, 256, 0, st>>>(A);
         }
     }
     HIP_TRY(hipEventRecord(P->ev[5], st));
@@ -1002,6 +1135,23 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
         (void)hipGetLastError();
     }
     return 0;
+}
+
+extern "C" {
+
+int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* dIEN, int64_t nel,
+                     const double* d_rho_n, double rho_t, const r2s_grid* grid, const r2s_params* params,
+                     int64_t k_begin, int64_t k_end, int32_t mode, double* d_dist, double* d_sign,
+                     double* d_sdf, double* d_xp, void* stream, r2s_stats* stats)
+{
+    const int et = params ? params->elem_type : R2S_HEX8;
+    if (et == R2S_HEX8)
+        return run_impl<HexT>(P, dX, nnp, dIEN, nel, d_rho_n, rho_t, grid, params, k_begin, k_end, mode, d_dist,
+                              d_sign, d_sdf, d_xp, stream, stats);
+    if (et == R2S_TET4)
+        return run_impl<TetT>(P, dX, nnp, dIEN, nel, d_rho_n, rho_t, grid, params, k_begin, k_end, mode, d_dist,
+                              d_sign, d_sdf, d_xp, stream, stats);
+    return fail(R2S_ERR_UNSUPPORTED, "unknown element type %d", et);
 }
 
 // ---- host-pointer entry points (what the Julia wrapper ccalls) ------------------------
@@ -1033,10 +1183,11 @@ static int run_host(const double* X, int64_t nnp, const int64_t* IEN, int64_t ne
     } while (0)
     HIP_TRY_C(hipMalloc((void**)&dX, sizeof(double) * 3 * (size_t)nnp));
     HIP_TRY_C(hipMalloc((void**)&dR, sizeof(double) * (size_t)nnp));
-    HIP_TRY_C(hipMalloc((void**)&dI, sizeof(int64_t) * 8 * (size_t)nel));
+    const int nen = prm.elem_type == R2S_TET4 ? 4 : 8;
+    HIP_TRY_C(hipMalloc((void**)&dI, sizeof(int64_t) * nen * (size_t)nel));
     HIP_TRY_C(hipMemcpy(dX, X, sizeof(double) * 3 * (size_t)nnp, hipMemcpyHostToDevice));
     HIP_TRY_C(hipMemcpy(dR, rho_n, sizeof(double) * (size_t)nnp, hipMemcpyHostToDevice));
-    HIP_TRY_C(hipMemcpy(dI, IEN, sizeof(int64_t) * 8 * (size_t)nel, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemcpy(dI, IEN, sizeof(int64_t) * nen * (size_t)nel, hipMemcpyHostToDevice));
     if (mode & R2S_OUT_DIST) HIP_TRY_C(hipMalloc((void**)&dD, sizeof(double) * (size_t)ngp));
     if (mode & R2S_OUT_SIGN) HIP_TRY_C(hipMalloc((void**)&dS, sizeof(double) * (size_t)ngp));
     if (mode & R2S_OUT_SDF) HIP_TRY_C(hipMalloc((void**)&dF, sizeof(double) * (size_t)ngp));

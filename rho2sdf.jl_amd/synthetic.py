@@ -36,3 +36,29 @@ def grid_n_max_for_points(npts):
     """N_max such that Grid(..., N_max, 3) on [-1,1]^3 has `npts` points per axis
     (N = N_max + 6 cells, +1 points; BASELINE.md: 505 -> 512)."""
     return npts - 7
+
+
+# Schlafli split of a HEX8 into 6 TET4 sharing the 1-7 diagonal
+# (reference test/PrimitiveGeometriesTest/SimpleCubeWithSchlafli.jl:22-29), 0-based local nodes
+SCHLAFLI = np.array([[0, 1, 2, 6], [0, 5, 1, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 4, 5, 6], [0, 7, 4, 6]])
+
+
+def hex_to_tets(IEN_hex):
+    """(nel, 8) 1-based HEX8 connectivity -> (6 nel, 4) TET4 connectivity, element-major"""
+    return np.ascontiguousarray(IEN_hex[:, SCHLAFLI].reshape(-1, 4))
+
+
+def tet_mesh(n, jitter=0.15, seed=20240501):
+    """BASELINE.md config 5 family: the jittered hex mesh split 6-way"""
+    X, IEN, rho_n = hex_mesh(n, jitter, seed)
+    return X, hex_to_tets(IEN), rho_n
+
+
+def radial_cube(n=10, side=10.0):
+    """SimpleCube.jl / SimpleCubeWithSchlafli.jl: cube of side `side` centred at 0, n^3 cells, nodal density
+    1 - r/(sqrt(3) side/2): the 0.5 iso-surface of the interpolant is close to a sphere of radius
+    sqrt(3) side/4.  Returns (X, IEN_hex, rho_n)."""
+    X, IEN, _ = hex_mesh(n, jitter=0.0)
+    X = X * (side / 2.0)
+    rho_n = 1.0 - np.linalg.norm(X, axis=1) / (np.sqrt(3.0) * side / 2.0)
+    return X, IEN, rho_n

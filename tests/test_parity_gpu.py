@@ -123,3 +123,43 @@ def test_slabs_equal_full_volume(pkg, oracle):
             pieces.append(out)
         assert torch.equal(torch.cat(pieces), full), f"{parts} slabs differ from the full volume"
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------
+# TET4 (the reference's only TET4 coverage is PrimitiveGeometriesTest/SimpleCubeWithSchlafli.jl)
+# ---------------------------------------------------------------------------------------
+def test_tet4_radial_cube(pkg, oracle):
+    """SimpleCubeWithSchlafli.jl:19-143: 10^3 cube of side 10 split 6-way, rho_n = 1 - r/(5 sqrt 3), rho_t = 0.5"""
+    from rho2sdf_jl_amd import synthetic
+    X, IH, rn = synthetic.radial_cube(10, 10.0)
+    IT = synthetic.hex_to_tets(IH)
+    pg = pkg.Grid(X.min(0), X.max(0), 40, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), 40, 3)
+    _compare(pkg, oracle, X, IT, rn, 0.5, pg, og, 1.1, "tet4 radial cube")
+    # analytic cross-check: HEX8 and TET4 discretisations of the same field agree to O(h^2)
+    dh, _ = pkg.evalDistances(pkg.Mesh(X, IH), pg, rn, 0.5, want_xp=False)
+    dt, _ = pkg.evalDistances(pkg.Mesh(X, IT), pg, rn, 0.5, want_xp=False)
+    assert np.array_equal(dh == 1e10, dt == 1e10)
+    both = dh < 1e9
+    assert np.abs(dh[both] - dt[both]).max() < 0.1          # h = 1
+
+
+@pytest.mark.parametrize("bf", [1.1, 2.5])
+def test_tet4_jittered(pkg, oracle, bf):
+    """BASELINE config 5 family (jittered Schlafli tets) at oracle size: 6^3*6 tets, 48^3 grid"""
+    from rho2sdf_jl_amd import synthetic
+    X, IT, rn = synthetic.tet_mesh(6)
+    nmax = synthetic.grid_n_max_for_points(48)
+    pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
+    _compare(pkg, oracle, X, IT, rn, 0.5, pg, og, bf, f"tet4 jittered bf{bf}")
+
+
+def test_tet4_solid_boundary(pkg, oracle):
+    """solid tets with boundary faces + iso tets with validated boundary triangles (rho_t low)"""
+    from rho2sdf_jl_amd import synthetic
+    X, IH, rn = synthetic.radial_cube(6, 6.0)
+    IT = synthetic.hex_to_tets(IH)
+    pg = pkg.Grid(X.min(0), X.max(0), 24, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), 24, 3)
+    _compare(pkg, oracle, X, IT, rn, 0.05, pg, og, 1.1, "tet4 solid boundary")
