@@ -306,8 +306,13 @@ static inline iso_fc iso_eval_fc(const double x[3], const double Xe[8][3], const
 /* one active-set pattern of the QP; returns 1 if primal feasible */
 static int qp_pattern(int pat, const double H[3][3], const double g[3], const double a[3],
                       double e, const double lo[3], const double hi[3], double d[3],
-                      double *lam_out, double *q_out, int *kkt_out)
+                      double *lam_out, double *q_out, int *kkt_out, int *next_pat)
 {
+    /* returns 0: pattern unusable, 2: primal infeasible, 1: primal feasible (kkt_out tells optimality);
+     * next_pat: the pattern an active-set step would try next (fix the most violated free variable /
+     * release the fixed variable with the worst multiplier), -1 if none */
+    static const int pw[3] = {1, 3, 9};
+    *next_pat = -1;
     int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
     double dB[3], aa[3], b[3], M[3][3];
     for (int i = 0; i < 3; ++i) dB[i] = (s[i] == 1) ? lo[i] : ((s[i] == 2) ? hi[i] : 0.0);
@@ -346,26 +351,35 @@ static int qp_pattern(int pat, const double H[3][3], const double g[3], const do
     if (!(den > 0.0)) return 0;
     double lam = (aa[0] * v[0] + aa[1] * v[1] + aa[2] * v[2] - ep) / den;
     int ok = 1;
+    double worst = 0.0;
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
             d[i] = dB[i];
         } else {
             d[i] = v[i] - lam * u[i];
-            if (!(d[i] >= lo[i] - QP_PTOL && d[i] <= hi[i] + QP_PTOL)) ok = 0;
+            if (!(d[i] >= lo[i] - QP_PTOL && d[i] <= hi[i] + QP_PTOL)) {
+                ok = 0;
+                double below = (lo[i] - QP_PTOL) - d[i], above = d[i] - (hi[i] + QP_PTOL);
+                double viol = fmax(below, above);
+                if (viol > worst) { worst = viol; *next_pat = pat + ((above > below) ? 2 : 1) * pw[i]; }
+            }
         }
     }
-    if (!ok) return 0;
+    if (!ok) return 2;
     double Hd[3], q = 0.0;
     for (int i = 0; i < 3; ++i) {
         Hd[i] = H[i][0] * d[0] + H[i][1] * d[1] + H[i][2] * d[2];
         q += d[i] * (0.5 * Hd[i] + g[i]);
     }
     int kkt = 1;
+    worst = 0.0;
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
             double z = Hd[i] + g[i] + lam * a[i];
+            double viol = (s[i] == 1) ? -z : z;
             if (s[i] == 1 && !(z >= 0.0)) kkt = 0;
             if (s[i] == 2 && !(z <= 0.0)) kkt = 0;
+            if (viol > worst) { worst = viol; *next_pat = pat - s[i] * pw[i]; }
         }
     }
     *lam_out = lam;
@@ -479,22 +493,35 @@ int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, con
                     H[1][2] += S[2]; H[2][1] += S[2];
                 }
                 double q, dd[3], l2;
-                int kkt, found = 0;
-                if (qp_pattern(pat, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt) && kkt) {
-                    found = 1;
-                    d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
-                    lam_new = l2;
-                } else {
+                int kkt, found = 0, nxt;
+                const int convex = spd3(H, 0.0);
+                {
+                    /* active-set walk from the previous pattern: accept the first pattern that is
+                     * primal feasible and satisfies KKT (the minimiser when the QP is convex) */
+                    int p = pat;
+                    for (int step = 0; step < (convex ? 6 : 1) && p >= 0; ++step) {
+                        int rc = qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt);
+                        if (rc == 0) break;
+                        if (rc == 1 && kkt) {
+                            found = 1;
+                            pat = p;
+                            d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
+                            lam_new = l2;
+                            break;
+                        }
+                        p = nxt;
+                    }
+                }
+                if (!found) {
                     /* patterns with 0, 1, 2 fixed variables (3 fixed cannot meet the
                      * equality); the first one satisfying KKT is the minimiser of the
                      * convex QP; failing that (rounding), the feasible one of least value */
                     static const int order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8,
                                                   10, 11, 19, 20, 12, 15, 21, 24};
                     double bestq = INFINITY;
-                    const int convex = spd3(H, 0.0); /* early exit only for a convex QP */
                     for (int ip = 0; ip < 19; ++ip) {
                         const int p = order[ip];
-                        if (qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt)) {
+                        if (qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt) == 1) {
                             kkt = kkt && convex;
                             if (kkt || q < bestq) {
                                 bestq = q;

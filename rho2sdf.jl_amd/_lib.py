@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librho2sdf_hip.so")
+LIB_PATH = os.environ.get("R2S_LIB_OVERRIDE") or os.path.join(_HERE, "librho2sdf_hip.so")  # override: A/B builds
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int64_p = ctypes.POINTER(ctypes.c_int64)

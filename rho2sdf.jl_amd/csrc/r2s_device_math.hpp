@@ -179,11 +179,14 @@ struct QpOut {
     double lam;
     double q;
     bool kkt;
+    int next;  // pattern an active-set step would try next (-1: none)
 };
 
-R2S_DEV bool qp_pattern(int pat, const double H[3][3], const double g[3], const double a[3], double e,
-                        const double lo[3], const double hi[3], QpOut& o)
+// returns 0: pattern unusable, 2: primal infeasible, 1: primal feasible (o.kkt tells optimality)
+R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const double a[3], double e,
+                       const double lo[3], const double hi[3], QpOut& o)
 {
+    o.next = -1;
     const int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
     double dB[3], aa[3], b[3], M[3][3];
 #pragma unroll
@@ -212,26 +215,33 @@ R2S_DEV bool qp_pattern(int pat, const double H[3][3], const double g[3], const 
     double D1 = M[1][1] - l10 * M[1][0], r1 = 1.0 / D1;
     double l21 = (M[2][1] - l20 * M[1][0]) * r1;
     double D2 = M[2][2] - l20 * M[2][0] - l21 * l21 * D1, r2 = 1.0 / D2;
-    if (!(D0 > 0.0 && D1 > 0.0 && D2 > 0.0)) return false;
+    if (!(D0 > 0.0 && D1 > 0.0 && D2 > 0.0)) return 0;
     double u[3], v[3];
     u[0] = aa[0]; u[1] = aa[1] - l10 * u[0]; u[2] = aa[2] - l20 * u[0] - l21 * u[1];
     v[0] = b[0];  v[1] = b[1] - l10 * v[0];  v[2] = b[2] - l20 * v[0] - l21 * v[1];
     u[2] = u[2] * r2; u[1] = u[1] * r1 - l21 * u[2]; u[0] = u[0] * r0 - l10 * u[1] - l20 * u[2];
     v[2] = v[2] * r2; v[1] = v[1] * r1 - l21 * v[2]; v[0] = v[0] * r0 - l10 * v[1] - l20 * v[2];
     double den = aa[0] * u[0] + aa[1] * u[1] + aa[2] * u[2];
-    if (!(den > 0.0)) return false;
+    if (!(den > 0.0)) return 0;
     double lam = (aa[0] * v[0] + aa[1] * v[1] + aa[2] * v[2] - ep) / den;
     bool ok = true;
+    double worst = 0.0;
+    const int pw[3] = {1, 3, 9};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
             o.d[i] = dB[i];
         } else {
             o.d[i] = v[i] - lam * u[i];
-            if (!(o.d[i] >= lo[i] - 1e-12 && o.d[i] <= hi[i] + 1e-12)) ok = false;
+            if (!(o.d[i] >= lo[i] - 1e-12 && o.d[i] <= hi[i] + 1e-12)) {
+                ok = false;
+                const double below = (lo[i] - 1e-12) - o.d[i], above = o.d[i] - (hi[i] + 1e-12);
+                const double viol = fmax(below, above);
+                if (viol > worst) { worst = viol; o.next = pat + ((above > below) ? 2 : 1) * pw[i]; }
+            }
         }
     }
-    if (!ok) return false;
+    if (!ok) return 2;
     double Hd[3], q = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -239,18 +249,21 @@ R2S_DEV bool qp_pattern(int pat, const double H[3][3], const double g[3], const 
         q += o.d[i] * (0.5 * Hd[i] + g[i]);
     }
     bool kkt = true;
+    worst = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
-            double z = Hd[i] + g[i] + lam * a[i];
+            const double z = Hd[i] + g[i] + lam * a[i];
+            const double viol = (s[i] == 1) ? -z : z;
             if (s[i] == 1 && !(z >= 0.0)) kkt = false;
             if (s[i] == 2 && !(z <= 0.0)) kkt = false;
+            if (viol > worst) { worst = viol; o.next = pat - s[i] * pw[i]; }
         }
     }
     o.lam = lam;
     o.q = q;
     o.kkt = kkt;
-    return true;
+    return 1;
 }
 
 static __constant__ int c_pat_order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8, 10, 11, 19, 20, 12, 15, 21, 24};
@@ -397,18 +410,32 @@ R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, dou
                 }
                 QpOut o;
                 bool found = false;
-                if (qp_pattern(pat, H, gp, a, e, lo, hi, o) && o.kkt) {
-                    found = true;
-                    d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
-                    lam_new = o.lam;
-                } else {
+                const bool convex = spd3(H);
+                {
+                    // active-set walk from the previous pattern: accept the first pattern that is
+                    // primal feasible and satisfies KKT (the minimiser when the QP is convex)
+                    int p = pat;
+                    const int nstep = convex ? 6 : 1;
+                    for (int step = 0; step < nstep && p >= 0; ++step) {
+                        const int rc = qp_pattern(p, H, gp, a, e, lo, hi, o);
+                        if (rc == 0) break;
+                        if (rc == 1 && o.kkt) {
+                            found = true;
+                            pat = p;
+                            d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
+                            lam_new = o.lam;
+                            break;
+                        }
+                        p = o.next;
+                    }
+                }
+                if (!found) {
                     // patterns with 0, 1, 2 fixed variables; the first KKT pattern of a convex
                     // QP is its minimiser, otherwise the feasible pattern of least value
                     double bestq = INFINITY;
-                    const bool convex = spd3(H);
                     for (int ip = 0; ip < 19; ++ip) {
                         const int p = c_pat_order[ip];
-                        if (qp_pattern(p, H, gp, a, e, lo, hi, o)) {
+                        if (qp_pattern(p, H, gp, a, e, lo, hi, o) == 1) {
                             const bool kkt = o.kkt && convex;
                             if (kkt || o.q < bestq) {
                                 bestq = o.q;

@@ -425,7 +425,7 @@ __global__ void item_chunks_kernel(BandItem* __restrict__ items, const uint32_t*
 // requested, `res_xp`; the ordered per-voxel gather (sdf_tiles_kernel) consumes them in the
 // reference's element order, so the strict-'<' update semantics are unchanged.
 template <class Rec>
-__global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __restrict__ items, uint32_t nitems,
+__global__ void __launch_bounds__(256, 3) /* 3 waves/SIMD (<=168 VGPRs): measured best */ iso_project_kernel(const BandItem* __restrict__ items, uint32_t nitems,
                                                          const uint32_t* __restrict__ chunk_off,
                                                          uint32_t nchunks, const Rec* __restrict__ erec,
                                                          GridDev g, double rho_t, double* __restrict__ res,
