@@ -124,7 +124,15 @@ R2S_DEV double cell_of(const GridDev& g, int ax, double x)
 
 // ---- inverse isoparametric map (FindLocalCoordinates.jl:16-107) ------------------
 // Box-clamped Newton from xi = 0 on Xe N(xi) = x; see DESIGN.md "inverse map".
-R2S_DEV bool inv_map_hex8(const ElemRec& E, const double x[3], double xi[3])
+// nodal coordinates + densities only (what the per-voxel solvers read); lets the sign kernel keep
+// candidate elements in LDS
+struct HexXR {
+    double X[8][3];
+    double r[8];
+};
+
+template <class ER>
+R2S_DEV bool inv_map_hex8(const ER& E, const double x[3], double xi[3])
 {
     xi[0] = xi[1] = xi[2] = 0.0;
     for (int it = 0; it < 50; ++it) {
@@ -643,7 +651,8 @@ R2S_DEV void process_iso(VoxState& s, const ElemRec& E, double rt, const double 
 }
 
 // per-voxel state machine of Sign_Detection_HEX8 for one candidate (SignDetection.jl:41-70)
-R2S_DEV void sign_visit(const ElemRec& E, double rt, const double x[3], double& max_local, double& sign,
+template <class ER>
+R2S_DEV void sign_visit(const ER& E, double rt, const double x[3], double& max_local, double& sign,
                         bool& done)
 {
     double xi[3], N[8];

@@ -584,10 +584,45 @@ __global__ void active_tiles_kernel(const uint32_t* __restrict__ band_cnt,
                                     uint32_t* __restrict__ active_band, uint32_t* __restrict__ active_sign,
                                     uint32_t* __restrict__ counters)
 {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntiles) return;
-    if (band_cnt[t]) active_band[atomicAdd(&counters[1], 1u)] = t;
-    if (sign_cnt[t] && hot[t]) active_sign[atomicAdd(&counters[2], 1u)] = t;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = t < ntiles;
+    const bool fb = in && band_cnt[t] != 0;
+    const bool fs = in && sign_cnt[t] != 0 && hot[t] != 0;
+    // wave-aggregated append: one atomic per wavefront and list
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mb = __ballot(fb), ms = __ballot(fs);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t base_b = 0, base_s = 0;
+    if (lane == 0) {
+        if (mb) base_b = atomicAdd(&counters[1], (uint32_t)__popcll(mb));
+        if (ms) base_s = atomicAdd(&counters[2], (uint32_t)__popcll(ms));
+    }
+    base_b = __shfl(base_b, 0, 64);
+    base_s = __shfl(base_s, 0, 64);
+    if (fb) active_band[base_b + __popcll(mb & below)] = t;
+    if (fs) active_sign[base_s + __popcll(ms & below)] = t;
+    // longest lists (decides whether the wave-per-tile sort has to run at all)
+    if (fb && band_cnt[t] > 64u) atomicMax(&counters[3], band_cnt[t]);
+    if (fs && sign_cnt[t] > 64u) atomicMax(&counters[4], sign_cnt[t]);
+}
+
+// short lists (<= 64 entries): one LANE per active tile, rank sort
+__global__ void __launch_bounds__(256) bin_sort_small_kernel(const uint32_t* __restrict__ active, uint32_t n_active,
+                                                            const uint32_t* __restrict__ off,
+                                                            const uint32_t* __restrict__ in,
+                                                            uint32_t* __restrict__ out)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_active) return;
+    const uint32_t t = active[w];
+    const uint32_t b = off[t], n = off[t + 1] - b;
+    if (n > 64) return;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t v = in[b + i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += (in[b + j] < v) ? 1u : 0u;
+        out[b + rank] = v;
+    }
 }
 
 // one wavefront per active tile: rank-sort both lists ascending (the reference visits
@@ -602,6 +637,7 @@ __global__ void __launch_bounds__(256) bin_sort_kernel(const uint32_t* __restric
     if (w >= n_active) return;
     const uint32_t t = active[w];
     const uint32_t b = off[t], n = off[t + 1] - b;
+    if (n <= 64) return;   // handled by bin_sort_small_kernel
     for (uint32_t i = lane; i < n; i += 64) {
         const uint32_t v = in[b + i];
         uint32_t rank = 0;
@@ -703,7 +739,9 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
     if (DO_SIGN) {
         const uint32_t b = A.sign_off[t], e = A.sign_off[t + 1];
         if constexpr (std::is_same<Rec, ElemRec>::value) {
-            // Sign_Detection_HEX8 (SignDetection.jl:27-70)
+            // Sign_Detection_HEX8 (SignDetection.jl:27-70): wave-uniform walk over the tile's candidate
+            // list (element record in SGPRs).  A per-lane walk with LDS-staged candidates was measured
+            // slower (register pressure halves the occupancy of this latency-bound Newton chain).
             bool any = false;
             double cmax = -INFINITY;
             for (uint32_t p = b; p < e; ++p) {
@@ -1025,7 +1063,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         int rc = scan_exclusive(P, P->nchunks.as<uint32_t>(), P->chunk_off.as<uint32_t>(), (int64_t)n_items + 1, st);
         if (rc) return rc;
         item_chunks_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(P->items.as<BandItem>(), P->chunk_off.as<uint32_t>(), n_items);
-        HIP_TRY(hipMemcpyAsync(&P->h_pinned[6], P->chunk_off.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&P->h_pinned[10], P->chunk_off.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(P->ev[1], st));
 
@@ -1046,11 +1084,11 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     active_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), counters);
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[2], P->band_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[3], P->sign_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4],
                    n_active_sign = P->h_pinned[5];
-    const uint32_t n_chunks = n_items ? P->h_pinned[6] : 0;
+    const uint32_t n_chunks = n_items ? P->h_pinned[10] : 0;
     ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_chunks, 1));
     if (mode & R2S_OUT_XP) ENSURE(P->iso_res_xp, sizeof(double) * 192 * (size_t)std::max<uint32_t>(n_chunks, 1));
     ENSURE(P->band_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
@@ -1063,10 +1101,17 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         band_bin_kernel<true><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>());
     if (want_sign)
         sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), nullptr);
-    if (n_active)
-        bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
-    if (n_active_sign)
-        bin_sort_kernel<<<(n_active_sign + 3) / 4, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>());
+    // lists longer than 64 entries only occur when the grid is coarse relative to the mesh (few tiles)
+    if (n_active) {
+        bin_sort_small_kernel<<<(n_active + 255) / 256, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
+        if (P->h_pinned[6] > 64u)
+            bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
+    }
+    if (n_active_sign) {
+        bin_sort_small_kernel<<<(n_active_sign + 255) / 256, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>());
+        if (P->h_pinned[7] > 64u)
+            bin_sort_kernel<<<(n_active_sign + 3) / 4, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>());
+    }
     HIP_TRY(hipEventRecord(P->ev[2], st));
 
     // ---- sentinel sweep ----
