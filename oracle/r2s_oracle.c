@@ -197,6 +197,71 @@ static int lu_solve(int n, double *A /* n*n row-major, destroyed */, double *b)
 }
 
 /* ------------------------------------------------------------------ */
+/* Monomial form of the trilinear maps (solver internals only)         */
+/*   X(xi) = sum_m C[m] mono_m(xi),                                     */
+/*   mono = [1, x1, x2, x3, x1x2, x1x3, x2x3, x1x2x3]                    */
+/* The coefficients live behind the nodal values: Xe[8+m], re[8+m]      */
+/* (element arrays are declared with 16 rows).  The reference evaluates */
+/* N(xi) node by node (hex8_shape.jl); the restated solvers (NLopt      */
+/* stand-ins) use this cheaper, algebraically identical form, while     */
+/* every quantity the reference itself computes (xp = Xe N, rho = N.re) */
+/* keeps the nodal form.                                                */
+/* ------------------------------------------------------------------ */
+static const double MONO_SIGN[8][8] = {
+    /* node:      0   1   2   3   4   5   6   7 */
+    /* 1     */ { 1,  1,  1,  1,  1,  1,  1,  1},
+    /* x1    */ {-1,  1,  1, -1, -1,  1,  1, -1},
+    /* x2    */ {-1, -1,  1,  1, -1, -1,  1,  1},
+    /* x3    */ {-1, -1, -1, -1,  1,  1,  1,  1},
+    /* x1x2  */ { 1, -1,  1, -1,  1, -1,  1, -1},
+    /* x1x3  */ { 1, -1, -1,  1, -1,  1,  1, -1},
+    /* x2x3  */ { 1,  1, -1, -1, -1, -1,  1,  1},
+    /* x1x2x3*/ {-1,  1, -1,  1,  1, -1,  1, -1}};
+
+static void hex8_monomials(double Xe[16][3], double re[16])
+{
+    for (int m = 0; m < 8; ++m) {
+        for (int i = 0; i < 3; ++i) {
+            double t = 0.0;
+            for (int k = 0; k < 8; ++k) t += MONO_SIGN[m][k] * Xe[k][i];
+            Xe[8 + m][i] = 0.125 * t;
+        }
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += MONO_SIGN[m][k] * re[k];
+        re[8 + m] = 0.125 * t;
+    }
+}
+
+/* value and first derivatives of one scalar trilinear field with coefficients c[0..7] (stride st) */
+typedef struct { double v, d1, d2, d3, m12, m13, m23; } tri_eval;
+static inline tri_eval tri_eval_full(const double *c, int st, const double xi[3])
+{
+    tri_eval o;
+    double q0 = fma(xi[2], c[3 * st], c[0]);          /* C0 + C3 x3    */
+    double q1 = fma(xi[2], c[5 * st], c[1 * st]);     /* C1 + C13 x3   */
+    double q2 = fma(xi[2], c[6 * st], c[2 * st]);     /* C2 + C23 x3   */
+    double q3 = fma(xi[2], c[7 * st], c[4 * st]);     /* C12 + C123 x3 */
+    double r0 = fma(xi[1], q2, q0);
+    double r1 = fma(xi[1], q3, q1);                   /* d/dx1         */
+    o.v = fma(xi[0], r1, r0);
+    o.d1 = r1;
+    o.d2 = fma(xi[0], q3, q2);
+    o.m13 = fma(xi[1], c[7 * st], c[5 * st]);         /* C13 + C123 x2 */
+    o.m23 = fma(xi[0], c[7 * st], c[6 * st]);         /* C23 + C123 x1 */
+    o.d3 = fma(xi[0], o.m13, fma(xi[1], c[6 * st], c[3 * st]));
+    o.m12 = q3;
+    return o;
+}
+static inline double tri_eval_value(const double *c, int st, const double xi[3])
+{
+    double q0 = fma(xi[2], c[3 * st], c[0]);
+    double q1 = fma(xi[2], c[5 * st], c[1 * st]);
+    double q2 = fma(xi[2], c[6 * st], c[2 * st]);
+    double q3 = fma(xi[2], c[7 * st], c[4 * st]);
+    return fma(xi[0], fma(xi[1], q3, q1), fma(xi[1], q2, q0));
+}
+
+/* ------------------------------------------------------------------ */
 /* Inverse isoparametric map, HEX8                                     */
 /* (src/SignedDistances/FindLocalCoordinates.jl:16-107)                */
 /*                                                                     */
@@ -215,17 +280,11 @@ static int inv_map_hex8(const double Xe[8][3], const double x[3], double xi[3])
 {
     xi[0] = xi[1] = xi[2] = 0.0;
     for (int it = 0; it < INV_MAXIT; ++it) {
-        double N[8], dN[8][3], R[3], J[3][3];
-        hex8_shape_d(xi, N, dN);
+        double R[3], J[3][3];
         for (int i = 0; i < 3; ++i) {
-            double s = 0.0;
-            for (int k = 0; k < 8; ++k) s = fma(Xe[k][i], N[k], s);
-            R[i] = s - x[i];
-            for (int j = 0; j < 3; ++j) {
-                double t = 0.0;
-                for (int k = 0; k < 8; ++k) t = fma(Xe[k][i], dN[k][j], t);
-                J[i][j] = t;
-            }
+            tri_eval t = tri_eval_full(&Xe[8][i], 3, xi);
+            R[i] = t.v - x[i];
+            J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
         }
         /* delta = -J^{-1} R by the adjugate */
         double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
@@ -287,17 +346,13 @@ typedef struct {
 static inline iso_fc iso_eval_fc(const double x[3], const double Xe[8][3], const double re[8],
                                  double rt, const double xi[3])
 {
-    double N[8];
-    hex8_shape(xi, N);
     iso_fc o;
-    double f = 0.0, rho = 0.0;
+    double f = 0.0;
     for (int i = 0; i < 3; ++i) {
-        double s = 0.0;
-        for (int k = 0; k < 8; ++k) s = fma(Xe[k][i], N[k], s);
-        double r = x[i] - s;
+        double r = x[i] - tri_eval_value(&Xe[8][i], 3, xi);
         f += r * r;
     }
-    for (int k = 0; k < 8; ++k) rho = fma(re[k], N[k], rho);
+    double rho = tri_eval_value(&re[8], 1, xi);
     o.f = f;
     o.c = rho - rt;
     return o;
@@ -401,36 +456,39 @@ static int spd3(const double H[3][3], double floor_)
 }
 
 /* returns number of iterations used (ISO_MAXIT+1 if not converged) */
-int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, const double re[8],
+static int iso_project_hex8(const double x[3], const double Xe[16][3], const double re[16], double rt, double xi[3]);
+int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, const double re_in[8],
                          double rt, double xi[3])
 {
-    const double(*Xe)[3] = (const double(*)[3])Xe_flat;
+    double Xe[16][3], re[16];
+    for (int k = 0; k < 8; ++k) {
+        for (int i = 0; i < 3; ++i) Xe[k][i] = Xe_flat[3 * k + i];
+        re[k] = re_in[k];
+    }
+    hex8_monomials(Xe, re);
+    return iso_project_hex8(x, Xe, re, rt, xi);
+}
+
+/* the solver proper; Xe/re carry the monomial coefficients in rows 8..15 */
+static int iso_project_hex8(const double x[3], const double Xe[16][3], const double re[16], double rt, double xi[3])
+{
     xi[0] = xi[1] = xi[2] = 0.0;
     double mu = 0.0, lam = 0.0, Delta = 2.0;
     int pat = 0;
     for (int it = 0; it < ISO_MAXIT; ++it) {
-        double N[8], dN[8][3], m2[8][3], r[3], J[3][3], a[3], g[3], G[3][3];
-        hex8_shape_d(xi, N, dN);
-        double f = 0.0, rho = 0.0;
+        double r[3], J[3][3], a[3], g[3], G[3][3], M2[3][3]; /* M2[i][q]: mixed derivatives of p_i */
+        double f = 0.0;
         for (int i = 0; i < 3; ++i) {
-            double s = 0.0;
-            for (int k = 0; k < 8; ++k) s = fma(Xe[k][i], N[k], s);
-            r[i] = x[i] - s;
+            tri_eval t = tri_eval_full(&Xe[8][i], 3, xi);
+            r[i] = x[i] - t.v;
             f += r[i] * r[i];
-            for (int j = 0; j < 3; ++j) {
-                double t = 0.0;
-                for (int k = 0; k < 8; ++k) t = fma(Xe[k][i], dN[k][j], t);
-                J[i][j] = t;
-            }
+            J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
+            M2[i][0] = t.m12; M2[i][1] = t.m13; M2[i][2] = t.m23;
         }
-        for (int k = 0; k < 8; ++k) rho = fma(re[k], N[k], rho);
-        double c = rho - rt;
-        for (int j = 0; j < 3; ++j) {
-            double t = 0.0;
-            for (int k = 0; k < 8; ++k) t = fma(re[k], dN[k][j], t);
-            a[j] = t;
-            g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
-        }
+        tri_eval tr = tri_eval_full(&re[8], 1, xi);
+        double c = tr.v - rt;
+        a[0] = tr.d1; a[1] = tr.d2; a[2] = tr.d3;
+        for (int j = 0; j < 3; ++j) g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j)
                 G[i][j] = 2.0 * (J[0][i] * J[0][j] + J[1][i] * J[1][j] + J[2][i] * J[2][j]);
@@ -444,15 +502,11 @@ int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, con
             lam = (den > 0.0) ? -num / den : 0.0;
         }
         /* second-order part: S_jl = -2 sum_i r_i d2p_i/djdl + lam d2rho/djdl */
-        hex8_shape_mixed(xi, m2);
         double S[3]; /* (0,1) (0,2) (1,2) */
-        for (int q = 0; q < 3; ++q) {
-            double pr = 0.0, rr = 0.0;
-            for (int k = 0; k < 8; ++k) {
-                pr = fma(r[0] * Xe[k][0] + r[1] * Xe[k][1] + r[2] * Xe[k][2], m2[k][q], pr);
-                rr = fma(re[k], m2[k][q], rr);
-            }
-            S[q] = -2.0 * pr + lam * rr;
+        {
+            const double mr[3] = {tr.m12, tr.m13, tr.m23};
+            for (int q = 0; q < 3; ++q)
+                S[q] = -2.0 * (r[0] * M2[0][q] + r[1] * M2[1][q] + r[2] * M2[2][q]) + lam * mr[q];
         }
         double lo[3], hi[3], d[3];
         for (int i = 0; i < 3; ++i) {
@@ -468,114 +522,105 @@ int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, con
         double trG = G[0][0] + G[1][1] + G[2][2];
         double aa2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
         double sigma = 100.0 * trG / aa2;
-        int use_exact = 1, corner, stop = 0;
-        double lam_new, alpha;
-        for (;;) {
-            corner = 0;
-            lam_new = lam;
-            if (e >= mplus) {
-                for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
-                corner = 1;
-            } else if (e <= mminus) {
-                for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
-                corner = 1;
-            } else {
-                /* convexified QP data: H' = H + sigma a a^T, g' = g - sigma e a
-                 * (identical to (H,g) on the plane a.d = e) */
-                double H[3][3], gp[3];
-                for (int i = 0; i < 3; ++i) {
+        int use_exact = 1, corner = 0, stop = 0;
+        double lam_new = lam, alpha = 1.0;
+        if (e >= mplus) {
+            for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
+            corner = 1;
+        } else if (e <= mminus) {
+            for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
+            corner = 1;
+        } else {
+            /* convexified QP data: H' = H + sigma a a^T, g' = g - sigma e a (identical to (H,g) on
+             * the plane a.d = e).  Exact Lagrangian Hessian when H' is positive definite, else
+             * Gauss-Newton (always positive definite): the QP is strictly convex either way. */
+            double H[3][3], gp[3];
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
+                gp[i] = g[i] - sigma * e * a[i];
+            }
+            H[0][1] += S[0]; H[1][0] += S[0];
+            H[0][2] += S[1]; H[2][0] += S[1];
+            H[1][2] += S[2]; H[2][1] += S[2];
+            if (!spd3(H, 0.0)) {
+                use_exact = 0;
+                for (int i = 0; i < 3; ++i)
                     for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
-                    gp[i] = g[i] - sigma * e * a[i];
+            }
+            double q, dd[3], l2;
+            int kkt, found = 0, nxt;
+            {
+                /* active-set walk from the previous pattern: the first pattern that is primal
+                 * feasible and satisfies KKT is the minimiser of the strictly convex QP */
+                int p = pat;
+                for (int step = 0; step < 6 && p >= 0; ++step) {
+                    int rc = qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt);
+                    if (rc == 0) break;
+                    if (rc == 1 && kkt) {
+                        found = 1;
+                        pat = p;
+                        d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
+                        lam_new = l2;
+                        break;
+                    }
+                    p = nxt;
                 }
-                if (use_exact) {
-                    H[0][1] += S[0]; H[1][0] += S[0];
-                    H[0][2] += S[1]; H[2][0] += S[1];
-                    H[1][2] += S[2]; H[2][1] += S[2];
-                }
-                double q, dd[3], l2;
-                int kkt, found = 0, nxt;
-                const int convex = spd3(H, 0.0);
-                {
-                    /* active-set walk from the previous pattern: accept the first pattern that is
-                     * primal feasible and satisfies KKT (the minimiser when the QP is convex) */
-                    int p = pat;
-                    for (int step = 0; step < (convex ? 6 : 1) && p >= 0; ++step) {
-                        int rc = qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt);
-                        if (rc == 0) break;
-                        if (rc == 1 && kkt) {
+            }
+            if (!found) {
+                /* exhaustive fallback: patterns with 0, 1, 2 fixed variables (3 fixed cannot meet
+                 * the equality); first KKT pattern, failing that (rounding) the feasible one of
+                 * least value */
+                static const int order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8,
+                                              10, 11, 19, 20, 12, 15, 21, 24};
+                double bestq = INFINITY;
+                for (int ip = 0; ip < 19; ++ip) {
+                    const int p = order[ip];
+                    if (qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt) == 1) {
+                        if (kkt || q < bestq) {
+                            bestq = q;
                             found = 1;
                             pat = p;
                             d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
                             lam_new = l2;
-                            break;
                         }
-                        p = nxt;
+                        if (kkt) break;
                     }
                 }
-                if (!found) {
-                    /* patterns with 0, 1, 2 fixed variables (3 fixed cannot meet the
-                     * equality); the first one satisfying KKT is the minimiser of the
-                     * convex QP; failing that (rounding), the feasible one of least value */
-                    static const int order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8,
-                                                  10, 11, 19, 20, 12, 15, 21, 24};
-                    double bestq = INFINITY;
-                    for (int ip = 0; ip < 19; ++ip) {
-                        const int p = order[ip];
-                        if (qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt) == 1) {
-                            kkt = kkt && convex;
-                            if (kkt || q < bestq) {
-                                bestq = q;
-                                found = 1;
-                                pat = p;
-                                d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
-                                lam_new = l2;
-                            }
-                            if (kkt) break;
-                        }
-                    }
-                }
-                if (!found) {
-                    if (use_exact) { use_exact = 0; continue; }
-                    /* numerically degenerate: corner move towards feasibility */
-                    for (int i = 0; i < 3; ++i)
-                        d[i] = (e > 0.0) ? ((a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0))
-                                         : ((a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0));
-                    corner = 1;
-                }
-                for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
             }
+            if (!found) { /* numerically degenerate: corner move towards feasibility */
+                for (int i = 0; i < 3; ++i)
+                    d[i] = (e > 0.0) ? ((a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0))
+                                     : ((a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0));
+                corner = 1;
+            }
+            for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
+        }
+        {
             double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
-            alpha = 1.0;
             if (!(dmax > ISO_TOL)) { /* converged (or stuck at an infeasible corner) */
                 stop = corner ? 2 : 1;
-                break;
-            }
-            double ad = a[0] * d[0] + a[1] * d[1] + a[2] * d[2];
-            double pred_c = fabs(c) - fabs(c + ad);
-            double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
-            double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
-            if (!(gd - mu_t * pred_c < 0.0)) {
-                if (pred_c > 0.0) {
-                    mu_t = 2.0 * gd / pred_c;
-                } else if (use_exact && !corner) {
-                    use_exact = 0;
-                    continue;
-                } else {
-                    stop = 2;
-                    break;
+            } else {
+                double ad = a[0] * d[0] + a[1] * d[1] + a[2] * d[2];
+                double pred_c = fabs(c) - fabs(c + ad);
+                double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+                double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
+                if (!(gd - mu_t * pred_c < 0.0)) {
+                    if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
+                    else stop = 2; /* no descent on the merit function */
+                }
+                if (!stop) {
+                    mu = mu_t;
+                    double D = gd - mu * pred_c;
+                    double phi0 = f + mu * fabs(c);
+                    for (int ls = 0; ls < 30; ++ls) {
+                        double xt[3];
+                        for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
+                        iso_fc t = iso_eval_fc(x, Xe, re, rt, xt);
+                        if (t.f + mu * fabs(t.c) <= phi0 + 1e-4 * alpha * D) break;
+                        alpha *= 0.5;
+                    }
                 }
             }
-            mu = mu_t;
-            double D = gd - mu * pred_c;
-            double phi0 = f + mu * fabs(c);
-            for (int ls = 0; ls < 30; ++ls) {
-                double xt[3];
-                for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
-                iso_fc t = iso_eval_fc(x, Xe, re, rt, xt);
-                if (t.f + mu * fabs(t.c) <= phi0 + 1e-4 * alpha * D) break;
-                alpha *= 0.5;
-            }
-            break;
         }
         {
             double dm = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
@@ -906,7 +951,7 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
     }
     int64_t n_solid = 0, n_iso = 0;
     for (int64_t el = 0; el < nel; ++el) {
-        double Xe[8][3], re[8];
+        double Xe[16][3], re[16];
         double rmin = INFINITY, rmax = -INFINITY;
         for (int a = 0; a < 8; ++a) {
             int64_t n = IEN[el * 8 + a] - 1;
@@ -915,6 +960,7 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
             if (re[a] < rmin) rmin = re[a];
             if (re[a] > rmax) rmax = re[a];
         }
+        if (rmin >= rho_t || rmax > rho_t) hex8_monomials(Xe, re); /* solver coefficients */
         if (rmin >= rho_t) { /* :201 */
             n_solid++;
             process_boundary_faces(&c, &m, el, 1, Xe, re, rho_t);
@@ -932,7 +978,7 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
                         int64_t vk = v / ((g->N[0] + 1) * (g->N[1] + 1));
                         double x[3], xi[3], N[8], xp[3], dv[3];
                         grid_point(g, vi, vj, vk, x);
-                        int it = orc_iso_project_hex8(x, &Xe[0][0], re, rho_t, xi); /* :616 */
+                        int it = iso_project_hex8(x, Xe, re, rho_t, xi); /* :616 */
                         c.n_iso_solves++;
                         if (it > ISO_MAXIT) c.n_iso_fail++;
                         hex8_shape(xi, N);
@@ -1028,8 +1074,9 @@ int orc_sign_detection_bruteforce(const double *X, int64_t nnp, const int64_t *I
                 const double *a = mn + 3 * el, *b = mx + 3 * el;
                 if (!(a[0] <= x[0] && a[1] <= x[1] && a[2] <= x[2] && x[0] <= b[0] && x[1] <= b[1] && x[2] <= b[2]))
                     continue;
-                double Xe[8][3], re[8], t1[3], t2[3], t3;
+                double Xe[16][3], re[16], t1[3], t2[3], t3;
                 elem_gather_hex8(X, IEN, rho_n, el, Xe, re, t1, t2, &t3);
+                hex8_monomials(Xe, re);
                 sign_visit(Xe, re, rho_t, x, &max_local, &signs[v], &done);
             }
         }
@@ -1051,8 +1098,9 @@ int orc_sign_detection(const double *X, int64_t nnp, const int64_t *IEN, int64_t
     for (int64_t v = 0; v < ngp; ++v) { signs[v] = -1.0; cmax[v] = -INFINITY; mloc[v] = 10.0; }
     for (int pass = 0; pass < 2; ++pass)
         for (int64_t el = 0; el < nel; ++el) {
-            double Xe[8][3], re[8], mn[3], mx[3], rmax;
+            double Xe[16][3], re[16], mn[3], mx[3], rmax;
             elem_gather_hex8(X, IEN, rho_n, el, Xe, re, mn, mx, &rmax);
+            if (pass == 1) hex8_monomials(Xe, re);
             int64_t lo[3], hi[3];
             for (int ax = 0; ax < 3; ++ax) { /* conservative lattice range; exact test below */
                 double a = floor((mn[ax] - g->amin[ax]) / g->cell) - 1.0;
@@ -1907,7 +1955,7 @@ int orc_eval_distances_tet4(const double *X, int64_t nnp, const int64_t *IEN, in
     }
     int64_t n_solid = 0, n_iso = 0;
     for (int64_t el = 0; el < nel; ++el) {
-        double Xe[8][3] = {{0}}, re[8] = {0}, rmin = INFINITY, rmax = -INFINITY;
+        double Xe[16][3] = {{0}}, re[16] = {0}, rmin = INFINITY, rmax = -INFINITY; /* 16 rows: shared signatures */
         for (int a = 0; a < 4; ++a) {
             int64_t n = IEN[el * 4 + a] - 1;
             for (int i = 0; i < 3; ++i) Xe[a][i] = X[3 * n + i];

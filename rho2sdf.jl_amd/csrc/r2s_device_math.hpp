@@ -22,6 +22,10 @@ struct alignas(16) ElemRec {
     double mx[3];
     double rmax;
     double rmin;
+    // monomial coefficients of the trilinear maps, used by the restated solvers only:
+    // X(xi) = sum_m C[m] mono_m(xi), mono = [1, x1, x2, x3, x1x2, x1x3, x2x3, x1x2x3]
+    double C[8][3];
+    double Cr[8];
 };
 
 // band work item: one boundary-face triangle (process_triangle_projection!,
@@ -124,33 +128,72 @@ R2S_DEV double cell_of(const GridDev& g, int ax, double x)
 
 // ---- inverse isoparametric map (FindLocalCoordinates.jl:16-107) ------------------
 // Box-clamped Newton from xi = 0 on Xe N(xi) = x; see DESIGN.md "inverse map".
-// nodal coordinates + densities only (what the per-voxel solvers read); lets the sign kernel keep
-// candidate elements in LDS
-struct HexXR {
-    double X[8][3];
-    double r[8];
+// signs of the monomial expansion: C[m] = 1/8 sum_k MONO_SIGN[m][k] X_k (node order of hex8_shape.jl)
+__device__ const double c_mono_sign[8][8] = {
+    {1, 1, 1, 1, 1, 1, 1, 1},     {-1, 1, 1, -1, -1, 1, 1, -1}, {-1, -1, 1, 1, -1, -1, 1, 1},
+    {-1, -1, -1, -1, 1, 1, 1, 1}, {1, -1, 1, -1, 1, -1, 1, -1}, {1, -1, -1, 1, -1, 1, 1, -1},
+    {1, 1, -1, -1, -1, -1, 1, 1}, {-1, 1, -1, 1, 1, -1, 1, -1}};
+
+R2S_DEV void hex8_monomials(ElemRec& R)
+{
+    for (int m = 0; m < 8; ++m) {
+        for (int i = 0; i < 3; ++i) {
+            double t = 0.0;
+            for (int k = 0; k < 8; ++k) t += c_mono_sign[m][k] * R.X[k][i];
+            R.C[m][i] = 0.125 * t;
+        }
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += c_mono_sign[m][k] * R.r[k];
+        R.Cr[m] = 0.125 * t;
+    }
+}
+
+// value, gradient and mixed second derivatives of one scalar trilinear field (12 FMAs)
+struct TriEval {
+    double v, d1, d2, d3, m12, m13, m23;
 };
+R2S_DEV TriEval tri_eval_full(double c0, double c1, double c2, double c3, double c12, double c13, double c23,
+                              double c123, const double xi[3])
+{
+    TriEval o;
+    const double q0 = fma(xi[2], c3, c0);
+    const double q1 = fma(xi[2], c13, c1);
+    const double q2 = fma(xi[2], c23, c2);
+    const double q3 = fma(xi[2], c123, c12);
+    const double r0 = fma(xi[1], q2, q0);
+    const double r1 = fma(xi[1], q3, q1);
+    o.v = fma(xi[0], r1, r0);
+    o.d1 = r1;
+    o.d2 = fma(xi[0], q3, q2);
+    o.m13 = fma(xi[1], c123, c13);
+    o.m23 = fma(xi[0], c123, c23);
+    o.d3 = fma(xi[0], o.m13, fma(xi[1], c23, c3));
+    o.m12 = q3;
+    return o;
+}
+R2S_DEV double tri_eval_value(double c0, double c1, double c2, double c3, double c12, double c13, double c23,
+                              double c123, const double xi[3])
+{
+    const double q0 = fma(xi[2], c3, c0);
+    const double q1 = fma(xi[2], c13, c1);
+    const double q2 = fma(xi[2], c23, c2);
+    const double q3 = fma(xi[2], c123, c12);
+    return fma(xi[0], fma(xi[1], q3, q1), fma(xi[1], q2, q0));
+}
+#define R2S_CX(E, i) (E).C[0][i], (E).C[1][i], (E).C[2][i], (E).C[3][i], (E).C[4][i], (E).C[5][i], (E).C[6][i], (E).C[7][i]
+#define R2S_CR(E) (E).Cr[0], (E).Cr[1], (E).Cr[2], (E).Cr[3], (E).Cr[4], (E).Cr[5], (E).Cr[6], (E).Cr[7]
 
 template <class ER>
 R2S_DEV bool inv_map_hex8(const ER& E, const double x[3], double xi[3])
 {
     xi[0] = xi[1] = xi[2] = 0.0;
     for (int it = 0; it < 50; ++it) {
-        double N[8], dN[8][3], R[3], J[3][3];
-        hex8_shape_d(xi, N, dN);
+        double R[3], J[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s = fma(E.X[k][i], N[k], s);
-            R[i] = s - x[i];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double t = 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) t = fma(E.X[k][i], dN[k][j], t);
-                J[i][j] = t;
-            }
+            const TriEval t = tri_eval_full(R2S_CX(E, i), xi);
+            R[i] = t.v - x[i];
+            J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
         }
         double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
         double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
@@ -291,19 +334,13 @@ R2S_DEV bool spd3(const double H[3][3])
 R2S_DEV void iso_eval_fc(const ElemRec& E, const double x[3], double rt, const double xi[3], double& f,
                          double& c)
 {
-    double N[8];
-    hex8_shape(xi, N);
-    double ff = 0.0, rho = 0.0;
+    double ff = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s = fma(E.X[k][i], N[k], s);
-        double r = x[i] - s;
+        const double r = x[i] - tri_eval_value(R2S_CX(E, i), xi);
         ff += r * r;
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) rho = fma(E.r[k], N[k], rho);
+    const double rho = tri_eval_value(R2S_CR(E), xi);
     f = ff;
     c = rho - rt;
 }
@@ -318,35 +355,21 @@ R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, dou
     double mu = 0.0, lam = 0.0, Delta = 2.0;
     int pat = 0;
     for (int it = 0; it < R2S_ISO_MAXIT; ++it) {
-        double N[8], dN[8][3], m2[8][3], r[3], J[3][3], a[3], g[3], G[3][3];
-        hex8_shape_d(xi, N, dN);
-        double f = 0.0, rho = 0.0;
+        double r[3], J[3][3], a[3], g[3], G[3][3], M2[3][3];   // M2[i][q]: mixed derivatives of p_i
+        double f = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s = fma(E.X[k][i], N[k], s);
-            r[i] = x[i] - s;
+            const TriEval t = tri_eval_full(R2S_CX(E, i), xi);
+            r[i] = x[i] - t.v;
             f += r[i] * r[i];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double t = 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) t = fma(E.X[k][i], dN[k][j], t);
-                J[i][j] = t;
-            }
+            J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
+            M2[i][0] = t.m12; M2[i][1] = t.m13; M2[i][2] = t.m23;
         }
+        const TriEval tr = tri_eval_full(R2S_CR(E), xi);
+        const double c = tr.v - rt;
+        a[0] = tr.d1; a[1] = tr.d2; a[2] = tr.d3;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) rho = fma(E.r[k], N[k], rho);
-        const double c = rho - rt;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t = fma(E.r[k], dN[k][j], t);
-            a[j] = t;
-            g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
-        }
+        for (int j = 0; j < 3; ++j) g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -360,17 +383,12 @@ R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, dou
                 if (!s[i]) { num += a[i] * g[i]; den += a[i] * a[i]; }
             lam = (den > 0.0) ? -num / den : 0.0;
         }
-        hex8_shape_mixed(xi, m2);
         double S[3];
+        {
+            const double mr[3] = {tr.m12, tr.m13, tr.m23};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            double pr = 0.0, rr = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                pr = fma(r[0] * E.X[k][0] + r[1] * E.X[k][1] + r[2] * E.X[k][2], m2[k][q], pr);
-                rr = fma(E.r[k], m2[k][q], rr);
-            }
-            S[q] = -2.0 * pr + lam * rr;
+            for (int q = 0; q < 3; ++q)
+                S[q] = -2.0 * (r[0] * M2[0][q] + r[1] * M2[1][q] + r[2] * M2[2][q]) + lam * mr[q];
         }
         double lo[3], hi[3], d[3];
 #pragma unroll
@@ -389,117 +407,111 @@ R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, dou
         const double trG = G[0][0] + G[1][1] + G[2][2];
         const double aa2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
         const double sigma = 100.0 * trG / aa2;
-        bool use_exact = true, corner = false;
+        bool corner = false;
         int stop = 0;
         double lam_new = lam, alpha = 1.0;
-        for (;;) {
-            corner = false;
-            lam_new = lam;
-            if (e >= mplus) {
+        if (e >= mplus) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
-                corner = true;
-            } else if (e <= mminus) {
+            for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
+            corner = true;
+        } else if (e <= mminus) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
-                corner = true;
-            } else {
-                double H[3][3], gp[3];
+            for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
+            corner = true;
+        } else {
+            // convexified QP data: H' = H + sigma a a^T, g' = g - sigma e a (identical to (H,g) on the
+            // plane a.d = e).  Exact Lagrangian Hessian when H' is positive definite, else Gauss-Newton
+            // (always positive definite): the QP is strictly convex either way.
+            double H[3][3], gp[3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
+                gp[i] = g[i] - sigma * e * a[i];
+            }
+            H[0][1] += S[0]; H[1][0] += S[0];
+            H[0][2] += S[1]; H[2][0] += S[1];
+            H[1][2] += S[2]; H[2][1] += S[2];
+            if (!spd3(H)) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
-                    gp[i] = g[i] - sigma * e * a[i];
+            }
+            QpOut o;
+            bool found = false;
+            {
+                // active-set walk from the previous pattern: the first pattern that is primal feasible
+                // and satisfies KKT is the minimiser of the strictly convex QP
+                int p = pat;
+                for (int step = 0; step < 6 && p >= 0; ++step) {
+                    const int rc = qp_pattern(p, H, gp, a, e, lo, hi, o);
+                    if (rc == 0) break;
+                    if (rc == 1 && o.kkt) {
+                        found = true;
+                        pat = p;
+                        d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
+                        lam_new = o.lam;
+                        break;
+                    }
+                    p = o.next;
                 }
-                if (use_exact) {
-                    H[0][1] += S[0]; H[1][0] += S[0];
-                    H[0][2] += S[1]; H[2][0] += S[1];
-                    H[1][2] += S[2]; H[2][1] += S[2];
-                }
-                QpOut o;
-                bool found = false;
-                const bool convex = spd3(H);
-                {
-                    // active-set walk from the previous pattern: accept the first pattern that is
-                    // primal feasible and satisfies KKT (the minimiser when the QP is convex)
-                    int p = pat;
-                    const int nstep = convex ? 6 : 1;
-                    for (int step = 0; step < nstep && p >= 0; ++step) {
-                        const int rc = qp_pattern(p, H, gp, a, e, lo, hi, o);
-                        if (rc == 0) break;
-                        if (rc == 1 && o.kkt) {
+            }
+            if (!found) {
+                // exhaustive fallback: patterns with 0, 1, 2 fixed variables; first KKT pattern,
+                // failing that (rounding) the feasible one of least value
+                double bestq = INFINITY;
+                for (int ip = 0; ip < 19; ++ip) {
+                    const int p = c_pat_order[ip];
+                    if (qp_pattern(p, H, gp, a, e, lo, hi, o) == 1) {
+                        if (o.kkt || o.q < bestq) {
+                            bestq = o.q;
                             found = true;
                             pat = p;
                             d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
                             lam_new = o.lam;
-                            break;
                         }
-                        p = o.next;
+                        if (o.kkt) break;
                     }
                 }
-                if (!found) {
-                    // patterns with 0, 1, 2 fixed variables; the first KKT pattern of a convex
-                    // QP is its minimiser, otherwise the feasible pattern of least value
-                    double bestq = INFINITY;
-                    for (int ip = 0; ip < 19; ++ip) {
-                        const int p = c_pat_order[ip];
-                        if (qp_pattern(p, H, gp, a, e, lo, hi, o) == 1) {
-                            const bool kkt = o.kkt && convex;
-                            if (kkt || o.q < bestq) {
-                                bestq = o.q;
-                                found = true;
-                                pat = p;
-                                d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
-                                lam_new = o.lam;
-                            }
-                            if (kkt) break;
-                        }
-                    }
-                }
-                if (!found) {
-                    if (use_exact) { use_exact = false; continue; }
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        d[i] = (e > 0.0) ? ((a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0))
-                                         : ((a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0));
-                    corner = true;
-                }
-#pragma unroll
-                for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
             }
+            if (!found) {   // numerically degenerate: corner move towards feasibility
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    d[i] = (e > 0.0) ? ((a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0))
+                                     : ((a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0));
+                corner = true;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
+        }
+        {
             const double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
-            alpha = 1.0;
-            if (!(dmax > R2S_ISO_TOL)) {
+            if (!(dmax > R2S_ISO_TOL)) {   // converged (or stuck at an infeasible corner)
                 stop = corner ? 2 : 1;
-                break;
-            }
-            const double ad = a[0] * d[0] + a[1] * d[1] + a[2] * d[2];
-            const double pred_c = fabs(c) - fabs(c + ad);
-            const double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
-            double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
-            if (!(gd - mu_t * pred_c < 0.0)) {
-                if (pred_c > 0.0) {
-                    mu_t = 2.0 * gd / pred_c;
-                } else if (use_exact && !corner) {
-                    use_exact = false;
-                    continue;
-                } else {
-                    stop = 2;
-                    break;
+            } else {
+                const double ad = a[0] * d[0] + a[1] * d[1] + a[2] * d[2];
+                const double pred_c = fabs(c) - fabs(c + ad);
+                const double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+                double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
+                if (!(gd - mu_t * pred_c < 0.0)) {
+                    if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
+                    else stop = 2;   // no descent on the merit function
+                }
+                if (!stop) {
+                    mu = mu_t;
+                    const double D = gd - mu * pred_c;
+                    const double phi0 = f + mu * fabs(c);
+                    for (int ls = 0; ls < 30; ++ls) {
+                        double xt[3], ft, ct;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
+                        iso_eval_fc(E, x, rt, xt, ft, ct);
+                        if (ft + mu * fabs(ct) <= phi0 + 1e-4 * alpha * D) break;
+                        alpha *= 0.5;
+                    }
                 }
             }
-            mu = mu_t;
-            const double D = gd - mu * pred_c;
-            const double phi0 = f + mu * fabs(c);
-            for (int ls = 0; ls < 30; ++ls) {
-                double xt[3], ft, ct;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
-                iso_eval_fc(E, x, rt, xt, ft, ct);
-                if (ft + mu * fabs(ct) <= phi0 + 1e-4 * alpha * D) break;
-                alpha *= 0.5;
-            }
-            break;
         }
         {
             const double dm = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
@@ -620,11 +632,16 @@ R2S_DEV void process_triangle(VoxState& s, const BandItem& T, const Rec& E, doub
 }
 
 // iso-surface candidate of one voxel (process_isocontour_element!, :612-623)
-R2S_DEV double iso_candidate(const ElemRec& E, double rt, const double x[3], double xp[3])
+R2S_DEV double iso_candidate(const ElemRec& E0, double rt, const double x[3], double xp[3])
 {
     double xi[3], N[8];
-    iso_project_hex8(E, x, rt, xi);
+    iso_project_hex8(E0, x, rt, xi);
     hex8_shape(xi, N);
+    // the nodal coordinates are only needed now: hide the (wave-uniform) pointer from the optimiser so
+    // their scalar loads are issued here instead of occupying 48 SGPRs during the whole solve
+    const ElemRec* Ep = &E0;
+    asm volatile("" : "+s"(Ep));
+    const ElemRec& E = *Ep;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         double t = 0.0;

@@ -158,7 +158,7 @@ struct HexT {
     using Rec = ElemRec;
     static constexpr int NEN = 8, NES = 6, NSN = 4;
     static __device__ __forceinline__ int face(int sg, int a) { return c_hex_isn[sg][a]; }
-    static __device__ __forceinline__ void finish(Rec&, const GridDev&) {}
+    static __device__ __forceinline__ void finish(Rec& R, const GridDev&) { hex8_monomials(R); }
 };
 struct TetT {
     using Rec = TetRec;
