@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--cpu-stride", type=int, default=16, help="CPU baseline samples every n-th Z plane")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare the sampled planes with the oracle")
+    ap.add_argument("--partition", choices=["interleaved", "contiguous"], default="interleaved",
+                    help="Z partition across GPUs (N > 1): interleaved 4-plane tile layers (balanced) or slabs")
     args = ap.parse_args()
 
     import torch
@@ -88,18 +90,19 @@ def main():
     ngp = grid.ngp
     dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rho_n))
     from rho2sdf_jl_amd import slabs
-    sg = slabs.SlabGather((nx, ny, nz), rank, world, dev)             # in-place all-gather buffer
-    k0, k1 = sg.k0, sg.k1
+    sg = slabs.SlabGather((nx, ny, nz), rank, world, dev,             # in-place all-gather buffer
+                          interleaved=(args.partition == "interleaved"))
     plane = sg.plane
-    gathered = sg.gathered
     plan = pkg.DevicePlan(local_rank)
     stats_acc = []
 
-    def compute_slab(a, b, out):
-        return plan.run(dX, dI, dR, rho_t, grid, k_begin=a, k_end=b, sdf=out)
+    def compute_slab(a, b, out, zstride, zphase):
+        return plan.run(dX, dI, dR, rho_t, grid, k_begin=a, k_end=b, sdf=out, zstride=zstride, zphase=zphase)
 
     def step():
-        return slabs.run_step(sg, compute_slab)
+        st = slabs.run_step(sg, compute_slab)
+        sg.volume()          # interleaved partition: put the gathered tile layers back in lattice order
+        return st
 
     def sync():
         if world > 1:
@@ -125,11 +128,19 @@ def main():
         sts = [s for s in stats_acc if s]
         avg = {k: float(np.mean([s[k] for s in sts])) for k in ("ms_prep", "ms_bins", "ms_fill", "ms_main", "ms_gather", "ms_sign")}
         st0 = sts[-1]
-        nvox_rank = (k1 - k0) * plane
+        nvox_rank = sg.my_planes * plane
         mesh_bytes = X.nbytes + IEN.nbytes + rho_n.nbytes
         alg_bytes = ALG_BYTES_PER_VOXEL * nvox_rank + mesh_bytes
         main_s = avg["ms_main"] * 1e-3
         achieved = alg_bytes / main_s / 1e9 if main_s > 0 else 0.0
+        # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are
+        # collected in separate rocprofv3 runs - tools/collect_traffic.py); only valid for the default workload
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tfile) and args.grid == 512 and args.mesh == 46 and world == 1:
+            k = json.load(open(tfile))["kernels"].get("iso_project_kernel<r2s::ElemRec>")
+            if k and k.get("FETCH_SIZE_KB") is not None and k.get("WRITE_SIZE_KB") is not None:
+                traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
         out = {
             "metric": "Mvoxels/s SDF extract on 512^3 grid over 100k HEX8; max|err| vs ref",
             "value": value, "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -138,10 +149,10 @@ def main():
             "config": {"workload": f"NS: synthetic jittered HEX8 {args.mesh}^3 = {len(IEN)} elements, "
                                    f"{nx}x{ny}x{nz} grid (N_max={n_max}), rho_t=0.5, band factor 1.1, "
                                    f"fused dist*sign, Z-slabs over {world} GPU(s)",
-                       "elements": int(len(IEN)), "voxels": int(ngp), "parallelism": f"zslab{world}"},
-            "roofline": {"bound": "hbm", "kernel": "iso_project_kernel",
+                       "elements": int(len(IEN)), "voxels": int(ngp), "parallelism": f"z-{args.partition if world > 1 else 'whole'}-{world}"},
+            "roofline": {"bound": "hbm", "kernel": "iso_project_kernel<r2s::ElemRec>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["ms_main"],
                          "note": "FP64-VALU/latency-bound kernel (SURVEY.md 0.7); algorithmic bytes = 8 B/voxel "
                                  "of the slab + mesh bytes; see DESIGN.md"},
@@ -155,7 +166,7 @@ def main():
             cb, ref = cpu_baseline(X, IEN, rho_n, rho_t, n_max, args.cpu_stride)
             out["cpu_baseline"] = cb
             if args.check:
-                got = gathered[:ngp].view(nz, ny, nx)[::args.cpu_stride].cpu().numpy().ravel()
+                got = sg.volume()[::args.cpu_stride].cpu().numpy().ravel()
                 want = ref.reshape(nz, ny, nx)[::args.cpu_stride].ravel()
                 sent = np.abs(want) > 1e9
                 real = ~sent

@@ -56,7 +56,13 @@ typedef struct {
     double band_factor; /* 1.1  : delta = band_factor*cell_size (sdfOnDensityField.jl:158) */
     int32_t elem_type;  /* R2S_HEX8 / R2S_TET4 (Rho2sdfOptions.element_type, RhoToSDF.jl:20) */
     int32_t device;     /* HIP device ordinal, -1 = current device */
-    int32_t reserved[4];
+    /* multi-GPU Z partition of r2s_plan_run_dev: zstride <= 1 -> contiguous planes [k_begin,k_end);
+     * zstride = G > 1 -> this call computes the 4-plane tile layers t with t % G == zphase of the whole
+     * grid (k_begin = 0, k_end = N3+1) and stores them consecutively: local plane 4*i+l holds lattice
+     * plane 4*(i*G + zphase) + l; the output then has 4*ceil((layers - zphase)/G) planes. */
+    int32_t zstride;
+    int32_t zphase;
+    int32_t reserved[2];
 } r2s_params;
 
 /* per-call counters (optional; pass NULL) */

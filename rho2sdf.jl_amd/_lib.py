@@ -22,7 +22,8 @@ class R2SGrid(ctypes.Structure):
 
 class R2SParams(ctypes.Structure):
     _fields_ = [("band_factor", ctypes.c_double), ("elem_type", ctypes.c_int32),
-                ("device", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+                ("device", ctypes.c_int32), ("zstride", ctypes.c_int32), ("zphase", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2)]
 
 
 class R2SStats(ctypes.Structure):

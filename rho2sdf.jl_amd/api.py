@@ -157,8 +157,12 @@ class DevicePlan:
             pass
 
     def run(self, dX, dIEN, d_rho_n, rho_t, grid, *, k_begin=0, k_end=None, band_factor=1.1,
-            elem_type=L.HEX8, dist=None, sign=None, sdf=None, xp=None, stream=None):
+            elem_type=None, dist=None, sign=None, sdf=None, xp=None, stream=None, zstride=1, zphase=0):
+        """one pass over planes [k_begin, k_end) (zstride <= 1) or over the interleaved tile layers
+        t % zstride == zphase of the whole grid (see r2s_params in include/rho2sdf_hip.h)"""
         import torch
+        if elem_type is None:
+            elem_type = L.HEX8 if dIEN.shape[1] == 8 else L.TET4
         k_end = int(grid.c.N[2]) + 1 if k_end is None else int(k_end)
         for t, dt in ((dX, torch.float64), (dIEN, torch.int64), (d_rho_n, torch.float64)):
             assert t.is_cuda and t.is_contiguous() and t.dtype == dt
@@ -175,6 +179,8 @@ class DevicePlan:
         L.lib().r2s_default_params(ctypes.byref(p))
         p.band_factor = float(band_factor)
         p.elem_type = int(elem_type)
+        p.zstride = int(zstride)
+        p.zphase = int(zphase)
         st = L.R2SStats()
         s = ctypes.c_void_p(stream.cuda_stream if stream is not None
                             else torch.cuda.current_stream().cuda_stream)

@@ -121,11 +121,44 @@ __global__ void ine_fill_kernel(const int64_t* __restrict__ IEN, int64_t nel, in
 #define CLS_SOLID 1
 #define CLS_ISO 2
 
+// The part of the grid one call (one rank) computes, as LOCAL planes 0..nzl-1:
+//   contiguous  (G == 1): local plane kl = lattice plane k0 + kl, planes [k0,k1)
+//   interleaved (G  > 1): the rank owns the 4-plane tile layers tz with tz % G == r of the whole grid;
+//                         local layer t = global layer t*G + r (balanced work for the Z-slab all-gather)
 struct SlabInfo {
-    int32_t k0, k1;          // lattice planes [k0,k1)
-    int32_t ntx, nty, ntz;   // tiles
+    int32_t k0, k1;          // lattice planes [k0,k1) (whole grid when interleaved)
+    int32_t ntx, nty, ntz;   // local tiles
     int32_t ntiles;
+    int32_t G, r;            // interleave stride / phase
+    int32_t nzl;             // local planes
 };
+
+__host__ __device__ __forceinline__ int slab_global_k(const SlabInfo& s, int kl)
+{
+    return s.G == 1 ? kl + s.k0 : ((kl >> 2) * s.G + s.r) * 4 + (kl & 3);
+}
+
+// lattice planes [a,b] (inclusive) -> local planes [la,lb]; false if the slab holds none of them
+__host__ __device__ __forceinline__ bool slab_local_range(const SlabInfo& s, int a, int b, int& la, int& lb)
+{
+    if (a < s.k0) a = s.k0;
+    if (b >= s.k1) b = s.k1 - 1;
+    if (a > b) return false;
+    if (s.G == 1) {
+        la = a - s.k0;
+        lb = b - s.k0;
+        return true;
+    }
+    const int layer_a = a >> 2, layer_b = b >> 2;
+    int ta = layer_a - s.r, tb = layer_b - s.r;
+    ta = ta <= 0 ? 0 : (ta + s.G - 1) / s.G;          // first owned layer >= layer_a
+    if (tb < 0) return false;
+    tb = tb / s.G;                                      // last owned layer <= layer_b
+    if (ta > tb) return false;
+    la = 4 * ta + ((ta * s.G + s.r == layer_a) ? (a & 3) : 0);
+    lb = 4 * tb + ((tb * s.G + s.r == layer_b) ? (b & 3) : 3);
+    return la <= lb;
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -397,9 +430,10 @@ __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, con
                 // to the lattice indices whose cell really lies in [imin,imax]
                 if ((int)cell_of(g, ax, grid_coord(g, ax, a)) < T.imin[ax]) a += 1;
                 if ((int)cell_of(g, ax, grid_coord(g, ax, b)) > T.imax[ax]) b -= 1;
-                if (ax == 2) {
-                    if (a < sl.k0) a = sl.k0;
-                    if (b >= sl.k1) b = sl.k1 - 1;
+                if (ax == 2) {   // Z in LOCAL planes of the slab
+                    int la, lb;
+                    if (a <= b && slab_local_range(sl, a, b, la, lb)) { a = la; b = lb; }
+                    else { a = 0; b = -1; }
                 }
             }
             T.lo[ax] = a;
@@ -425,10 +459,12 @@ __global__ void item_chunks_kernel(BandItem* __restrict__ items, const uint32_t*
 // requested, `res_xp`; the ordered per-voxel gather (sdf_tiles_kernel) consumes them in the
 // reference's element order, so the strict-'<' update semantics are unchanged.
 template <class Rec>
-__global__ void __launch_bounds__(256, 3) /* 3 waves/SIMD (<=168 VGPRs): measured best */ iso_project_kernel(const BandItem* __restrict__ items, uint32_t nitems,
+// 205 VGPRs -> 2 waves/SIMD, no scratch.  Forcing 3 waves/SIMD (168 VGPRs) is 2.5 % faster but spills
+// 156 B/lane, i.e. ~2.8 GB of scratch traffic per launch against 0.17 GB of algorithmic writes.
+__global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __restrict__ items, uint32_t nitems,
                                                          const uint32_t* __restrict__ chunk_off,
                                                          uint32_t nchunks, const Rec* __restrict__ erec,
-                                                         GridDev g, double rho_t, double* __restrict__ res,
+                                                         GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
                                                          double* __restrict__ res_xp)
 {
     const uint32_t c = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -449,7 +485,7 @@ __global__ void __launch_bounds__(256, 3) /* 3 waves/SIMD (<=168 VGPRs): measure
     double x[3];
     x[0] = grid_coord(g, 0, T.lo[0] + li);
     x[1] = grid_coord(g, 1, T.lo[1] + lj);
-    x[2] = grid_coord(g, 2, T.lo[2] + lk);
+    x[2] = grid_coord(g, 2, slab_global_k(sl, T.lo[2] + lk));   // T.lo[2] is a local plane
     const int ci = (int)cell_of(g, 0, x[0]), cj = (int)cell_of(g, 1, x[1]), ck = (int)cell_of(g, 2, x[2]);
     const bool in = ci >= T.imin[0] && ci <= T.imax[0] && cj >= T.imin[1] && cj <= T.imax[1] &&
                     ck >= T.imin[2] && ck <= T.imax[2];
@@ -480,9 +516,10 @@ __device__ __forceinline__ bool band_tile_range(const BandItem& T, const GridDev
         if (a > b || a > nmax[ax]) return false;
         b = (b >= nmax[ax]) ? nmax[ax] : b + 1;
         if (ax == 2) {
-            if (b < s.k0 || a >= s.k1) return false;
-            a = (a < s.k0 ? s.k0 : a) - s.k0;
-            b = (b >= s.k1 ? s.k1 - 1 : b) - s.k0;
+            int la, lb;
+            if (!slab_local_range(s, a, b, la, lb)) return false;
+            a = la;
+            b = lb;
         }
         lo[ax] = a >> 2;
         hi[ax] = b >> 2;
@@ -503,9 +540,10 @@ __device__ __forceinline__ bool sign_tile_range(const ElemRec& E, const GridDev&
         int a = (fa < 0.0) ? 0 : (int)fa;
         int b = (fb > (double)nmax[ax]) ? nmax[ax] : (int)fb;
         if (ax == 2) {
-            if (b < s.k0 || a >= s.k1) return false;
-            a = (a < s.k0 ? s.k0 : a) - s.k0;
-            b = (b >= s.k1 ? s.k1 - 1 : b) - s.k0;
+            int la, lb;
+            if (!slab_local_range(s, a, b, la, lb)) return false;
+            a = la;
+            b = lb;
         }
         lo[ax] = a >> 2;
         hi[ax] = b >> 2;
@@ -527,9 +565,10 @@ __device__ __forceinline__ bool sign_tile_range(const TetRec& E, const GridDev& 
         if (b > nmax[ax]) b = nmax[ax];
         if (a > b) return false;
         if (ax == 2) {
-            if (b < s.k0 || a >= s.k1) return false;
-            a = (a < s.k0 ? s.k0 : a) - s.k0;
-            b = (b >= s.k1 ? s.k1 - 1 : b) - s.k0;
+            int la, lb;
+            if (!slab_local_range(s, a, b, la, lb)) return false;
+            a = la;
+            b = lb;
         }
         lo[ax] = a >> 2;
         hi[ax] = b >> 2;
@@ -696,8 +735,8 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
     const uint32_t t = A.active[w];
     const int tx = t % A.s.ntx, ty = (t / A.s.ntx) % A.s.nty, tz = t / (A.s.ntx * A.s.nty);
     const int i = tx * 4 + (lane & 3), j = ty * 4 + ((lane >> 2) & 3), kl = tz * 4 + (lane >> 4);
-    const int k = kl + A.s.k0;
-    const bool valid = (i < A.g.nx) && (j < A.g.ny) && (k < A.s.k1);
+    const int k = slab_global_k(A.s, kl);
+    const bool valid = (i < A.g.nx) && (j < A.g.ny) && (kl < A.s.nzl) && (k < A.s.k1);
     double x[3];
     x[0] = grid_coord(A.g, 0, i);
     x[1] = grid_coord(A.g, 1, j);
@@ -719,7 +758,7 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                 if (T.kind == 0) {
                     // WriteValue of the pre-computed iso candidate (sdfOnDensityField.jl:617-621)
                     const size_t slot = (size_t)T.chunk_off * 64u +
-                                        ((size_t)(k - T.lo[2]) * T.dim[1] + (j - T.lo[1])) * T.dim[0] + (i - T.lo[0]);
+                                        ((size_t)(kl - T.lo[2]) * T.dim[1] + (j - T.lo[1])) * T.dim[0] + (i - T.lo[0]);
                     const double d = A.iso_res[slot];
                     if (fabs(d) < st.cur) {
                         st.cur = d;
@@ -998,12 +1037,25 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     g.nx = g.N[0] + 1; g.ny = g.N[1] + 1; g.nz = g.N[2] + 1;
     SlabInfo s;
     s.k0 = (int32_t)k_begin; s.k1 = (int32_t)k_end;
-    s.ntx = (g.nx + 3) / 4; s.nty = (g.ny + 3) / 4; s.ntz = (int32_t)((k_end - k_begin + 3) / 4);
+    s.G = prm.zstride > 1 ? prm.zstride : 1;
+    s.r = prm.zstride > 1 ? prm.zphase : 0;
+    if (s.G > 1) {
+        // interleaved tile layers over the whole grid (balanced Z partition for the all-gather)
+        if (k_begin != 0 || k_end != g.nz) return fail(R2S_ERR_ARG, "zstride > 1 needs the full Z range [0, N3+1)");
+        if (s.r < 0 || s.r >= s.G) return fail(R2S_ERR_ARG, "zphase %d not in [0, zstride=%d)", s.r, s.G);
+        const int layers = (g.nz + 3) / 4;
+        const int owned = layers > s.r ? (layers - s.r + s.G - 1) / s.G : 0;
+        if (owned == 0) return fail(R2S_ERR_ARG, "this rank owns no tile layer (grid has %d, zstride %d)", layers, s.G);
+        s.nzl = 4 * owned;
+    } else {
+        s.nzl = (int32_t)(k_end - k_begin);
+    }
+    s.ntx = (g.nx + 3) / 4; s.nty = (g.ny + 3) / 4; s.ntz = (s.nzl + 3) / 4;
     const int64_t ntiles64 = (int64_t)s.ntx * s.nty * s.ntz;
     if (ntiles64 >= ((int64_t)1 << 31)) return fail(R2S_ERR_ARG, "slab too large");
     s.ntiles = (int32_t)ntiles64;
     const uint32_t ntiles = (uint32_t)s.ntiles;
-    const int64_t nvox = (k_end - k_begin) * (int64_t)g.nx * g.ny;
+    const int64_t nvox = (int64_t)s.nzl * g.nx * g.ny;   // output voxels of this call (local planes)
     const double delta = prm.band_factor * g.cell;  // sdfOnDensityField.jl:158
 
     // ---- workspace ----
@@ -1138,7 +1190,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         if (want_dist && n_chunks)
             iso_project_kernel<typename ET::Rec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
                 P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
-                rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+                s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
         HIP_TRY(hipEventRecord(P->ev[6], st));
         if (want_dist && n_active) {
             A.active = P->active.as<uint32_t>(); A.n_active = n_active;

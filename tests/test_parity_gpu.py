@@ -163,3 +163,29 @@ def test_tet4_solid_boundary(pkg, oracle):
     pg = pkg.Grid(X.min(0), X.max(0), 24, 3)
     og = oracle.grid_make(X.min(0), X.max(0), 24, 3)
     _compare(pkg, oracle, X, IT, rn, 0.05, pg, og, 1.1, "tet4 solid boundary")
+
+
+@pytest.mark.parametrize("dims_n", [40, 37])
+def test_interleaved_layers_equal_full_volume(pkg, oracle, dims_n):
+    """the balanced multi-GPU partition (4-plane tile layers dealt round-robin, r2s_params.zstride/zphase):
+    all ranks' parts, gathered and reordered exactly as bench.py does, == one full-volume run"""
+    import torch
+    from rho2sdf_jl_amd import slabs, synthetic
+    X, IEN, rn = synthetic.hex_mesh(8)
+    pg = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(dims_n), 3)
+    dev = torch.device("cuda:0")
+    dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rn))
+    plan = pkg.DevicePlan(0)
+    nx, ny, nz = pg.dims
+    full = torch.empty(nz * ny * nx, dtype=torch.float64, device=dev)
+    plan.run(dX, dI, dR, 0.5, pg, sdf=full)
+    for world in (2, 3, 8):
+        sgs = [slabs.SlabGather((nx, ny, nz), r, world, dev, interleaved=True) for r in range(world)]
+        for r, sg in enumerate(sgs):
+            if sg.my_planes:
+                plan.run(dX, dI, dR, 0.5, pg, sdf=sg.my_slab, zstride=world, zphase=r)
+        # emulate the all-gather: every rank's `mine` into rank 0's buffer
+        for r, sg in enumerate(sgs[1:], start=1):
+            sgs[0].gathered[r * sgs[0].per * sgs[0].plane:(r + 1) * sgs[0].per * sgs[0].plane].copy_(sg.mine)
+        assert torch.equal(sgs[0].volume().reshape(-1), full), f"{world} interleaved parts differ from the full volume"
+    plan.close()

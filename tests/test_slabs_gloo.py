@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, load_fixture
 
 
-def _worker(rank, world, port, ref_path, dims):
+def _worker(rank, world, port, ref_path, dims, interleaved):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -22,11 +22,21 @@ def _worker(rank, world, port, ref_path, dims):
     graft.load_package()
     from rho2sdf_jl_amd import slabs
     ref = torch.from_numpy(np.load(ref_path))
-    sg = slabs.SlabGather(dims, rank, world, torch.device("cpu"))
+    sg = slabs.SlabGather(dims, rank, world, torch.device("cpu"), interleaved=interleaved)
     plane = dims[0] * dims[1]
+    nz = dims[2]
 
-    def compute_slab(k0, k1, out):
-        out.copy_(ref[k0 * plane:k1 * plane])
+    def compute_slab(k0, k1, out, zstride, zphase):
+        if zstride == 1:
+            out.copy_(ref[k0 * plane:k1 * plane])
+        else:   # what r2s_plan_run_dev(zstride, zphase) returns: the owned 4-plane layers, consecutively
+            o = out.view(-1, plane)
+            o.fill_(float("nan"))
+            for i in range(o.shape[0] // 4):
+                for l in range(4):
+                    k = 4 * (i * zstride + zphase) + l
+                    if k < nz:
+                        o[4 * i + l] = ref[k * plane:(k + 1) * plane]
 
     slabs.run_step(sg, compute_slab)
     ok = torch.equal(sg.volume().reshape(-1), ref)
@@ -37,8 +47,9 @@ def _worker(rank, world, port, ref_path, dims):
         raise SystemExit(3)
 
 
+@pytest.mark.parametrize("interleaved", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_zslab_allgather(oracle, tmp_path, world):
+def test_zslab_allgather(oracle, tmp_path, world, interleaved):
     X, IEN, rho = load_fixture("sphere")
     rn = oracle.dense_in_nodes(X, IEN, rho)
     g = oracle.grid_make(X.min(0), X.max(0), 10)          # 17 planes: not divisible by 2 or 3
@@ -47,7 +58,7 @@ def test_zslab_allgather(oracle, tmp_path, world):
     ref_path = str(tmp_path / "ref.npy")
     np.save(ref_path, sdf)
     port = 29500 + (os.getpid() % 500) + world
-    mp.spawn(_worker, args=(world, port, ref_path, g.dims), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port + (10 if interleaved else 0), ref_path, g.dims, interleaved), nprocs=world, join=True)
 
 
 def test_slab_bounds():
@@ -61,3 +72,6 @@ def test_slab_bounds():
     assert per == 65 and b[3] == (195, 257)
     per, b = slabs.slab_bounds(5, 8)
     assert per == 1 and b[4] == (4, 5) and b[5] == (5, 5) and b[7] == (5, 5)
+    assert slabs.interleaved_layers(512, 8, 3) == (16, 16)
+    assert slabs.interleaved_layers(257, 4, 0) == (17, 17) and slabs.interleaved_layers(257, 4, 1) == (16, 17)
+    assert slabs.interleaved_layers(17, 8, 5) == (0, 1)
