@@ -68,13 +68,21 @@ __global__ void ccl_flatten_count_kernel(const uint32_t* __restrict__ L, uint32_
                                          uint32_t* __restrict__ size)
 {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    uint32_t r = L[v];
-    if (r != NOLABEL) {
+    uint32_t r = (v < n) ? L[v] : NOLABEL;
+    if (r != NOLABEL)
         while (L[r] != r) r = L[r];
-        atomicAdd(&size[r], 1u);
+    if (v < n) root[v] = r;
+    // most lanes of a wavefront share a root (one big component): one atomic per distinct root and wave
+    bool pending = r != NOLABEL;
+    const int lane = threadIdx.x & 63;
+    while (__any(pending)) {
+        const unsigned long long todo = __ballot(pending);
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lr = __shfl(r, leader, 64);
+        const unsigned long long same = __ballot(pending && r == lr);
+        if (lane == leader) atomicAdd(&size[lr], (uint32_t)__popcll(same));
+        if (r == lr) pending = false;
     }
-    root[v] = r;
 }
 
 // counters: [0] largest size, [1] smallest root having it, [2] flipped count, [3] interior count
@@ -265,6 +273,83 @@ __global__ void __launch_bounds__(256) sum_f32_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) *out = red[0];
 }
 
+// Row version: one workgroup per (j,k) row of cells, threads along x (coalesced corner loads, no
+// integer division).  Full cells are summed per thread; cut cells are listed in LDS in x order and
+// then worked off one WAVEFRONT per cell (lanes split the order^3 Gauss points), so a few cut cells
+// do not stall 63 idle lanes for 729 iterations.  Every reduction has a fixed order (no float atomics).
+__global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restrict__ sdf, int nx, int ny, int nz,
+                                                         float shift, float iso, float elvol, float jac,
+                                                         QuadTab q, float* __restrict__ partial)
+{
+    __shared__ float red[256];
+    __shared__ int s_flag[256];
+    __shared__ int s_cut[256];
+    __shared__ int s_ncut;
+    const int row = blockIdx.x;
+    const int j = row % (ny - 1), k = row / (ny - 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t sy = nx, sz = (int64_t)nx * ny;
+    const int npts = q.order * q.order * q.order;
+    float acc = 0.0f;    // full cells (per thread)
+    float wacc = 0.0f;   // cut cells (lane 0 of each wave)
+    for (int i0 = 0; i0 < nx - 1; i0 += 256) {
+        const int i = i0 + tid;
+        int cls = 0;
+        if (i < nx - 1) {
+            const int64_t b = ((int64_t)k * ny + j) * nx + i;
+            const float c000 = sdf[b] - shift, c100 = sdf[b + 1] - shift, c010 = sdf[b + sy] - shift,
+                        c110 = sdf[b + sy + 1] - shift, c001 = sdf[b + sz] - shift, c101 = sdf[b + sz + 1] - shift,
+                        c011 = sdf[b + sz + sy] - shift, c111 = sdf[b + sz + sy + 1] - shift;
+            const float mn = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111)));
+            const float mx = fmaxf(fmaxf(fmaxf(c000, c100), fmaxf(c010, c110)), fmaxf(fmaxf(c001, c101), fmaxf(c011, c111)));
+            if (!(mx < iso)) {
+                if (mn >= iso) acc += elvol;
+                else cls = 1;
+            }
+        }
+        s_flag[tid] = cls;
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int t = 0; t < 256; ++t)
+                if (s_flag[t]) s_cut[n++] = i0 + t;
+            s_ncut = n;
+        }
+        __syncthreads();
+        const int ncut = s_ncut;
+        for (int c = wave; c < ncut; c += 4) {
+            const int64_t b = ((int64_t)k * ny + j) * nx + s_cut[c];
+            const float c000 = sdf[b] - shift, c100 = sdf[b + 1] - shift, c010 = sdf[b + sy] - shift,
+                        c110 = sdf[b + sy + 1] - shift, c001 = sdf[b + sz] - shift, c101 = sdf[b + sz + 1] - shift,
+                        c011 = sdf[b + sz + sy] - shift, c111 = sdf[b + sz + sy + 1] - shift;
+            float part = 0.0f;
+            for (int p = lane; p < npts; p += 64) {
+                const int iq = p % q.order, jq = (p / q.order) % q.order, kq = p / (q.order * q.order);
+                const float zeta = (q.gp[kq] + 1) / 2, eta = (q.gp[jq] + 1) / 2, xi = (q.gp[iq] + 1) / 2;
+                const float c00 = c000 * (1.0f - xi) + c100 * xi;
+                const float c01 = c001 * (1.0f - xi) + c101 * xi;
+                const float c10 = c010 * (1.0f - xi) + c110 * xi;
+                const float c11 = c011 * (1.0f - xi) + c111 * xi;
+                const float c0 = c00 * (1.0f - eta) + c10 * eta;
+                const float c1 = c01 * (1.0f - eta) + c11 * eta;
+                const float pv = c0 * (1.0f - zeta) + c1 * zeta;
+                if (pv >= iso) part += q.gw[iq] * q.gw[jq] * q.gw[kq] * jac;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (lane == 0) wacc += part;
+        }
+        __syncthreads();
+    }
+    red[tid] = acc + wacc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) partial[row] = red[0];
+}
+
 struct VolumeWork {
     DevBuf partial, result;
     QuadTab q;
@@ -285,8 +370,10 @@ struct VolumeWork {
     {
         const float elvol = edge * edge * edge;       // element_edge_length^3 (:40)
         const float jac = elvol / 8.0f;               // :51
-        volume_cells_kernel<<<nblocks, 256, 0, st>>>(d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>());
-        sum_f32_kernel<<<1, 256, 0, st>>>(partial.as<float>(), nblocks, result.as<float>());
+        const int nrows = (ny - 1) * (nz - 1);
+        ENSURE(partial, sizeof(float) * (size_t)nrows);
+        volume_rows_kernel<<<nrows, 256, 0, st>>>(d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>());
+        sum_f32_kernel<<<1, 256, 0, st>>>(partial.as<float>(), nrows, result.as<float>());
         HIP_TRY(hipMemcpyAsync(out, result.p, sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         return 0;
@@ -304,15 +391,18 @@ struct Stencil {
     signed char off[512][3];
 };
 
-static void build_stencil(int s, const int frac[3], Stencil* st)
+static void build_stencil(int s, const int frac[3], Stencil* st, double R2)
 {
+    // candidates: lattice distance^2 (in 1/s cells) up to 5 % beyond the support radius; the run-time
+    // `dist <= max_distance` test (RBFs4Smoothing.jl:240) decides
+    const int d2max = (int)std::floor(R2 * 1.05 * s * s + 0.25);
     int cand[512][4], n = 0;
     for (int dz = -3; dz <= 4; ++dz)
         for (int dy = -3; dy <= 4; ++dy)
             for (int dx = -3; dx <= 4; ++dx) {
                 const int ex = dx * s - frac[0], ey = dy * s - frac[1], ez = dz * s - frac[2];
                 const int d2 = ex * ex + ey * ey + ez * ez;
-                if (d2 > 9 * s * s) continue;
+                if (d2 > d2max) continue;
                 cand[n][0] = d2; cand[n][1] = dz; cand[n][2] = dy; cand[n][3] = dx;
                 n++;
             }
@@ -337,6 +427,7 @@ struct RbfGeom {
     double sigma;
     float max_distance;
     double thr;
+    int tap_r, tap_d2;       // stencil radius / largest lattice distance^2 that can reach the threshold
 };
 
 // rbf_interpolation_kdtree (:219-248): 1 thread / target point
@@ -376,9 +467,12 @@ __global__ void __launch_bounds__(256) rbf_matvec_kernel(RbfGeom G, const float*
     const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
     const float px = G.cx[i], py = G.cy[j], pz = G.cz[k];
     float acc = 0.0f;
-    for (int ck = k - 3; ck <= k + 3; ++ck)
-        for (int cj = j - 3; cj <= j + 3; ++cj)
-            for (int ci = i - 3; ci <= i + 3; ++ci) {
+    // taps beyond lattice distance^2 = tap_d2 are far outside the kernel support (next possible value of a
+    // sum of three squares leaves a margin of > 5 % in r) and cannot pass `val > threshold`
+    for (int ck = k - G.tap_r; ck <= k + G.tap_r; ++ck)
+        for (int cj = j - G.tap_r; cj <= j + G.tap_r; ++cj)
+            for (int ci = i - G.tap_r; ci <= i + G.tap_r; ++ci) {
+                if ((ck - k) * (ck - k) + (cj - j) * (cj - j) + (ci - i) * (ci - i) > G.tap_d2) continue;
                 if (ci < 0 || cj < 0 || ck < 0 || ci >= G.nx || cj >= G.ny || ck >= G.nz) continue;
                 const float dx = px - G.cx[ci], dy = py - G.cy[cj], dz = pz - G.cz[ck];
                 const float r = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -394,12 +488,22 @@ __global__ void pv_max_kernel(const double* __restrict__ v, int64_t n, float* __
                               uint32_t* __restrict__ any)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = (float)v[i];
-    f[i] = x;
-    const float a = fabsf(x);
-    if (a < 1.0e9f) {
-        atomicMax(maxbits, __float_as_uint(a));
+    uint32_t bits = 0;
+    bool has = false;
+    if (i < n) {
+        const float x = (float)v[i];
+        f[i] = x;
+        const float a = fabsf(x);
+        if (a < 1.0e9f) { bits = __float_as_uint(a); has = true; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(bits, off, 64);
+        bits = o > bits ? o : bits;
+    }
+    const bool anyw = __any(has);
+    if ((threadIdx.x & 63) == 0 && anyw) {
+        atomicMax(maxbits, bits);
         *any = 1u;
     }
 }
@@ -461,11 +565,22 @@ __global__ void minmax_kernel(const float* __restrict__ v, int64_t n, int* __res
 {
     // order-preserving int encoding of floats
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int b = __float_as_int(v[i]);
-    b = b >= 0 ? b : (b ^ 0x7FFFFFFF);
-    atomicMin(&mm[0], b);
-    atomicMax(&mm[1], b);
+    int lo = 0x7FFFFFFF, hi = (int)0x80000000;
+    if (i < n) {
+        int b = __float_as_int(v[i]);
+        b = b >= 0 ? b : (b ^ 0x7FFFFFFF);
+        lo = hi = b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
 }
 
 static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
@@ -551,12 +666,12 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     std::vector<Stencil> sts(1 + (size_t)smooth * smooth * smooth);
     {
         int fr0[3] = {0, 0, 0};
-        build_stencil(1, fr0, &sts[0]);
+        build_stencil(1, fr0, &sts[0], -std::log(kthr));
         for (int a = 0; a < smooth; ++a)
             for (int b = 0; b < smooth; ++b)
                 for (int c = 0; c < smooth; ++c) {
                     int fr[3] = {c, b, a};
-                    build_stencil(smooth, fr, &sts[1 + (a * smooth + b) * smooth + c]);
+                    build_stencil(smooth, fr, &sts[1 + (a * smooth + b) * smooth + c], -std::log(kthr));
                 }
     }
     ENSURE_C(d_st, sizeof(Stencil) * sts.size());
@@ -567,6 +682,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     G.sigma = g->cell_size;                                                    // :346
     G.thr = kthr;
     G.max_distance = (float)std::sqrt(-std::log(kthr) * G.sigma * G.sigma);     // :221
+    {
+        const double R2 = -std::log(kthr);                 // support radius^2 in cells (sigma = cell size)
+        G.tap_d2 = (int)std::floor(R2 * 1.05 + 0.25);      // 1e-3 -> 7 (i.e. 6: 7 is not a sum of three squares)
+        G.tap_r = (int)std::floor(std::sqrt((double)G.tap_d2));
+    }
     // ---- weights ----
     int its = 0;
     if (is_interp) {   // compute_rbf_weights (:191-202): cg(K, b), IterativeSolvers 0.9.4 defaults
