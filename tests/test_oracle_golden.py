@@ -83,3 +83,22 @@ def test_sign_elementmajor_equals_literal(oracle):
             a = oracle.sign_detection(X, IEN, rn, rt, g)
             b = oracle.sign_detection(X, IEN, rn, rt, g, bruteforce=True)
             assert np.array_equal(a, b)
+
+
+def test_iso_projection_vs_independent_slsqp(oracle):
+    """compute_coords_on_iso (HEX8): the oracle's SQP against an independent Kraft SLSQP (scipy), the
+    optimiser family of the reference's NLopt LD_SLSQP, on 400 jittered elements with smooth density
+    fields (vectors + generator: tests/golden/make_slsqp_vectors.py)."""
+    import os
+    from conftest import ROOT
+    d = np.load(os.path.join(ROOT, "tests", "golden", "slsqp_iso_projection.npz"))
+    S = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float)
+    worst = 0.0
+    for x, Xe, re, rt, dist in zip(d["x"], d["Xe"], d["re"], d["rt"], d["dist"]):
+        xi, it = oracle.iso_project_hex8(x, Xe, re, float(rt))
+        assert it <= 60
+        N = 0.125 * np.prod(1 + S * xi, axis=1)
+        assert abs(re @ N - rt) < 1e-10
+        mine = np.linalg.norm(x - Xe.T @ N)
+        worst = max(worst, abs(mine - dist) / max(dist, 1e-300))
+    assert worst <= 1e-6, worst
