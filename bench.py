@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare the sampled planes with the oracle")
     ap.add_argument("--partition", choices=["interleaved", "contiguous"], default="interleaved",
                     help="Z partition across GPUs (N > 1): interleaved 4-plane tile layers (balanced) or slabs")
+    ap.add_argument("--stitch", choices=["sparse", "dense"], default="sparse",
+                    help="N > 1: all-gather only the non-sentinel 4x4x4 tiles (sparse, interleaved partition) "
+                         "or the whole Float64 volume (dense)")
     args = ap.parse_args()
 
     import torch
@@ -75,11 +78,18 @@ def main():
     pkg = graft.build()
     from rho2sdf_jl_amd import synthetic
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # R2S_BENCH_REHEARSAL=1: functional rehearsal of the N > 1 path on ONE GPU (all ranks on cuda:0, gloo);
+    # never used for reported numbers
+    rehearsal = os.environ.get("R2S_BENCH_REHEARSAL", "0") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- workload (synthetic, deterministic) ----
     X, IEN, rho_n = synthetic.hex_mesh(args.mesh)
@@ -90,10 +100,17 @@ def main():
     ngp = grid.ngp
     dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rho_n))
     from rho2sdf_jl_amd import slabs
-    sg = slabs.SlabGather((nx, ny, nz), rank, world, dev,             # in-place all-gather buffer
-                          interleaved=(args.partition == "interleaved"))
+    plan = pkg.DevicePlan(dev_index)
+
+    class TileOps:   # HIP kernels behind the sparse stitching (r2s_plan_pack_tiles_dev & co.)
+        pack = staticmethod(lambda local, payload, ids: plan.pack_tiles(local, payload, ids))
+        unpack = staticmethod(lambda payload, ids, n, vol: plan.unpack_tiles(payload, ids, n, grid, vol))
+        fill = staticmethod(lambda t, v: plan.fill(t, v))
+
+    sg = slabs.SlabGather((nx, ny, nz), rank, world, dev,
+                          interleaved=(args.partition == "interleaved"),
+                          sparse=(args.stitch == "sparse"), ops=TileOps)
     plane = sg.plane
-    plan = pkg.DevicePlan(local_rank)
     stats_acc = []
 
     def compute_slab(a, b, out, zstride, zphase):
@@ -149,7 +166,8 @@ def main():
             "config": {"workload": f"NS: synthetic jittered HEX8 {args.mesh}^3 = {len(IEN)} elements, "
                                    f"{nx}x{ny}x{nz} grid (N_max={n_max}), rho_t=0.5, band factor 1.1, "
                                    f"fused dist*sign, Z-slabs over {world} GPU(s)",
-                       "elements": int(len(IEN)), "voxels": int(ngp), "parallelism": f"z-{args.partition if world > 1 else 'whole'}-{world}"},
+                       "elements": int(len(IEN)), "voxels": int(ngp), "parallelism": (f"z-{args.partition}-{'sparse' if sg.sparse else 'dense'}-allgather-{world}"
+                                       if world > 1 else "single-gpu")},
             "roofline": {"bound": "hbm", "kernel": "iso_project_kernel<r2s::ElemRec>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -162,9 +180,10 @@ def main():
                             if avg["ms_fill"] > 0 else None},
             "work": {k: int(st0[k]) for k in ("n_items", "n_band_entries", "n_sign_entries", "n_tiles", "n_active_tiles", "n_active_sign_tiles")},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if (world == 1 and not args.no_cpu_baseline) or args.check:
             cb, ref = cpu_baseline(X, IEN, rho_n, rho_t, n_max, args.cpu_stride)
-            out["cpu_baseline"] = cb
+            if world == 1:
+                out["cpu_baseline"] = cb      # timed on rank 0 at N = 1 only
             if args.check:
                 got = sg.volume()[::args.cpu_stride].cpu().numpy().ravel()
                 want = ref.reshape(nz, ny, nx)[::args.cpu_stride].ravel()

@@ -76,6 +76,7 @@ typedef struct {
     int64_t n_active_tiles; /* tiles that ran the distance kernel          */
     int64_t n_active_sign_tiles; /* tiles that ran the sign kernel         */
     int64_t n_iso_chunks;   /* 64-voxel chunks swept by iso_project_kernel    */
+    int64_t n_any_tiles;    /* tiles that can hold non-sentinel voxels (sparse gather) */
     /* HIP-event times of the last call, measured on the call's stream: mesh prep+items,
      * tile bins, sentinel sweep, iso_project_kernel (ms_main), ordered gather
      * (sdf_tiles_kernel<dist>), sign kernel */
@@ -135,6 +136,17 @@ int r2s_plan_run_dev(r2s_plan *plan, const double *dX, int64_t nnp, const int64_
                      const r2s_params *params, int64_t k_begin, int64_t k_end, int32_t mode,
                      double *d_dist, double *d_sign, double *d_sdf, double *d_xp, void *stream,
                      r2s_stats *stats);
+
+/* ---- sparse stitching of the volume across GPUs (only non-sentinel tiles travel) ---------------
+ * After r2s_plan_run_dev with R2S_OUT_SDF on a tile-layer-aligned Z partition (zstride > 1, or k_begin a
+ * multiple of 4), pack the 4x4x4 tiles that can differ from the sentinel -1e10: 64 doubles per tile in
+ * lane order (x + 4y + 16z) + the tile id in the whole grid's tile numbering.  Receivers pre-fill their
+ * volume with the sentinel (r2s_fill_dev) and scatter every rank's tiles (r2s_unpack_tiles_dev). */
+int r2s_plan_pack_tiles_dev(r2s_plan *plan, const double *d_local_sdf, double *d_payload, uint32_t *d_ids,
+                            int64_t capacity_tiles, int64_t *n_tiles_out, void *stream);
+int r2s_unpack_tiles_dev(const double *d_payload, const uint32_t *d_ids, int64_t n_tiles, const r2s_grid *grid,
+                         double *d_volume, void *stream);
+int r2s_fill_dev(double *d, int64_t n, double value, void *stream);
 
 /* ---- pre-stage: mesh volume, nodal densities, volume-preserving threshold ------------- */
 

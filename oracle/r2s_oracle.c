@@ -276,7 +276,7 @@ static inline double tri_eval_value(const double *c, int st, const double xi[3])
 /* ------------------------------------------------------------------ */
 #define INV_MAXIT 50
 #define INV_TOL 1e-10
-static int inv_map_hex8(const double Xe[8][3], const double x[3], double xi[3])
+static int inv_map_hex8(const double Xe[16][3] /* nodes + monomials */, const double x[3], double xi[3])
 {
     xi[0] = xi[1] = xi[2] = 0.0;
     for (int it = 0; it < INV_MAXIT; ++it) {
@@ -522,7 +522,7 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
         double trG = G[0][0] + G[1][1] + G[2][2];
         double aa2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
         double sigma = 100.0 * trG / aa2;
-        int use_exact = 1, corner = 0, stop = 0;
+        int use_exact = 1, corner = 0, stop = 0; (void)use_exact;
         double lam_new = lam, alpha = 1.0;
         if (e >= mplus) {
             for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
@@ -2084,5 +2084,47 @@ int orc_sign_detection_tet4(const double *X, const int64_t *IEN, int64_t nel, co
         }
     }
     free(done); free(gidx);
+    return 0;
+}
+
+/* calculate_element_volume, TET4 (src/MeshGrid/MeshVolume.jl:75-117): cube Gauss points collapsed onto
+ * the unit tetrahedron; calculate_mesh_volume for TET4 meshes */
+int orc_mesh_volume_tet4(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_e,
+                         double *V_domain, double *V_frac)
+{
+    (void)nnp;
+    double gp[3], gw[3], dom = 0.0, to = 0.0;
+    orc_gauss_legendre(3, gp, gw);
+    for (int64_t e = 0; e < nel; ++e) {
+        double xe[4][3];
+        for (int a = 0; a < 4; ++a)
+            for (int i = 0; i < 3; ++i) xe[a][i] = X[3 * (IEN[e * 4 + a] - 1) + i];
+        /* J = xe * dN with dN rows (1,0,0),(0,1,0),(0,0,1),(-1,-1,-1) (ShapeFunctions.jl:53-72) */
+        double J[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double s = 0.0;
+                for (int a = 0; a < 4; ++a) {
+                    double dn = (a == c) ? 1.0 : ((a == 3) ? -1.0 : 0.0);
+                    s += xe[a][r] * dn;
+                }
+                J[r][c] = s;
+            }
+        double adet = fabs(det3(J)), vol = 0.0;
+        for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 3; ++i) {
+                    double xi = (gp[i] + 1.0) / 2.0;
+                    double eta = (gp[j] + 1.0) / 2.0 * (1.0 - xi);
+                    double zeta = (gp[k] + 1.0) / 2.0 * (1.0 - xi - eta);
+                    if (xi < 0 || eta < 0 || zeta < 0 || xi + eta + zeta > 1.0) continue; /* :97-99 */
+                    double jt = (1.0 - xi) * (1.0 - xi) * (1.0 - xi - eta) / 8.0;           /* :108 */
+                    vol += gw[i] * gw[j] * gw[k] * adet * jt;
+                }
+        dom += vol;
+        to += vol * rho_e[e];
+    }
+    *V_domain = dom;
+    *V_frac = to / dom;
     return 0;
 }

@@ -31,6 +31,7 @@ class R2SStats(ctypes.Structure):
                 ("n_band_entries", ctypes.c_int64), ("n_sign_entries", ctypes.c_int64),
                 ("n_tiles", ctypes.c_int64), ("n_active_tiles", ctypes.c_int64),
                 ("n_active_sign_tiles", ctypes.c_int64), ("n_iso_chunks", ctypes.c_int64),
+                ("n_any_tiles", ctypes.c_int64),
                 ("ms_prep", ctypes.c_double), ("ms_bins", ctypes.c_double),
                 ("ms_fill", ctypes.c_double), ("ms_main", ctypes.c_double),
                 ("ms_gather", ctypes.c_double), ("ms_sign", ctypes.c_double)]
@@ -60,6 +61,9 @@ SYMBOLS = [
      [_P, _P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_double, ctypes.POINTER(R2SGrid),
       ctypes.POINTER(R2SParams), ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, _P, _P, _P, _P, _P,
       ctypes.POINTER(R2SStats)]),
+    ("r2s_plan_pack_tiles_dev", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, c_int64_p, _P]),
+    ("r2s_unpack_tiles_dev", ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.POINTER(R2SGrid), _P, _P]),
+    ("r2s_fill_dev", ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_double, _P]),
     ("r2s_mesh_volume", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_int32, c_double_p, c_double_p]),
     ("r2s_dense_in_nodes", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_int32, c_double_p]),
     ("r2s_find_threshold", ctypes.c_int, _MESH + [c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int32,

@@ -191,6 +191,30 @@ class DevicePlan:
                                          ptr[0], ptr[1], ptr[2], ptr[3], s, ctypes.byref(st)))
         return st.as_dict()
 
+    # ---- sparse stitching (see include/rho2sdf_hip.h) ----
+    @staticmethod
+    def _stream(stream):
+        import torch
+        return ctypes.c_void_p(stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+
+    def pack_tiles(self, local_sdf, payload, ids, stream=None):
+        """pack the non-sentinel tiles of the last run's output into payload (n,64) f64 / ids (n,) i32"""
+        n = ctypes.c_int64()
+        L.check(L.lib().r2s_plan_pack_tiles_dev(self._h, ctypes.c_void_p(local_sdf.data_ptr()),
+                                                ctypes.c_void_p(payload.data_ptr()), ctypes.c_void_p(ids.data_ptr()),
+                                                int(ids.numel()), ctypes.byref(n), self._stream(stream)))
+        return int(n.value)
+
+    @staticmethod
+    def unpack_tiles(payload, ids, n, grid, volume, stream=None):
+        L.check(L.lib().r2s_unpack_tiles_dev(ctypes.c_void_p(payload.data_ptr()), ctypes.c_void_p(ids.data_ptr()), int(n),
+                                             ctypes.byref(grid.c), ctypes.c_void_p(volume.data_ptr()),
+                                             DevicePlan._stream(stream)))
+
+    @staticmethod
+    def fill(t, value, stream=None):
+        L.check(L.lib().r2s_fill_dev(ctypes.c_void_p(t.data_ptr()), int(t.numel()), float(value), DevicePlan._stream(stream)))
+
 
 # ---------------------------------------------------------------------------------------
 # pre-stage and post-processing (same thin marshalling; reference citations at each function)

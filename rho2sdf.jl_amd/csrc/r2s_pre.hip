@@ -88,6 +88,41 @@ __global__ void __launch_bounds__(256) elem_volume_kernel(const double* __restri
     if (lane == 0) vol[e] = acc;
 }
 
+// calculate_element_volume, TET4 (MeshVolume.jl:75-117): cube Gauss points collapsed onto the unit
+// tetrahedron.  NOTE: the reference's `jacobian_transform = (1-xi)^2 (1-xi-eta)/8` (:108) carries one
+// factor (1-xi) too many, so every TET4 volume comes out 25 % low (V_frac is unaffected); restated as is.
+__global__ void tet_volume_kernel(const double* __restrict__ X, const int64_t* __restrict__ IEN, int64_t nel,
+                                  GaussTab g3, double* __restrict__ vol)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nel) return;
+    double xe[4][3], J[3][3];
+    for (int a = 0; a < 4; ++a)
+        for (int i = 0; i < 3; ++i) xe[a][i] = X[3 * (IEN[e * 4 + a] - 1) + i];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (int a = 0; a < 4; ++a) {
+                const double dn = (a == c) ? 1.0 : ((a == 3) ? -1.0 : 0.0);
+                s += xe[a][r] * dn;
+            }
+            J[r][c] = s;
+        }
+    const double adet = fabs(det3(J));
+    double v = 0.0;
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {
+                const double xi = (g3.gp[i] + 1.0) / 2.0;
+                const double eta = (g3.gp[j] + 1.0) / 2.0 * (1.0 - xi);
+                const double zeta = (g3.gp[k] + 1.0) / 2.0 * (1.0 - xi - eta);
+                if (xi < 0 || eta < 0 || zeta < 0 || xi + eta + zeta > 1.0) continue;
+                const double jt = (1.0 - xi) * (1.0 - xi) * (1.0 - xi - eta) / 8.0;
+                v += g3.gw[i] * g3.gw[j] * g3.gw[k] * adet * jt;
+            }
+    vol[e] = v;
+}
+
 // sums v[i] and v[i]*s[i] (s may be null) in a fixed order: grid-stride partials, block tree
 __global__ void __launch_bounds__(256) sum2_kernel(const double* __restrict__ v, const double* __restrict__ s, int64_t n,
                                                   double* __restrict__ partial)
@@ -325,7 +360,8 @@ int r2s_mesh_volume(const double* X, int64_t nnp, const int64_t* IEN, int64_t ne
                     const double* rho_e, int32_t device, double* V_domain, double* V_frac)
 {
     if (!X || !IEN || !rho_e || !V_domain || !V_frac || nnp <= 0 || nel <= 0) return fail(R2S_ERR_ARG, "bad argument");
-    if (elem_type != R2S_HEX8) return fail(R2S_ERR_UNSUPPORTED, "mesh volume: HEX8 only for now");
+    if (elem_type != R2S_HEX8 && elem_type != R2S_TET4) return fail(R2S_ERR_UNSUPPORTED, "unknown element type %d", elem_type);
+    const int nen = elem_type == R2S_HEX8 ? 8 : 4;
     int rc = use_device(device);
     if (rc) return rc;
     MeshDev m;
@@ -333,13 +369,17 @@ int r2s_mesh_volume(const double* X, int64_t nnp, const int64_t* IEN, int64_t ne
     GaussTab g3, g15;
     tables(g3, g15);
     auto done = [&](int r) { m.release(); vol.release(); rho.release(); part.release(); return r; };
-    if ((rc = upload_mesh(m, X, nnp, IEN, nel, 8))) return done(rc);
+    if ((rc = upload_mesh(m, X, nnp, IEN, nel, nen))) return done(rc);
     if (vol.ensure(sizeof(double) * (size_t)nel) || rho.ensure(sizeof(double) * (size_t)nel))
         return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
     if (hipMemcpy(rho.p, rho_e, sizeof(double) * (size_t)nel, hipMemcpyHostToDevice) != hipSuccess)
         return done(fail(R2S_ERR_HIP, "hipMemcpy failed"));
-    elem_volume_kernel<<<(unsigned)((nel + 3) / 4), 256>>>(m.X.as<double>(), m.IEN.as<int64_t>(), nullptr, nel, 0, 0.0,
-                                                          g3, g15, vol.as<double>());
+    if (elem_type == R2S_HEX8)
+        elem_volume_kernel<<<(unsigned)((nel + 3) / 4), 256>>>(m.X.as<double>(), m.IEN.as<int64_t>(), nullptr, nel, 0,
+                                                              0.0, g3, g15, vol.as<double>());
+    else
+        tet_volume_kernel<<<(unsigned)((nel + 255) / 256), 256>>>(m.X.as<double>(), m.IEN.as<int64_t>(), nel, g3,
+                                                                 vol.as<double>());
     double s[2];
     if ((rc = sum2(vol.as<double>(), rho.as<double>(), nel, part, s))) return done(rc);
     *V_domain = s[0];

@@ -621,7 +621,7 @@ __global__ void active_tiles_kernel(const uint32_t* __restrict__ band_cnt,
                                     const uint32_t* __restrict__ sign_cnt,
                                     const uint8_t* __restrict__ hot, uint32_t ntiles,
                                     uint32_t* __restrict__ active_band, uint32_t* __restrict__ active_sign,
-                                    uint32_t* __restrict__ counters)
+                                    uint32_t* __restrict__ active_any, uint32_t* __restrict__ counters)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = t < ntiles;
@@ -640,6 +640,14 @@ __global__ void active_tiles_kernel(const uint32_t* __restrict__ band_cnt,
     base_s = __shfl(base_s, 0, 64);
     if (fb) active_band[base_b + __popcll(mb & below)] = t;
     if (fs) active_sign[base_s + __popcll(ms & below)] = t;
+    {   // union: every tile whose voxels can differ from the sentinel (what a sparse all-gather has to move)
+        const bool fa = fb || fs;
+        const unsigned long long ma = __ballot(fa);
+        uint32_t base_a = 0;
+        if (lane == 0 && ma) base_a = atomicAdd(&counters[5], (uint32_t)__popcll(ma));
+        base_a = __shfl(base_a, 0, 64);
+        if (fa) active_any[base_a + __popcll(ma & below)] = t;
+    }
     // longest lists (decides whether the wave-per-tile sort has to run at all)
     if (fb && band_cnt[t] > 64u) atomicMax(&counters[3], band_cnt[t]);
     if (fs && sign_cnt[t] > 64u) atomicMax(&counters[4], sign_cnt[t]);
@@ -853,13 +861,53 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
 }
 
 // ------------------------------------------------------------------------------------
+// sparse stitching of the volume across GPUs: only tiles that can differ from the sentinel travel.
+// A packed tile is 64 doubles in lane order (x + 4 y + 16 z inside the tile) plus its id in the
+// tile numbering of the WHOLE grid.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_tiles_kernel(const uint32_t* __restrict__ tiles, uint32_t n, SlabInfo s,
+                                                        GridDev g, const double* __restrict__ local, double sentinel,
+                                                        double* __restrict__ payload, uint32_t* __restrict__ ids)
+{
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= n) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = tiles[w];
+    const int tx = t % s.ntx, ty = (t / s.ntx) % s.nty, tz = t / (s.ntx * s.nty);
+    const int i = tx * 4 + (lane & 3), j = ty * 4 + ((lane >> 2) & 3), kl = tz * 4 + (lane >> 4);
+    const int k = slab_global_k(s, kl);
+    const bool valid = (i < g.nx) && (j < g.ny) && (kl < s.nzl) && (k < s.k1);
+    payload[(size_t)w * 64 + lane] = valid ? local[((int64_t)kl * g.ny + j) * g.nx + i] : sentinel;
+    if (lane == 0) ids[w] = ((uint32_t)(k >> 2) * s.nty + ty) * s.ntx + tx;   // tile layer of the whole grid
+}
+
+__global__ void __launch_bounds__(256) unpack_tiles_kernel(const double* __restrict__ payload,
+                                                          const uint32_t* __restrict__ ids, uint32_t n, int nx, int ny,
+                                                          int nz, double* __restrict__ volume)
+{
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int ntx = (nx + 3) / 4, nty = (ny + 3) / 4;
+    const uint32_t t = ids[w];
+    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+    const int i = tx * 4 + (lane & 3), j = ty * 4 + ((lane >> 2) & 3), k = tz * 4 + (lane >> 4);
+    if (i < nx && j < ny && k < nz) volume[((int64_t)k * ny + j) * nx + i] = payload[(size_t)w * 64 + lane];
+}
+
+// ------------------------------------------------------------------------------------
 // plan: device workspace that survives across calls
 // ------------------------------------------------------------------------------------
 struct r2s_plan {
     int device = 0;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
-    DevBuf active, active_sign, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
+    DevBuf active, active_sign, active_any, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
+    // state of the last run, for r2s_plan_pack_tiles_dev
+    SlabInfo last_s;
+    GridDev last_g;
+    uint32_t last_n_any = 0;
+    bool has_last = false;
     uint32_t* h_pinned = nullptr;  // 16 words
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -990,7 +1038,7 @@ void r2s_plan_destroy(r2s_plan* P)
     (void)hipSetDevice(P->device);
     DevBuf* all[] = {&P->deg, &P->ine_ptr, &P->ine, &P->cursor, &P->erec, &P->cls, &P->fmask, &P->nitems,
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
-                     &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign,
+                     &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any,
                      &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
     for (DevBuf* b : all) b->release();
@@ -1074,6 +1122,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->sign_off, sizeof(uint32_t) * (size_t)(ntiles + 1));
     ENSURE(P->active, sizeof(uint32_t) * (size_t)ntiles);
     ENSURE(P->active_sign, sizeof(uint32_t) * (size_t)ntiles);
+    ENSURE(P->active_any, sizeof(uint32_t) * (size_t)ntiles);
     ENSURE(P->hot, (size_t)ntiles + 1);
     ENSURE(P->counters, 64);
     uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] band tiles, [2] sign tiles
@@ -1133,13 +1182,14 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         rc = scan_exclusive(P, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
         if (rc) return rc;
     }
-    active_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), counters);
+    active_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), counters);
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[2], P->band_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[3], P->sign_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 20, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4],
                    n_active_sign = P->h_pinned[5];
+    P->last_s = s; P->last_g = g; P->last_n_any = P->h_pinned[8]; P->has_last = true;
     const uint32_t n_chunks = n_items ? P->h_pinned[10] : 0;
     ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_chunks, 1));
     if (mode & R2S_OUT_XP) ENSURE(P->iso_res_xp, sizeof(double) * 192 * (size_t)std::max<uint32_t>(n_chunks, 1));
@@ -1221,6 +1271,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         stats->n_tiles = ntiles;
         stats->n_active_tiles = n_active;
         stats->n_active_sign_tiles = n_active_sign;
+        stats->n_any_tiles = P->last_n_any;
         float ms = 0;
         if (hipEventElapsedTime(&ms, P->ev[0], P->ev[1]) == hipSuccess) stats->ms_prep = ms;
         if (hipEventElapsedTime(&ms, P->ev[1], P->ev[2]) == hipSuccess) stats->ms_bins = ms;
@@ -1297,6 +1348,43 @@ static int run_host(const double* X, int64_t nnp, const int64_t* IEN, int64_t ne
     if (mode & R2S_OUT_SDF) HIP_TRY_C(hipMemcpy(sdf, dF, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost));
     if (mode & R2S_OUT_XP) HIP_TRY_C(hipMemcpy(xp, dP, sizeof(double) * 3 * (size_t)ngp, hipMemcpyDeviceToHost));
     cleanup();
+    return 0;
+}
+
+int r2s_plan_pack_tiles_dev(r2s_plan* P, const double* d_local, double* d_payload, uint32_t* d_ids,
+                            int64_t capacity_tiles, int64_t* n_tiles_out, void* stream)
+{
+    if (!P || !P->has_last) return fail(R2S_ERR_ARG, "r2s_plan_pack_tiles_dev: no previous r2s_plan_run_dev on this plan");
+    const uint32_t n = P->last_n_any;
+    if (n_tiles_out) *n_tiles_out = n;
+    if (!d_local || !d_payload || !d_ids) return fail(R2S_ERR_ARG, "null argument");
+    if ((int64_t)n > capacity_tiles) return fail(R2S_ERR_ARG, "payload capacity %lld < %u tiles", (long long)capacity_tiles, n);
+    if ((P->last_s.k0 & 3) != 0) return fail(R2S_ERR_ARG, "tile packing needs a Z partition aligned to 4-plane tile layers");
+    HIP_TRY(hipSetDevice(P->device));
+    if (n)
+        pack_tiles_kernel<<<(n + 3) / 4, 256, 0, (hipStream_t)stream>>>(P->active_any.as<uint32_t>(), n, P->last_s, P->last_g,
+                                                                      d_local, -1.0e10, d_payload, d_ids);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int r2s_unpack_tiles_dev(const double* d_payload, const uint32_t* d_ids, int64_t n_tiles, const r2s_grid* grid,
+                         double* d_volume, void* stream)
+{
+    if (!grid || !d_volume || (n_tiles > 0 && (!d_payload || !d_ids)) || n_tiles < 0 || n_tiles >= ((int64_t)1 << 31))
+        return fail(R2S_ERR_ARG, "r2s_unpack_tiles_dev: bad argument");
+    if (n_tiles)
+        unpack_tiles_kernel<<<(unsigned)((n_tiles + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+            d_payload, d_ids, (uint32_t)n_tiles, (int)grid->N[0] + 1, (int)grid->N[1] + 1, (int)grid->N[2] + 1, d_volume);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int r2s_fill_dev(double* d, int64_t n, double value, void* stream)
+{
+    if (!d || n < 0) return fail(R2S_ERR_ARG, "r2s_fill_dev: bad argument");
+    if (n) fill_kernel<<<256 * 8, 256, 0, (hipStream_t)stream>>>(d, n, value);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

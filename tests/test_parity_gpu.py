@@ -189,3 +189,41 @@ def test_interleaved_layers_equal_full_volume(pkg, oracle, dims_n):
             sgs[0].gathered[r * sgs[0].per * sgs[0].plane:(r + 1) * sgs[0].per * sgs[0].plane].copy_(sg.mine)
         assert torch.equal(sgs[0].volume().reshape(-1), full), f"{world} interleaved parts differ from the full volume"
     plan.close()
+
+
+def test_sparse_tile_stitching_equals_full_volume(pkg, oracle):
+    """sparse multi-GPU stitching on one GPU: every rank's interleaved part is packed into tiles
+    (r2s_plan_pack_tiles_dev), scattered into a sentinel-filled volume (r2s_fill_dev / r2s_unpack_tiles_dev),
+    and the result must equal the full-volume run bit for bit"""
+    import torch
+    from rho2sdf_jl_amd import slabs, synthetic
+    X, IEN, rn = synthetic.hex_mesh(8)
+    dev = torch.device("cuda:0")
+    dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rn))
+    plan = pkg.DevicePlan(0)
+    for npts in (40, 37):
+        pg = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(npts), 3)
+        nx, ny, nz = pg.dims
+        full = torch.empty(nz * ny * nx, dtype=torch.float64, device=dev)
+        plan.run(dX, dI, dR, 0.5, pg, sdf=full)
+        for world in (2, 3, 8):
+            vol = torch.empty_like(full)
+            plan.fill(vol, -1.0e10)
+            moved = 0
+            for r in range(world):
+                owned, _ = slabs.interleaved_layers(nz, world, r)
+                if not owned:
+                    continue
+                local = torch.empty(4 * owned * ny * nx, dtype=torch.float64, device=dev)
+                st = plan.run(dX, dI, dR, 0.5, pg, sdf=local, zstride=world, zphase=r)
+                n = st["n_any_tiles"]
+                payload = torch.empty(max(n, 1) * 64, dtype=torch.float64, device=dev)
+                ids = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+                assert plan.pack_tiles(local, payload, ids) == n
+                plan.unpack_tiles(payload, ids, n, pg, vol)
+                moved += n
+            torch.cuda.synchronize()
+            assert torch.equal(vol, full), f"{world} ranks, {npts}^3: sparse stitching differs"
+            ntiles = ((nx + 3) // 4) * ((ny + 3) // 4) * ((nz + 3) // 4)
+            assert moved < ntiles       # fewer tiles than the dense volume
+    plan.close()

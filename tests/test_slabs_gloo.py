@@ -13,7 +13,54 @@ import torch.multiprocessing as mp
 from conftest import ROOT, load_fixture
 
 
-def _worker(rank, world, port, ref_path, dims, interleaved):
+class NumpyTileOps:
+    """CPU stand-ins for r2s_plan_pack_tiles_dev / r2s_unpack_tiles_dev / r2s_fill_dev (same tile layout)"""
+
+    def __init__(self, dims, world, rank):
+        self.nx, self.ny, self.nz = dims
+        self.world, self.rank = world, rank
+        self.ntx, self.nty = (self.nx + 3) // 4, (self.ny + 3) // 4
+
+    def _tiles(self, local):
+        v = local.view(-1, self.ny, self.nx).numpy()
+        out = []
+        for tz in range(v.shape[0] // 4):
+            for ty in range(self.nty):
+                for tx in range(self.ntx):
+                    blk = np.full((4, 4, 4), -1.0e10)
+                    sub = v[4 * tz:4 * tz + 4, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4]
+                    kg = 4 * (tz * self.world + self.rank)
+                    sub = sub[:max(0, min(4, self.nz - kg))]
+                    blk[:sub.shape[0], :sub.shape[1], :sub.shape[2]] = sub
+                    if (blk != -1.0e10).any():
+                        out.append((((tz * self.world + self.rank) * self.nty + ty) * self.ntx + tx, blk.reshape(-1)))
+        return out
+
+    def count(self, local):
+        return len(self._tiles(local))
+
+    def pack(self, local, payload, ids):
+        t = self._tiles(local)
+        for w, (tid, blk) in enumerate(t):
+            payload[w * 64:(w + 1) * 64] = torch.from_numpy(blk)
+            ids[w] = tid
+        return len(t)
+
+    def unpack(self, payload, ids, n, vol):
+        v = vol.view(self.nz, self.ny, self.nx).numpy()
+        for w in range(n):
+            tid = int(ids[w])
+            tx, ty, tz = tid % self.ntx, (tid // self.ntx) % self.nty, tid // (self.ntx * self.nty)
+            blk = payload[w * 64:(w + 1) * 64].numpy().reshape(4, 4, 4)
+            sub = v[4 * tz:4 * tz + 4, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4]
+            sub[...] = blk[:sub.shape[0], :sub.shape[1], :sub.shape[2]]
+
+    @staticmethod
+    def fill(t, value):
+        t.fill_(value)
+
+
+def _worker(rank, world, port, ref_path, dims, interleaved, sparse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -22,7 +69,8 @@ def _worker(rank, world, port, ref_path, dims, interleaved):
     graft.load_package()
     from rho2sdf_jl_amd import slabs
     ref = torch.from_numpy(np.load(ref_path))
-    sg = slabs.SlabGather(dims, rank, world, torch.device("cpu"), interleaved=interleaved)
+    ops = NumpyTileOps(dims, world, rank)
+    sg = slabs.SlabGather(dims, rank, world, torch.device("cpu"), interleaved=interleaved, sparse=sparse, ops=ops)
     plane = dims[0] * dims[1]
     nz = dims[2]
 
@@ -37,6 +85,8 @@ def _worker(rank, world, port, ref_path, dims, interleaved):
                     k = 4 * (i * zstride + zphase) + l
                     if k < nz:
                         o[4 * i + l] = ref[k * plane:(k + 1) * plane]
+            o[torch.isnan(o)] = -1.0e10      # planes beyond the grid
+            return {"n_any_tiles": ops.count(out)}
 
     slabs.run_step(sg, compute_slab)
     ok = torch.equal(sg.volume().reshape(-1), ref)
@@ -75,3 +125,18 @@ def test_slab_bounds():
     assert slabs.interleaved_layers(512, 8, 3) == (16, 16)
     assert slabs.interleaved_layers(257, 4, 0) == (17, 17) and slabs.interleaved_layers(257, 4, 1) == (16, 17)
     assert slabs.interleaved_layers(17, 8, 5) == (0, 1)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sparse_tile_allgather(oracle, tmp_path, world):
+    """sparse stitching: only non-sentinel 4x4x4 tiles travel (counts + padded payload all-gather + scatter)"""
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    g = oracle.grid_make(X.min(0), X.max(0), 10)
+    d, _, _ = oracle.eval_distances(X, IEN, rn, 0.5, g, 1.1, want_xp=False)
+    sdf = d * oracle.sign_detection(X, IEN, rn, 0.5, g)
+    assert (sdf == -1.0e10).sum() > 1000          # the case has plenty of sentinel tiles to skip
+    ref_path = str(tmp_path / "ref.npy")
+    np.save(ref_path, sdf)
+    port = 29700 + (os.getpid() % 200) + world
+    mp.spawn(_worker, args=(world, port, ref_path, g.dims, True, True), nprocs=world, join=True)

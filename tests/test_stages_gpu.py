@@ -136,3 +136,16 @@ def test_rho2sdf_end_to_end(pkg, oracle):
     opts2 = pkg.Rho2sdfOptions(sdf_grid_setup="automatic", rbf_interp=False)
     out = pkg.rho2sdf("beam", X, IEN, rho, options=opts2)
     assert out[0].shape == (11, 27, 67)
+
+
+def test_mesh_volume_tet4(pkg, oracle):
+    """calculate_element_volume TET4 (MeshVolume.jl:75-117): restated with the reference's Jacobian (25 % low)"""
+    from rho2sdf_jl_amd import synthetic
+    X, IT, rn = synthetic.tet_mesh(5)
+    rho = np.linspace(0.1, 0.9, len(IT))
+    vd, vf = pkg.calculate_mesh_volume(pkg.Mesh(X, IT), rho)
+    ovd, ovf = oracle.mesh_volume_tet4(X, IT, rho)
+    assert vd == pytest.approx(ovd, rel=1e-12) and vf == pytest.approx(ovf, rel=1e-12)
+    assert vd == pytest.approx(0.75 * 8.0, rel=1e-12)      # [-1,1]^3, see the note in r2s_pre.hip
+    rn_gpu = pkg.DenseInNodes(pkg.Mesh(X, IT), rho)
+    assert np.abs(rn_gpu - oracle.dense_in_nodes(X, IT, rho)).max() <= 1e-12
