@@ -10,8 +10,11 @@ timed region; the output SDF stays in HBM.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 512] [--mesh 46]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-With N > 1 the fixed 512^3 grid is split into N equal Z-slabs (one rank per GPU) and stitched
-with ONE all_gather_into_tensor over RCCL/xGMI ("scaling": "strong").
+With N > 1 the fixed 512^3 grid is partitioned along Z (one rank per GPU; default: interleaved
+4-plane tile layers, balanced) and stitched over RCCL/xGMI so that every rank holds the whole volume
+("scaling": "strong"): by default only the 4x4x4 tiles that can differ from the sentinel travel
+(one padded all_gather_into_tensor of tile payloads + ids after a tiny count exchange; --stitch dense
+gathers the full Float64 volume instead).
 """
 import argparse
 import json
