@@ -26,6 +26,11 @@ struct alignas(16) ElemRec {
     // X(xi) = sum_m C[m] mono_m(xi), mono = [1, x1, x2, x3, x1x2, x1x3, x2x3, x1x2x3]
     double C[8][3];
     double Cr[8];
+    // six half-spaces pn[f].x <= po[f] that contain the image of the cube |xi| <= 1.011 (convex hull of
+    // the inflated corners): a point outside one of them has no local coordinates with max|xi| < 1.01, so
+    // Sign_Detection's candidate test cannot accept it and the Newton solve is skipped (exact pruning)
+    double pn[6][3];
+    double po[6];
 };
 
 // band work item: one boundary-face triangle (process_triangle_projection!,
@@ -148,6 +153,63 @@ R2S_DEV void hex8_monomials(ElemRec& R)
     }
 }
 
+// Bounding half-spaces of the inflated element (see ElemRec::pn).  Face f = 2a + (s > 0): normal = cross
+// product of the two in-face tangents at the face centre, oriented along s * dX/dxi_a; offset = max of
+// n.X over the 8 corners of the cube |xi| = 1.011 (a trilinear map takes the cube into the convex hull of
+// the corner images) plus a rounding margin.  Degenerate faces give n = 0 and never reject.
+R2S_DEV void hex8_planes(ElemRec& R)
+{
+    const double lamb = 1.011;
+    double ext = 0.0;
+    for (int i = 0; i < 3; ++i) ext += R.mx[i] - R.mn[i];
+    for (int a = 0; a < 3; ++a) {
+        for (int sg = 0; sg < 2; ++sg) {
+            const double s = sg ? 1.0 : -1.0;
+            double xi[3] = {0.0, 0.0, 0.0};
+            xi[a] = s;
+            double J[3][3];   // J[i][q] = dX_i / dxi_q
+            for (int i = 0; i < 3; ++i) {
+                J[i][0] = R.C[1][i] + xi[1] * R.C[4][i] + xi[2] * R.C[5][i] + xi[1] * xi[2] * R.C[7][i];
+                J[i][1] = R.C[2][i] + xi[0] * R.C[4][i] + xi[2] * R.C[6][i] + xi[0] * xi[2] * R.C[7][i];
+                J[i][2] = R.C[3][i] + xi[0] * R.C[5][i] + xi[1] * R.C[6][i] + xi[0] * xi[1] * R.C[7][i];
+            }
+            const int b = (a + 1) % 3, c = (a + 2) % 3;
+            double n[3] = {J[1][b] * J[2][c] - J[2][b] * J[1][c], J[2][b] * J[0][c] - J[0][b] * J[2][c],
+                           J[0][b] * J[1][c] - J[1][b] * J[0][c]};
+            const double along = s * (n[0] * J[0][a] + n[1] * J[1][a] + n[2] * J[2][a]);
+            if (along < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+            if (!(along != 0.0)) { n[0] = n[1] = n[2] = 0.0; }   // degenerate or NaN: never rejects
+            double off = -INFINITY;
+            for (int k = 0; k < 8; ++k) {
+                const double s1 = (k & 1) ? lamb : -lamb, s2 = (k & 2) ? lamb : -lamb, s3 = (k & 4) ? lamb : -lamb;
+                double v = 0.0;
+                for (int i = 0; i < 3; ++i) {
+                    const double Xi = R.C[0][i] + s1 * R.C[1][i] + s2 * R.C[2][i] + s3 * R.C[3][i] +
+                                      s1 * s2 * R.C[4][i] + s1 * s3 * R.C[5][i] + s2 * s3 * R.C[6][i] +
+                                      s1 * s2 * s3 * R.C[7][i];
+                    v += n[i] * Xi;
+                }
+                off = fmax(off, v);
+            }
+            const double nn = fabs(n[0]) + fabs(n[1]) + fabs(n[2]);
+            const int f = 2 * a + sg;
+            R.pn[f][0] = n[0]; R.pn[f][1] = n[1]; R.pn[f][2] = n[2];
+            R.po[f] = off + 1e-9 * nn * ext;
+        }
+    }
+}
+
+// true when x lies outside one of the bounding half-spaces (no local coordinates with max|xi| < 1.01)
+template <class ER>
+R2S_DEV bool hex8_outside(const ER& E, const double x[3])
+{
+    bool out = false;
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+        out = out || (E.pn[f][0] * x[0] + E.pn[f][1] * x[1] + E.pn[f][2] * x[2] > E.po[f]);
+    return out;
+}
+
 // value, gradient and mixed second derivatives of one scalar trilinear field (12 FMAs)
 struct TriEval {
     double v, d1, d2, d3, m12, m13, m23;
@@ -241,7 +303,10 @@ R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const d
     const int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
     double dB[3], aa[3], b[3], M[3][3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dB[i] = (s[i] == 1) ? lo[i] : ((s[i] == 2) ? hi[i] : 0.0);
+    for (int i = 0; i < 3; ++i) {
+        const double l = lo[i], h = hi[i];   // loaded before the select: keeps the caller's state in registers
+        dB[i] = (s[i] == 1) ? l : ((s[i] == 2) ? h : 0.0);
+    }
     double ep = e;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -523,6 +588,231 @@ R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, dou
         if (stop == 1) return it + 1;
     }
     return R2S_ISO_MAXIT + 1;
+}
+
+// ---- the same SQP as a per-lane state machine ---------------------------------------
+// iso_project_hex8 cut into phases so that the lanes of a wavefront can sit in different phases /
+// iterations / voxels (iso_project_hex_kernel): every phase performs exactly the arithmetic of the
+// corresponding part of iso_project_hex8, in the same order, so the results are bit-identical.
+//   EVAL  fields, QP data, corner test            -> QP | POST
+//   QP    ONE active-set pattern (walk or exhaustive fallback) per visit -> QP | POST
+//   POST  step test, merit parameter               -> LS | UPD
+//   LS    ONE backtracking trial per visit         -> LS | UPD
+//   UPD   trust region, iterate update             -> EVAL | DONE
+enum { ISO_IDLE = 0, ISO_EVAL, ISO_QP, ISO_POST, ISO_LS, ISO_UPD, ISO_DONE };
+
+struct IsoLane {
+    double x[3];
+    double xi[3], mu, Delta;
+    double H[3][3], gp[3], a[3], g[3], lo[3], hi[3], d[3];
+    double e, f, c, lam_new, alpha, D, phi0, bestq;
+    int pat, it, p, step, ip, ls, stop, phase;
+    bool corner, found, fb;
+};
+
+R2S_DEV void iso_lane_start(IsoLane& s, const double x[3])
+{
+    s.x[0] = x[0]; s.x[1] = x[1]; s.x[2] = x[2];
+    s.xi[0] = s.xi[1] = s.xi[2] = 0.0;
+    s.mu = 0.0; s.Delta = 2.0;
+    s.pat = 0; s.it = 0;
+    s.phase = ISO_EVAL;
+}
+
+R2S_DEV void iso_lane_eval(const ElemRec& E, double rt, IsoLane& s)
+{
+    double r[3], J[3][3], G[3][3], M2[3][3];
+    double f = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const TriEval t = tri_eval_full(R2S_CX(E, i), s.xi);
+        r[i] = s.x[i] - t.v;
+        f += r[i] * r[i];
+        J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
+        M2[i][0] = t.m12; M2[i][1] = t.m13; M2[i][2] = t.m23;
+    }
+    const TriEval tr = tri_eval_full(R2S_CR(E), s.xi);
+    const double c = tr.v - rt;
+    s.a[0] = tr.d1; s.a[1] = tr.d2; s.a[2] = tr.d3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s.g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            G[i][j] = 2.0 * (J[0][i] * J[0][j] + J[1][i] * J[1][j] + J[2][i] * J[2][j]);
+    double lam;
+    {
+        double num = 0.0, den = 0.0;
+        const int sp[3] = {s.pat % 3, (s.pat / 3) % 3, s.pat / 9};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (!sp[i]) { num += s.a[i] * s.g[i]; den += s.a[i] * s.a[i]; }
+        lam = (den > 0.0) ? -num / den : 0.0;
+    }
+    double S[3];
+    {
+        const double mr[3] = {tr.m12, tr.m13, tr.m23};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            S[q] = -2.0 * (r[0] * M2[0][q] + r[1] * M2[1][q] + r[2] * M2[2][q]) + lam * mr[q];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        s.lo[i] = fmax(-1.0 - s.xi[i], -s.Delta);
+        s.hi[i] = fmin(1.0 - s.xi[i], s.Delta);
+    }
+    const double e = -c;
+    double mplus = 0.0, mminus = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double p = s.a[i] * s.lo[i], q = s.a[i] * s.hi[i];
+        mplus += fmax(p, q);
+        mminus += fmin(p, q);
+    }
+    const double trG = G[0][0] + G[1][1] + G[2][2];
+    const double aa2 = s.a[0] * s.a[0] + s.a[1] * s.a[1] + s.a[2] * s.a[2];
+    const double sigma = 100.0 * trG / aa2;
+    s.corner = false;
+    s.stop = 0;
+    s.lam_new = lam;
+    s.alpha = 1.0;
+    s.e = e; s.f = f; s.c = c;
+    if (e >= mplus) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? s.hi[i] : ((s.a[i] < 0.0) ? s.lo[i] : 0.0);
+        s.corner = true;
+        s.phase = ISO_POST;
+    } else if (e <= mminus) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? s.lo[i] : ((s.a[i] < 0.0) ? s.hi[i] : 0.0);
+        s.corner = true;
+        s.phase = ISO_POST;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s.H[i][j] = G[i][j] + sigma * s.a[i] * s.a[j];
+            s.gp[i] = s.g[i] - sigma * e * s.a[i];
+        }
+        s.H[0][1] += S[0]; s.H[1][0] += S[0];
+        s.H[0][2] += S[1]; s.H[2][0] += S[1];
+        s.H[1][2] += S[2]; s.H[2][1] += S[2];
+        if (!spd3(s.H)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) s.H[i][j] = G[i][j] + sigma * s.a[i] * s.a[j];
+        }
+        s.p = s.pat;
+        s.step = 0;
+        s.found = false;
+        s.fb = false;
+        s.phase = ISO_QP;
+    }
+}
+
+R2S_DEV void iso_lane_qp(IsoLane& s)
+{
+    QpOut o;
+    const int p = s.fb ? c_pat_order[s.ip] : s.p;
+    const int rc = qp_pattern(p, s.H, s.gp, s.a, s.e, s.lo, s.hi, o);
+    bool done = false;
+    if (!s.fb) {
+        // active-set walk: the first primal feasible KKT pattern is the minimiser
+        if (rc == 1 && o.kkt) {
+            s.found = true;
+            s.pat = p;
+            s.d[0] = o.d[0]; s.d[1] = o.d[1]; s.d[2] = o.d[2];
+            s.lam_new = o.lam;
+            done = true;
+        } else {
+            bool to_fb = (rc == 0);
+            if (!to_fb) {
+                s.p = o.next;
+                s.step += 1;
+                to_fb = !(s.step < 6 && s.p >= 0);
+            }
+            if (to_fb) { s.fb = true; s.ip = 0; s.bestq = INFINITY; }
+        }
+    } else {
+        // exhaustive fallback, one pattern per visit
+        if (rc == 1) {
+            if (o.kkt || o.q < s.bestq) {
+                s.bestq = o.q;
+                s.found = true;
+                s.pat = p;
+                s.d[0] = o.d[0]; s.d[1] = o.d[1]; s.d[2] = o.d[2];
+                s.lam_new = o.lam;
+            }
+            if (o.kkt) done = true;
+        }
+        s.ip += 1;
+        if (s.ip == 19) done = true;
+    }
+    if (done) {
+        if (!s.found) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                s.d[i] = (s.e > 0.0) ? ((s.a[i] > 0.0) ? s.hi[i] : ((s.a[i] < 0.0) ? s.lo[i] : 0.0))
+                                     : ((s.a[i] > 0.0) ? s.lo[i] : ((s.a[i] < 0.0) ? s.hi[i] : 0.0));
+            s.corner = true;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.d[i] = fmin(fmax(s.d[i], s.lo[i]), s.hi[i]);
+        s.phase = ISO_POST;
+    }
+}
+
+R2S_DEV void iso_lane_post(IsoLane& s)
+{
+    const double dmax = fmax(fabs(s.d[0]), fmax(fabs(s.d[1]), fabs(s.d[2])));
+    if (!(dmax > R2S_ISO_TOL)) {
+        s.stop = s.corner ? 2 : 1;
+    } else {
+        const double ad = s.a[0] * s.d[0] + s.a[1] * s.d[1] + s.a[2] * s.d[2];
+        const double pred_c = fabs(s.c) - fabs(s.c + ad);
+        const double gd = s.g[0] * s.d[0] + s.g[1] * s.d[1] + s.g[2] * s.d[2];
+        double mu_t = s.corner ? s.mu : fmax(0.5 * s.mu, 2.0 * fabs(s.lam_new));
+        if (!(gd - mu_t * pred_c < 0.0)) {
+            if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
+            else s.stop = 2;
+        }
+        if (!s.stop) {
+            s.mu = mu_t;
+            s.D = gd - s.mu * pred_c;
+            s.phi0 = s.f + s.mu * fabs(s.c);
+            s.ls = 0;
+        }
+    }
+    s.phase = s.stop ? ISO_UPD : ISO_LS;
+}
+
+R2S_DEV void iso_lane_ls(const ElemRec& E, double rt, IsoLane& s)
+{
+    double xt[3], ft, ct;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(s.xi[i] + s.alpha * s.d[i], -1.0), 1.0);
+    iso_eval_fc(E, s.x, rt, xt, ft, ct);
+    if (ft + s.mu * fabs(ct) <= s.phi0 + 1e-4 * s.alpha * s.D) {
+        s.phase = ISO_UPD;
+    } else {
+        s.alpha *= 0.5;
+        s.ls += 1;
+        if (s.ls == 30) s.phase = ISO_UPD;
+    }
+}
+
+R2S_DEV void iso_lane_update(IsoLane& s)
+{
+    const double dm = fmax(fabs(s.d[0]), fmax(fabs(s.d[1]), fabs(s.d[2])));
+    s.Delta = (s.alpha < 1.0) ? s.alpha * dm : fmin(2.0, fmax(s.Delta, 2.0 * dm));
+    if (s.stop == 2) { s.phase = ISO_DONE; return; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s.xi[i] = fmin(fmax(s.xi[i] + s.alpha * s.d[i], -1.0), 1.0);
+    if (s.stop == 1) { s.phase = ISO_DONE; return; }
+    s.it += 1;
+    s.phase = (s.it == R2S_ISO_MAXIT) ? ISO_DONE : ISO_EVAL;
 }
 
 // running minimum of one voxel: WriteValue / update_distance_parallel!

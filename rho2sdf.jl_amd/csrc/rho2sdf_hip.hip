@@ -191,7 +191,7 @@ struct HexT {
     using Rec = ElemRec;
     static constexpr int NEN = 8, NES = 6, NSN = 4;
     static __device__ __forceinline__ int face(int sg, int a) { return c_hex_isn[sg][a]; }
-    static __device__ __forceinline__ void finish(Rec& R, const GridDev&) { hex8_monomials(R); }
+    static __device__ void finish(Rec& R, const GridDev&) { hex8_monomials(R); hex8_planes(R); }
 };
 struct TetT {
     using Rec = TetRec;
@@ -501,6 +501,110 @@ __global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __rest
     }
 }
 
+// HEX8 variant with lane refill (DESIGN.md "iso_project"): one wavefront works off `cpw` consecutive
+// 64-voxel chunks; every lane runs the SQP state machine of r2s_device_math.hpp (IsoLane) on its own
+// voxel and, when it has finished, takes the next voxel of the item, so that slowly converging voxels,
+// extra active-set steps and line-search trials of one lane no longer stall the other 63.  The element
+// record stays wave-uniform (SGPRs): lanes are only refilled from the same item.
+#ifndef R2S_ISO_LB2
+#define R2S_ISO_LB2 , 3   // 168 VGPRs, 12 B/lane of scratch: 3 waves/SIMD measured 3-7 % faster than 2
+#endif
+#ifndef R2S_ISO_REFILL_MIN
+#define R2S_ISO_REFILL_MIN 16
+#endif //   // finished lanes wait until this many can be finalised + refilled together
+__global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_kernel(const BandItem* __restrict__ items, uint32_t nitems,
+                                                              const uint32_t* __restrict__ chunk_off,
+                                                              uint32_t nchunks, uint32_t cpw,
+                                                              const ElemRec* __restrict__ erec, GridDev g,
+                                                              SlabInfo sl, double rho_t, double* __restrict__ res,
+                                                              double* __restrict__ res_xp)
+{
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    uint32_t c = w * cpw;
+    if (c >= nchunks) return;
+    const uint32_t c_end = (c + cpw < nchunks) ? c + cpw : nchunks;
+    // last item with chunk_off[it] <= c  (chunk_off has nitems+1 entries, non-decreasing)
+    uint32_t lo = 0, hi = nitems;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunk_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    while (c < c_end) {
+        lo = __builtin_amdgcn_readfirstlane(lo);
+        const BandItem& T = items[lo];
+        const ElemRec& E = erec[T.el];
+        const uint32_t co = chunk_off[lo], cn = chunk_off[lo + 1];
+        const uint32_t seg_end = (cn < c_end) ? cn : c_end;
+        const uint32_t bx = T.dim[0], bxy = T.dim[0] * T.dim[1], vol = bxy * T.dim[2];
+        uint32_t next = (c - co) * 64u;
+        const uint32_t v_end = ((seg_end - co) * 64u < vol) ? (seg_end - co) * 64u : vol;
+        const int lo0 = T.lo[0], lo1 = T.lo[1], lo2 = T.lo[2];
+        const size_t base = (size_t)co * 64u;
+
+        IsoLane s;
+        s.phase = ISO_IDLE;
+        uint32_t my = 0;
+        for (;;) {
+            // ---- finalise finished lanes, hand out new voxels ----
+            const uint64_t m_done = __ballot(s.phase == ISO_DONE);
+            const uint64_t m_busy = __ballot(s.phase != ISO_DONE && s.phase != ISO_IDLE);
+            if (m_busy == 0 || __popcll(m_done) >= R2S_ISO_REFILL_MIN) {
+                if (s.phase == ISO_DONE) {
+                    double N[8], xp[3];
+                    hex8_shape(s.xi, N);
+                    const ElemRec* Ep = &E;
+                    asm volatile("" : "+s"(Ep));   // nodal coordinates: scalar loads here, not live in the solve
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) t += Ep->X[k][i] * N[k];
+                        xp[i] = t;
+                    }
+                    const size_t slot = base + my;
+                    res[slot] = norm3(s.x[0] - xp[0], s.x[1] - xp[1], s.x[2] - xp[2]);
+                    if (res_xp) {
+                        res_xp[3 * slot] = xp[0];
+                        res_xp[3 * slot + 1] = xp[1];
+                        res_xp[3 * slot + 2] = xp[2];
+                    }
+                    s.phase = ISO_IDLE;
+                }
+                const uint64_t m_idle = __ballot(s.phase == ISO_IDLE);
+                if (next < v_end) {
+                    if (s.phase == ISO_IDLE) {
+                        const uint32_t v = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                        if (v < v_end) {
+                            my = v;
+                            const uint32_t lk = v / bxy, rem = v - lk * bxy;
+                            const uint32_t lj = rem / bx, li = rem - lj * bx;
+                            double x[3];
+                            x[0] = grid_coord(g, 0, lo0 + (int)li);
+                            x[1] = grid_coord(g, 1, lo1 + (int)lj);
+                            x[2] = grid_coord(g, 2, slab_global_k(sl, lo2 + (int)lk));   // T.lo[2] is a local plane
+                            iso_lane_start(s, x);
+                        }
+                    }
+                    next += (uint32_t)__popcll(m_idle);
+                } else if (m_busy == 0) {
+                    break;      // every lane idle, nothing left in this segment
+                }
+            }
+            // ---- one visit of each phase ----
+            if (s.phase == ISO_EVAL) iso_lane_eval(E, rho_t, s);
+            if (s.phase == ISO_QP) iso_lane_qp(s);
+            if (s.phase == ISO_POST) iso_lane_post(s);
+            if (s.phase == ISO_LS) iso_lane_ls(E, rho_t, s);
+            if (s.phase == ISO_UPD) iso_lane_update(s);
+        }
+        c = seg_end;
+        if (c < c_end) {
+            do { ++lo; } while (chunk_off[lo + 1] <= c);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // tile binning.  A tile is a 4x4x4 block of VOXELS (lattice indices); a voxel's cell
 // index (Grid.jl:58) is its lattice index or one less, so an item with cell box
@@ -617,40 +721,63 @@ __global__ void sign_bin_kernel(const Rec* __restrict__ erec, uint32_t nel, Grid
 }
 
 // active tiles = tiles with a non-empty band list, or a sign list whose elements reach rho_t
-__global__ void active_tiles_kernel(const uint32_t* __restrict__ band_cnt,
-                                    const uint32_t* __restrict__ sign_cnt,
-                                    const uint8_t* __restrict__ hot, uint32_t ntiles,
-                                    uint32_t* __restrict__ active_band, uint32_t* __restrict__ active_sign,
-                                    uint32_t* __restrict__ active_any, uint32_t* __restrict__ counters)
+#define AT_ITEMS 8   // tiles per thread
+__global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __restrict__ band_cnt,
+                                                           const uint32_t* __restrict__ sign_cnt,
+                                                           const uint8_t* __restrict__ hot, uint32_t ntiles,
+                                                           uint32_t* __restrict__ active_band,
+                                                           uint32_t* __restrict__ active_sign,
+                                                           uint32_t* __restrict__ active_any,
+                                                           uint32_t* __restrict__ counters)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = t < ntiles;
-    const bool fb = in && band_cnt[t] != 0;
-    const bool fs = in && sign_cnt[t] != 0 && hot[t] != 0;
-    // wave-aggregated append: one atomic per wavefront and list
+    // block-aggregated append: the three lists are collected in LDS (wave-aggregated LDS atomics), then ONE
+    // global atomic per block and list reserves the output range (2.1 M tiles used to mean ~100 k same-address
+    // atomics = 0.49 ms)
+    __shared__ uint32_t s_cnt[3], s_base[3], s_max[2];
+    __shared__ uint32_t s_list[3][256 * AT_ITEMS];
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_max[threadIdx.x] = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const unsigned long long mb = __ballot(fb), ms = __ballot(fs);
     const unsigned long long below = (1ull << lane) - 1ull;
-    uint32_t base_b = 0, base_s = 0;
-    if (lane == 0) {
-        if (mb) base_b = atomicAdd(&counters[1], (uint32_t)__popcll(mb));
-        if (ms) base_s = atomicAdd(&counters[2], (uint32_t)__popcll(ms));
-    }
-    base_b = __shfl(base_b, 0, 64);
-    base_s = __shfl(base_s, 0, 64);
-    if (fb) active_band[base_b + __popcll(mb & below)] = t;
-    if (fs) active_sign[base_s + __popcll(ms & below)] = t;
-    {   // union: every tile whose voxels can differ from the sentinel (what a sparse all-gather has to move)
-        const bool fa = fb || fs;
-        const unsigned long long ma = __ballot(fa);
-        uint32_t base_a = 0;
-        if (lane == 0 && ma) base_a = atomicAdd(&counters[5], (uint32_t)__popcll(ma));
-        base_a = __shfl(base_a, 0, 64);
-        if (fa) active_any[base_a + __popcll(ma & below)] = t;
+    const uint32_t t0 = blockIdx.x * (256u * AT_ITEMS);
+    uint32_t mxb = 0, mxs = 0;
+    for (int i = 0; i < AT_ITEMS; ++i) {
+        const uint32_t t = t0 + (uint32_t)i * 256u + threadIdx.x;
+        const bool in = t < ntiles;
+        const uint32_t bc = in ? band_cnt[t] : 0u, sc = in ? sign_cnt[t] : 0u;
+        const bool f[3] = {bc != 0, sc != 0 && hot[t] != 0, false};
+        const bool fl[3] = {f[0], f[1], f[0] || f[1]};   // [2]: union = what a sparse all-gather has to move
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const unsigned long long m = __ballot(fl[l]);
+            if (m) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_cnt[l], (uint32_t)__popcll(m));
+                base = __shfl(base, 0, 64);
+                if (fl[l]) s_list[l][base + __popcll(m & below)] = t;
+            }
+        }
+        if (fl[0] && bc > mxb) mxb = bc;
+        if (fl[1] && sc > mxs) mxs = sc;
     }
     // longest lists (decides whether the wave-per-tile sort has to run at all)
-    if (fb && band_cnt[t] > 64u) atomicMax(&counters[3], band_cnt[t]);
-    if (fs && sign_cnt[t] > 64u) atomicMax(&counters[4], sign_cnt[t]);
+    if (mxb > 64u) atomicMax(&s_max[0], mxb);
+    if (mxs > 64u) atomicMax(&s_max[1], mxs);
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int idx[3] = {1, 2, 5};
+        const uint32_t n = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = n ? atomicAdd(&counters[idx[threadIdx.x]], n) : 0u;
+    } else if (threadIdx.x < 5) {
+        const uint32_t v = s_max[threadIdx.x - 3];
+        if (v > 64u) atomicMax(&counters[threadIdx.x], v);
+    }
+    __syncthreads();
+    uint32_t* const out[3] = {active_band, active_sign, active_any};
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+        for (uint32_t j = threadIdx.x; j < s_cnt[l]; j += 256u) out[l][s_base[l] + j] = s_list[l][j];
 }
 
 // short lists (<= 64 entries): one LANE per active tile, rank sort
@@ -729,7 +856,8 @@ struct MainArgs {
     double* xp;
     const double* iso_res;     // per (iso item, box voxel) distances from iso_project_kernel
     const double* iso_res_xp;  // projection points (only when xp is requested)
-    int sdf_mode;  // 1: sdf = dist*sign in one kernel; 2: dist pass stores -dist; 3: sign pass flips
+    int sdf_mode;  // 1: sdf = dist*sign in one kernel; 2: dist pass stores -dist; 3: sign pass flips;
+                   // 4: dist pass after the sign pass (keeps the sign already stored)
 };
 
 template <class Rec, bool DO_DIST, bool DO_SIGN>
@@ -806,8 +934,10 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
             if (__any(go)) {
                 for (uint32_t p = b; p < e; ++p) {
                     const ElemRec& E = erec[A.sign_ent[p]];
+                    // AABB test of the reference, then the exact half-space pruning (ElemRec::pn): a voxel
+                    // outside the inflated element cannot pass sign_visit's max|xi| < 1.01 test
                     const bool in = go && !done && E.mn[0] <= x[0] && E.mn[1] <= x[1] && E.mn[2] <= x[2] &&
-                                    x[0] <= E.mx[0] && x[1] <= E.mx[1] && x[2] <= E.mx[2];
+                                    x[0] <= E.mx[0] && x[1] <= E.mx[1] && x[2] <= E.mx[2] && !hex8_outside(E, x);
                     if (in) sign_visit(E, A.rho_t, x, max_local, sg, done);
                 }
             }
@@ -850,6 +980,7 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
             // dist * (-1), the sign pass negates where the sign is +1 (bit-identical products)
             if (A.sdf_mode == 1) A.sdf[v] = st.cur * sg;
             else if (A.sdf_mode == 2) A.sdf[v] = -st.cur;
+            else if (A.sdf_mode == 4) A.sdf[v] = (A.sdf[v] > 0.0) ? st.cur : -st.cur;   // sign pass ran first
             else if (sg > 0.0) A.sdf[v] = -A.sdf[v];
         }
         if (A.xp) {
@@ -910,6 +1041,9 @@ struct r2s_plan {
     bool has_last = false;
     uint32_t* h_pinned = nullptr;  // 16 words
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // second stream: sentinel sweep + sign pass run beside the iso-surface projection (fused SDF output)
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev2[3] = {nullptr, nullptr, nullptr};
 };
 
 static int scan_exclusive(r2s_plan* P, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st, int level = 0)
@@ -1028,6 +1162,15 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     P->device = device;
     HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocDefault));
     for (int i = 0; i < 7; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
+    {
+        // lowest priority: the sign pass fills the wave slots the projection kernel leaves free and its tail
+        // (measured: equal priority 9.1 ms/step, high 9.6, low 8.5 on the north-star workload)
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        (void)prio_hi;
+        HIP_TRY(hipStreamCreateWithPriority(&P->st2, hipStreamNonBlocking, prio_lo));
+    }
     *out = P;
     return 0;
 }
@@ -1045,6 +1188,9 @@ void r2s_plan_destroy(r2s_plan* P)
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
     for (int i = 0; i < 7; ++i)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
+    for (int i = 0; i < 3; ++i)
+        if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
+    if (P->st2) (void)hipStreamDestroy(P->st2);
     delete P;
 }
 
@@ -1182,7 +1328,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         rc = scan_exclusive(P, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
         if (rc) return rc;
     }
-    active_tiles_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), counters);
+    active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), counters);
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[2], P->band_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[3], P->sign_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 20, hipMemcpyDeviceToHost, st));
@@ -1217,12 +1363,21 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipEventRecord(P->ev[2], st));
 
     // ---- sentinel sweep ----
+    // Fused SDF output only: after the sweep the sign pass goes to a second stream and runs beside the iso-surface
+    // projection (both are latency-bound FP64 chains; together they fill the SIMDs better); the ordered
+    // gather then waits for both and keeps the sign already stored.
+    static const bool overlap_env = !(getenv("R2S_NO_OVERLAP") && atoi(getenv("R2S_NO_OVERLAP")));
+    const bool overlap = overlap_env && mode == R2S_OUT_SDF && want_sign && want_dist;
     const unsigned fill_grid = 256 * 8;
     if (mode & R2S_OUT_DIST) fill_kernel<<<fill_grid, 256, 0, st>>>(d_dist, nvox, 1.0e10);
     if (mode & R2S_OUT_SIGN) fill_kernel<<<fill_grid, 256, 0, st>>>(d_sign, nvox, -1.0);
     if (mode & R2S_OUT_SDF) fill_kernel<<<fill_grid, 256, 0, st>>>(d_sdf, nvox, -1.0e10);
     if (mode & R2S_OUT_XP) HIP_TRY(hipMemsetAsync(d_xp, 0, sizeof(double) * 3 * (size_t)nvox, st));
     HIP_TRY(hipEventRecord(P->ev[3], st));
+    if (overlap) {   // fork: the sign pass follows the sweep on the second stream
+        HIP_TRY(hipStreamWaitEvent(P->st2, P->ev[3], 0));
+        HIP_TRY(hipEventRecord(P->ev2[1], P->st2));
+    }
 
     // ---- projection / sign kernel over the active tiles ----
     {
@@ -1234,24 +1389,53 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         A.dist = (mode & R2S_OUT_DIST) ? d_dist : nullptr;
         A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
         A.sdf = (mode & R2S_OUT_SDF) ? d_sdf : nullptr;
+        if (overlap) {
+            if (n_active_sign) {
+                MainArgs B = A;
+                B.active = P->active_sign.as<uint32_t>(); B.n_active = n_active_sign;
+                B.dist = nullptr; B.xp = nullptr; B.sign = nullptr;
+                B.sdf_mode = 3;
+                // one-wave workgroups: they take freed wave slots as readily as the projection kernel's
+                sdf_tiles_kernel<typename ET::Rec, false, true><<<n_active_sign, 64, 0, P->st2>>>(B);
+            }
+            HIP_TRY(hipEventRecord(P->ev2[2], P->st2));
+        }
         // item-major iso-surface projections, then the ordered gather over the band tiles
         A.iso_res = P->iso_res.as<double>();
         A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
-        if (want_dist && n_chunks)
-            iso_project_kernel<typename ET::Rec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
-                P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
-                s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+        if (want_dist && n_chunks) {
+            if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
+                static const int cpw_env = getenv("R2S_ISO_CPW") ? atoi(getenv("R2S_ISO_CPW")) : 8;
+                if (cpw_env > 0) {
+                    const uint32_t cpw = (uint32_t)cpw_env, nwaves = (n_chunks + cpw - 1) / cpw;
+                    iso_project_hex_kernel<<<nwaves, 64, 0, st>>>(
+                        P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, cpw, P->erec.as<ElemRec>(), g,
+                        s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+                } else {
+                    iso_project_kernel<ElemRec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
+                        P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<ElemRec>(), g,
+                        s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+                }
+            } else {
+                iso_project_kernel<typename ET::Rec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
+                    P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
+                    s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+            }
+        }
         HIP_TRY(hipEventRecord(P->ev[6], st));
         if (want_dist && n_active) {
             A.active = P->active.as<uint32_t>(); A.n_active = n_active;
             A.sign = nullptr;
             A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
-            A.sdf_mode = 2;
+            A.sdf_mode = overlap ? 4 : 2;
+            if (overlap) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
             sdf_tiles_kernel<typename ET::Rec, true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+        } else if (overlap) {
+            HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
         }
         HIP_TRY(hipEventRecord(P->ev[4], st));
         // sign pass over the tiles whose candidate elements reach rho_t
-        if (want_sign && n_active_sign) {
+        if (!overlap && want_sign && n_active_sign) {
             A.active = P->active_sign.as<uint32_t>(); A.n_active = n_active_sign;
             A.dist = nullptr; A.xp = nullptr;
             A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
@@ -1280,6 +1464,9 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         if (hipEventElapsedTime(&ms, P->ev[6], P->ev[4]) == hipSuccess) stats->ms_gather = ms;
         stats->n_iso_chunks = n_chunks;
         if (hipEventElapsedTime(&ms, P->ev[4], P->ev[5]) == hipSuccess) stats->ms_sign = ms;
+        if (overlap) {   // stages of the second stream (they overlap ms_main)
+            if (hipEventElapsedTime(&ms, P->ev2[1], P->ev2[2]) == hipSuccess) stats->ms_sign = ms;
+        }
         (void)hipGetLastError();
     }
     return 0;
