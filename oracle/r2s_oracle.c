@@ -420,7 +420,16 @@ static int qp_pattern(int pat, const double H[3][3], const double g[3], const do
             }
         }
     }
-    if (!ok) return 2;
+    if (!ok) {
+        /* two variables fixed already: fixing the violated third one leaves no freedom for the
+         * equality, so the walk restarts from the violated bound alone */
+        const int np = *next_pat;
+        if (np >= 0 && (np % 3) && ((np / 3) % 3) && (np / 9)) {
+            for (int i = 0; i < 3; ++i)
+                if (!s[i]) *next_pat = ((np / pw[i]) % 3) * pw[i];
+        }
+        return 2;
+    }
     double Hd[3], q = 0.0;
     for (int i = 0; i < 3; ++i) {
         Hd[i] = H[i][0] * d[0] + H[i][1] * d[1] + H[i][2] * d[2];
@@ -553,7 +562,7 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
                 /* active-set walk from the previous pattern: the first pattern that is primal
                  * feasible and satisfies KKT is the minimiser of the strictly convex QP */
                 int p = pat;
-                for (int step = 0; step < 6 && p >= 0; ++step) {
+                for (int step = 0; step < 8 && p >= 0; ++step) {
                     int rc = qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt);
                     if (rc == 0) break;
                     if (rc == 1 && kkt) {

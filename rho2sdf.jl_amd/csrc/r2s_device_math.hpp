@@ -357,7 +357,17 @@ R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const d
             }
         }
     }
-    if (!ok) return 2;
+    if (!ok) {
+        // two variables fixed already: fixing the violated third one leaves no freedom for the equality,
+        // so the walk restarts from the violated bound alone
+        const int np = o.next;
+        if (np >= 0 && (np % 3) && ((np / 3) % 3) && (np / 9)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (!s[i]) o.next = ((np / pw[i]) % 3) * pw[i];
+        }
+        return 2;
+    }
     double Hd[3], q = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -410,6 +420,7 @@ R2S_DEV void iso_eval_fc(const ElemRec& E, const double x[3], double rt, const d
     c = rho - rt;
 }
 
+#define R2S_QP_WALK 8   // active-set steps before the exhaustive fallback
 #define R2S_ISO_MAXIT 60
 #define R2S_ISO_TOL 1e-8
 
@@ -509,7 +520,7 @@ R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, dou
                 // active-set walk from the previous pattern: the first pattern that is primal feasible
                 // and satisfies KKT is the minimiser of the strictly convex QP
                 int p = pat;
-                for (int step = 0; step < 6 && p >= 0; ++step) {
+                for (int step = 0; step < R2S_QP_WALK && p >= 0; ++step) {
                     const int rc = qp_pattern(p, H, gp, a, e, lo, hi, o);
                     if (rc == 0) break;
                     if (rc == 1 && o.kkt) {
@@ -731,7 +742,7 @@ R2S_DEV void iso_lane_qp(IsoLane& s)
             if (!to_fb) {
                 s.p = o.next;
                 s.step += 1;
-                to_fb = !(s.step < 6 && s.p >= 0);
+                to_fb = !(s.step < R2S_QP_WALK && s.p >= 0);
             }
             if (to_fb) { s.fb = true; s.ip = 0; s.bestq = INFINITY; }
         }

@@ -501,6 +501,43 @@ __global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __rest
     }
 }
 
+// v -> (li, lj, lk) of a box with row length bx and plane size bxy.  Float reciprocals (exact to +-1,
+// corrected) instead of two integer divisions when the box is small enough for exact float indices.
+struct BoxDecode {
+    uint32_t bx, bxy;
+    float rbx, rbxy;
+    bool small;
+};
+__device__ __forceinline__ BoxDecode box_decode_make(uint32_t bx, uint32_t by, uint32_t bz)
+{
+    BoxDecode d;
+    d.bx = bx; d.bxy = bx * by;
+    d.rbx = 1.0f / (float)bx; d.rbxy = 1.0f / (float)d.bxy;
+    d.small = (uint64_t)d.bxy * bz < (1u << 22);
+    return d;
+}
+__device__ __forceinline__ void box_decode(const BoxDecode& d, uint32_t v, uint32_t& li, uint32_t& lj, uint32_t& lk)
+{
+    if (d.small) {
+        uint32_t q = (uint32_t)((float)v * d.rbxy);
+        int32_t rem = (int32_t)(v - q * d.bxy);
+        if (rem < 0) { q -= 1; rem += (int32_t)d.bxy; }
+        else if (rem >= (int32_t)d.bxy) { q += 1; rem -= (int32_t)d.bxy; }
+        lk = q;
+        uint32_t q2 = (uint32_t)((float)rem * d.rbx);
+        int32_t r2 = rem - (int32_t)(q2 * d.bx);
+        if (r2 < 0) { q2 -= 1; r2 += (int32_t)d.bx; }
+        else if (r2 >= (int32_t)d.bx) { q2 += 1; r2 -= (int32_t)d.bx; }
+        lj = q2;
+        li = (uint32_t)r2;
+    } else {
+        lk = v / d.bxy;
+        const uint32_t rem = v - lk * d.bxy;
+        lj = rem / d.bx;
+        li = rem - lj * d.bx;
+    }
+}
+
 // HEX8 variant with lane refill (DESIGN.md "iso_project"): one wavefront works off `cpw` consecutive
 // 64-voxel chunks; every lane runs the SQP state machine of r2s_device_math.hpp (IsoLane) on its own
 // voxel and, when it has finished, takes the next voxel of the item, so that slowly converging voxels,
@@ -535,7 +572,8 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_kernel(const B
         const ElemRec& E = erec[T.el];
         const uint32_t co = chunk_off[lo], cn = chunk_off[lo + 1];
         const uint32_t seg_end = (cn < c_end) ? cn : c_end;
-        const uint32_t bx = T.dim[0], bxy = T.dim[0] * T.dim[1], vol = bxy * T.dim[2];
+        const BoxDecode dec = box_decode_make((uint32_t)T.dim[0], (uint32_t)T.dim[1], (uint32_t)T.dim[2]);
+        const uint32_t vol = dec.bxy * (uint32_t)T.dim[2];
         uint32_t next = (c - co) * 64u;
         const uint32_t v_end = ((seg_end - co) * 64u < vol) ? (seg_end - co) * 64u : vol;
         const int lo0 = T.lo[0], lo1 = T.lo[1], lo2 = T.lo[2];
@@ -577,8 +615,8 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_kernel(const B
                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
                         if (v < v_end) {
                             my = v;
-                            const uint32_t lk = v / bxy, rem = v - lk * bxy;
-                            const uint32_t lj = rem / bx, li = rem - lj * bx;
+                            uint32_t li, lj, lk;
+                            box_decode(dec, v, li, lj, lk);
                             double x[3];
                             x[0] = grid_coord(g, 0, lo0 + (int)li);
                             x[1] = grid_coord(g, 1, lo1 + (int)lj);
@@ -720,6 +758,166 @@ __global__ void sign_bin_kernel(const Rec* __restrict__ erec, uint32_t nel, Grid
             }
 }
 
+// ---- item-major inverse maps for Sign_Detection_HEX8 ----------------------------------------
+// The reference walks, per grid point, the elements whose AABB holds the point and runs the Newton
+// inverse map for each (SignDetection.jl:27-70).  Here the inverse maps are computed element-major
+// (sign_project_kernel: element record in SGPRs, lanes = lattice points of the element's AABB box, dense
+// lanes) into `sres`, and the ordered per-voxel state machine (sdf_tiles_kernel) only looks them up.
+struct alignas(16) SignBox {
+    int32_t lo[3];    // first lattice index per axis (Z: local plane of the slab)
+    int32_t dim[3];   // 0 in any axis = no box (element irrelevant for the sign pass)
+    double rmax;      // max nodal density (SignDetection.jl:33-36): all the ordered gather needs of an element
+};
+
+// lattice indices i with mn <= grid_coord(i) <= mx: exactly the reference's AABB comparisons
+__device__ __forceinline__ bool coord_range(const GridDev& g, int ax, double mn, double mx, int nmax, int& a, int& b)
+{
+    const double fa = ceil((mn - g.amin[ax]) / g.cell), fb = floor((mx - g.amin[ax]) / g.cell);
+    if (!(fa <= (double)nmax + 2.0) || !(fb >= -2.0)) return false;   // outside the grid (or NaN)
+    a = (fa < 0.0) ? 0 : ((fa > (double)nmax) ? nmax : (int)fa);
+    b = (fb > (double)nmax) ? nmax : ((fb < 0.0) ? 0 : (int)fb);
+    while (a > 0 && grid_coord(g, ax, a - 1) >= mn) --a;
+    while (a <= nmax && grid_coord(g, ax, a) < mn) ++a;
+    while (b < nmax && grid_coord(g, ax, b + 1) <= mx) ++b;
+    while (b >= 0 && grid_coord(g, ax, b) > mx) --b;
+    return a <= b;
+}
+
+// one thread per element: relevant (its tile range holds a hot tile) -> lattice box + chunk count
+__global__ void sign_box_kernel(const ElemRec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s,
+                                const uint8_t* __restrict__ hot, SignBox* __restrict__ sbox,
+                                uint32_t* __restrict__ nchunks)
+{
+    const uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
+    if (el >= nel) return;
+    SignBox B;
+    memset(&B, 0, sizeof B);
+    const ElemRec& E = erec[el];
+    int lo[3], hi[3];
+    bool rel = false;
+    if (sign_tile_range(E, g, s, lo, hi)) {
+        for (int tz = lo[2]; tz <= hi[2] && !rel; ++tz)
+            for (int ty = lo[1]; ty <= hi[1] && !rel; ++ty)
+                for (int tx = lo[0]; tx <= hi[0]; ++tx)
+                    if (hot[((uint32_t)tz * s.nty + ty) * s.ntx + tx]) { rel = true; break; }
+    }
+    if (rel) {
+        const int nmax[3] = {g.nx - 1, g.ny - 1, g.nz - 1};
+        uint64_t vol = 1;
+        for (int ax = 0; ax < 3; ++ax) {
+            int a = 0, b = -1;
+            if (coord_range(g, ax, E.mn[ax], E.mx[ax], nmax[ax], a, b)) {
+                if (ax == 2) {   // Z in LOCAL planes of the slab
+                    int la, lb;
+                    if (slab_local_range(s, a, b, la, lb)) { a = la; b = lb; }
+                    else { a = 0; b = -1; }
+                }
+            } else { a = 0; b = -1; }
+            B.lo[ax] = a;
+            B.dim[ax] = (b >= a) ? (b - a + 1) : 0;
+            vol *= (uint64_t)B.dim[ax];
+        }
+        if (vol == 0) B.dim[0] = B.dim[1] = B.dim[2] = 0;
+        nchunks[el] = (uint32_t)((vol + 63) / 64);
+    }
+    B.rmax = E.rmax;
+    sbox[el] = B;
+}
+
+// one wavefront per `cpw` chunks (64 lattice points each) of the boxes.  64 points at a time are tested
+// (hot tile, inside the element's bounding half-spaces - ElemRec::pn; the others cannot pass the
+// max|xi| < 1.01 test); the survivors are compacted through a small LDS queue and the Newton inverse
+// maps run on full wavefronts.  Stored per slot: +m when the interpolated density reaches rho_t, -m when
+// it does not, +inf when the candidate has no effect.
+__global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restrict__ sbox, uint32_t nel,
+                                                          const uint32_t* __restrict__ chunk_off, uint32_t nchunks,
+                                                          uint32_t cpw, const ElemRec* __restrict__ erec, GridDev g,
+                                                          SlabInfo sl, double rho_t, const uint8_t* __restrict__ hot,
+                                                          double* __restrict__ res)
+{
+    __shared__ uint32_t queue[128];
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    uint32_t c = w * cpw;
+    if (c >= nchunks) return;
+    const uint32_t c_end = (c + cpw < nchunks) ? c + cpw : nchunks;
+    uint32_t lo = 0, hi = nel;   // last element with chunk_off[el] <= c
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunk_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    while (c < c_end) {
+        lo = __builtin_amdgcn_readfirstlane(lo);
+        const SignBox& B = sbox[lo];
+        const ElemRec& E = erec[lo];
+        const uint32_t co = chunk_off[lo], cn = chunk_off[lo + 1];
+        const uint32_t seg_end = (cn < c_end) ? cn : c_end;
+        const BoxDecode dec = box_decode_make((uint32_t)B.dim[0], (uint32_t)B.dim[1], (uint32_t)B.dim[2]);
+        const uint32_t vol = dec.bxy * (uint32_t)B.dim[2];
+        const uint32_t v_begin = (c - co) * 64u;
+        const uint32_t v_end = ((seg_end - co) * 64u < vol) ? (seg_end - co) * 64u : vol;
+        const int lo0 = B.lo[0], lo1 = B.lo[1], lo2 = B.lo[2];
+        const size_t base = (size_t)co * 64u;
+        uint32_t qn = 0;   // wave-uniform queue length
+        for (uint32_t v0 = v_begin; v0 < v_end || qn > 0; v0 += 64u) {
+            if (v0 < v_end) {
+                const uint32_t v = v0 + lane;
+                bool pass = false;
+                if (v < v_end) {
+                    uint32_t li, lj, lk;
+                    box_decode(dec, v, li, lj, lk);
+                    const int i = lo0 + (int)li, j = lo1 + (int)lj, kl = lo2 + (int)lk;
+                    double x[3];
+                    x[0] = grid_coord(g, 0, i);
+                    x[1] = grid_coord(g, 1, j);
+                    x[2] = grid_coord(g, 2, slab_global_k(sl, kl));
+                    const uint32_t t = ((uint32_t)(kl >> 2) * sl.nty + (uint32_t)(j >> 2)) * sl.ntx + (uint32_t)(i >> 2);
+                    pass = hot[t] && !hex8_outside(E, x);
+                    if (!pass) res[base + v] = INFINITY;
+                }
+                const uint64_t m = __ballot(pass);
+                if (pass) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = v;
+                qn += (uint32_t)__popcll(m);
+                __syncthreads();
+            }
+            // a full wavefront of survivors (or the rest once the segment's points are exhausted)
+            if (qn >= 64u || (v0 + 64u >= v_end && qn > 0)) {
+                const uint32_t take = qn < 64u ? qn : 64u;
+                const bool have = lane < take;
+                const uint32_t v = queue[lane];
+                const uint32_t spill = queue[64u + lane];
+                __syncthreads();
+                if (lane + 64u < qn) queue[lane] = spill;
+                qn -= take;
+                __syncthreads();
+                if (have) {
+                    uint32_t li, lj, lk;
+                    box_decode(dec, v, li, lj, lk);
+                    double x[3], xi[3], N[8];
+                    x[0] = grid_coord(g, 0, lo0 + (int)li);
+                    x[1] = grid_coord(g, 1, lo1 + (int)lj);
+                    x[2] = grid_coord(g, 2, slab_global_k(sl, lo2 + (int)lk));
+                    inv_map_hex8(E, x, xi);
+                    const double m = fmax(fabs(xi[0]), fmax(fabs(xi[1]), fabs(xi[2])));
+                    double val = INFINITY;
+                    if (m < 1.01) {
+                        hex8_shape(xi, N);
+                        double rho = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) rho += N[k] * E.r[k];
+                        val = (rho >= rho_t) ? m : -m;
+                    }
+                    res[base + v] = val;
+                }
+            }
+        }
+        c = seg_end;
+        if (c < c_end) {
+            do { ++lo; } while (chunk_off[lo + 1] <= c);
+        }
+    }
+}
+
 // active tiles = tiles with a non-empty band list, or a sign list whose elements reach rho_t
 #define AT_ITEMS 8   // tiles per thread
 __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __restrict__ band_cnt,
@@ -856,6 +1054,10 @@ struct MainArgs {
     double* xp;
     const double* iso_res;     // per (iso item, box voxel) distances from iso_project_kernel
     const double* iso_res_xp;  // projection points (only when xp is requested)
+    const void* sbox;          // HEX8: per-element boxes / chunk offsets / results of sign_project_kernel
+    const uint32_t* s_chunk_off;
+    const double* sres;
+    const uint8_t* hot;        // per tile: some candidate reaches rho_t
     int sdf_mode;  // 1: sdf = dist*sign in one kernel; 2: dist pass stores -dist; 3: sign pass flips;
                    // 4: dist pass after the sign pass (keeps the sign already stored)
 };
@@ -915,31 +1117,50 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
         const uint32_t b = A.sign_off[t], e = A.sign_off[t + 1];
         if constexpr (std::is_same<Rec, ElemRec>::value) {
             // Sign_Detection_HEX8 (SignDetection.jl:27-70): wave-uniform walk over the tile's candidate
-            // list (element record in SGPRs).  A per-lane walk with LDS-staged candidates was measured
-            // slower (register pressure halves the occupancy of this latency-bound Newton chain).
-            bool any = false;
-            double cmax = -INFINITY;
-            for (uint32_t p = b; p < e; ++p) {
-                const ElemRec& E = erec[A.sign_ent[p]];
-                const bool in = E.mn[0] <= x[0] && E.mn[1] <= x[1] && E.mn[2] <= x[2] && x[0] <= E.mx[0] &&
-                                x[1] <= E.mx[1] && x[2] <= E.mx[2];
-                if (in) {
-                    any = true;
-                    if (E.rmax > cmax) cmax = E.rmax;
+            // list in ascending element order; the inverse maps were computed item-major by
+            // sign_project_kernel, so a visit is a lookup.  The state machine (:41-70) runs while the
+            // candidates' max density is collected; the test of :36 is applied at the end (same result).
+            if (A.hot[t]) {
+                const SignBox* __restrict__ sbox = static_cast<const SignBox*>(A.sbox);
+                bool any = false, done = false;
+                double cmax = -INFINITY, max_local = 10.0;
+                // four candidates per trip: their records and lookups are independent loads (issued together),
+                // the state machine then consumes them in order.  "Point inside the element's AABB"
+                // (SignDetection.jl:30) == "lattice index inside the element's box" by construction of the box.
+                for (uint32_t p = b; p < e; p += 4) {
+                    uint32_t el[4], co[4];
+                    SignBox B[4];
+                    bool in[4];
+                    double v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) el[q] = A.sign_ent[(p + q < e) ? p + q : e - 1];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { B[q] = sbox[el[q]]; co[q] = A.s_chunk_off[el[q]]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t di = (uint32_t)(i - B[q].lo[0]), dj = (uint32_t)(j - B[q].lo[1]),
+                                       dk = (uint32_t)(kl - B[q].lo[2]);
+                        in[q] = valid && (p + q < e) && di < (uint32_t)B[q].dim[0] && dj < (uint32_t)B[q].dim[1] &&
+                                dk < (uint32_t)B[q].dim[2];
+                        v[q] = INFINITY;
+                        if (in[q])
+                            v[q] = A.sres[(size_t)co[q] * 64u + ((size_t)dk * B[q].dim[1] + dj) * B[q].dim[0] + di];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (in[q]) {
+                            any = true;
+                            if (B[q].rmax > cmax) cmax = B[q].rmax;
+                            const double m = fabs(v[q]);
+                            if (!done && m < 1.01 && max_local > m) {
+                                if (!__builtin_signbit(v[q])) sg = 1.0;
+                                if (m < 0.95) done = true;
+                                else max_local = m;
+                            }
+                        }
+                    }
                 }
-            }
-            bool go = valid && any && !(cmax < A.rho_t);  // SignDetection.jl:36
-            double max_local = 10.0;
-            bool done = false;
-            if (__any(go)) {
-                for (uint32_t p = b; p < e; ++p) {
-                    const ElemRec& E = erec[A.sign_ent[p]];
-                    // AABB test of the reference, then the exact half-space pruning (ElemRec::pn): a voxel
-                    // outside the inflated element cannot pass sign_visit's max|xi| < 1.01 test
-                    const bool in = go && !done && E.mn[0] <= x[0] && E.mn[1] <= x[1] && E.mn[2] <= x[2] &&
-                                    x[0] <= E.mx[0] && x[1] <= E.mx[1] && x[2] <= E.mx[2] && !hex8_outside(E, x);
-                    if (in) sign_visit(E, A.rho_t, x, max_local, sg, done);
-                }
+                if (!(any && !(cmax < A.rho_t))) sg = -1.0;   // SignDetection.jl:36
             }
         } else {
             // Sign_Detection_TET4 (SignDetection.jl:116-151): bin index of the point (:258-268),
@@ -1034,16 +1255,17 @@ struct r2s_plan {
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
     DevBuf active, active_sign, active_any, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
+    DevBuf sbox, s_nchunks, s_chunk_off, sres;   // item-major inverse maps of the sign pass (HEX8)
     // state of the last run, for r2s_plan_pack_tiles_dev
     SlabInfo last_s;
     GridDev last_g;
     uint32_t last_n_any = 0;
     bool has_last = false;
     uint32_t* h_pinned = nullptr;  // 16 words
-    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // second stream: sentinel sweep + sign pass run beside the iso-surface projection (fused SDF output)
     hipStream_t st2 = nullptr;
-    hipEvent_t ev2[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev2[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 static int scan_exclusive(r2s_plan* P, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st, int level = 0)
@@ -1161,8 +1383,8 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     r2s_plan* P = new r2s_plan();
     P->device = device;
     HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocDefault));
-    for (int i = 0; i < 7; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
-    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
+    for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
     {
         // lowest priority: the sign pass fills the wave slots the projection kernel leaves free and its tail
         // (measured: equal priority 9.1 ms/step, high 9.6, low 8.5 on the north-star workload)
@@ -1183,12 +1405,13 @@ void r2s_plan_destroy(r2s_plan* P)
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
                      &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any,
                      &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp,
+                     &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
     for (DevBuf* b : all) b->release();
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < 8; ++i)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i)
         if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
     if (P->st2) (void)hipStreamDestroy(P->st2);
     delete P;
@@ -1274,6 +1497,18 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] band tiles, [2] sign tiles
 
     HIP_TRY(hipEventRecord(P->ev[0], st));
+    // ---- sentinel sweep: on the second stream, beside the mesh preparation and the binning ----
+    // (HBM-bound, needs only the outputs; the first kernel that writes a voxel waits for ev2[3])
+    {
+        const unsigned fill_grid = 256 * 8;
+        HIP_TRY(hipStreamWaitEvent(P->st2, P->ev[0], 0));
+        HIP_TRY(hipEventRecord(P->ev2[0], P->st2));
+        if (mode & R2S_OUT_DIST) fill_kernel<<<fill_grid, 256, 0, P->st2>>>(d_dist, nvox, 1.0e10);
+        if (mode & R2S_OUT_SIGN) fill_kernel<<<fill_grid, 256, 0, P->st2>>>(d_sign, nvox, -1.0);
+        if (mode & R2S_OUT_SDF) fill_kernel<<<fill_grid, 256, 0, P->st2>>>(d_sdf, nvox, -1.0e10);
+        if (mode & R2S_OUT_XP) HIP_TRY(hipMemsetAsync(d_xp, 0, sizeof(double) * 3 * (size_t)nvox, P->st2));
+        HIP_TRY(hipEventRecord(P->ev2[3], P->st2));
+    }
     // ---- node -> element CSR ----
     HIP_TRY(hipMemsetAsync(P->deg.p, 0, sizeof(uint32_t) * (size_t)(nnp + 1), st));
     HIP_TRY(hipMemsetAsync(P->cursor.p, 0, sizeof(uint32_t) * (size_t)(nnp + 1), st));
@@ -1328,6 +1563,21 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         rc = scan_exclusive(P, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
         if (rc) return rc;
     }
+    constexpr bool HEX = std::is_same<typename ET::Rec, ElemRec>::value;
+    const bool sign_items = HEX && want_sign && nel > 0;
+    if constexpr (HEX) {
+        if (sign_items) {
+            // boxes of the elements that can be candidates in a hot tile (hot[] is complete after the count pass)
+            ENSURE(P->sbox, sizeof(SignBox) * (size_t)nel);
+            ENSURE(P->s_nchunks, sizeof(uint32_t) * (size_t)(nel + 1));
+            ENSURE(P->s_chunk_off, sizeof(uint32_t) * (size_t)(nel + 1));
+            HIP_TRY(hipMemsetAsync(P->s_nchunks.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
+            sign_box_kernel<<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>());
+            int rc = scan_exclusive(P, P->s_nchunks.as<uint32_t>(), P->s_chunk_off.as<uint32_t>(), nel + 1, st);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(&P->h_pinned[11], P->s_chunk_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
+        }
+    }
     active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), counters);
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[2], P->band_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[3], P->sign_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
@@ -1338,6 +1588,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     P->last_s = s; P->last_g = g; P->last_n_any = P->h_pinned[8]; P->has_last = true;
     const uint32_t n_chunks = n_items ? P->h_pinned[10] : 0;
     ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_chunks, 1));
+    const uint32_t n_schunks = sign_items ? P->h_pinned[11] : 0;
+    if (sign_items) ENSURE(P->sres, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_schunks, 1));
     if (mode & R2S_OUT_XP) ENSURE(P->iso_res_xp, sizeof(double) * 192 * (size_t)std::max<uint32_t>(n_chunks, 1));
     ENSURE(P->band_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
     ENSURE(P->band_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
@@ -1362,19 +1614,16 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     }
     HIP_TRY(hipEventRecord(P->ev[2], st));
 
-    // ---- sentinel sweep ----
+    // ---- fork ----
     // Fused SDF output only: after the sweep the sign pass goes to a second stream and runs beside the iso-surface
     // projection (both are latency-bound FP64 chains; together they fill the SIMDs better); the ordered
     // gather then waits for both and keeps the sign already stored.
     static const bool overlap_env = !(getenv("R2S_NO_OVERLAP") && atoi(getenv("R2S_NO_OVERLAP")));
-    const bool overlap = overlap_env && mode == R2S_OUT_SDF && want_sign && want_dist;
-    const unsigned fill_grid = 256 * 8;
-    if (mode & R2S_OUT_DIST) fill_kernel<<<fill_grid, 256, 0, st>>>(d_dist, nvox, 1.0e10);
-    if (mode & R2S_OUT_SIGN) fill_kernel<<<fill_grid, 256, 0, st>>>(d_sign, nvox, -1.0);
-    if (mode & R2S_OUT_SDF) fill_kernel<<<fill_grid, 256, 0, st>>>(d_sdf, nvox, -1.0e10);
-    if (mode & R2S_OUT_XP) HIP_TRY(hipMemsetAsync(d_xp, 0, sizeof(double) * 3 * (size_t)nvox, st));
+    const bool overlap = !HEX && overlap_env && mode == R2S_OUT_SDF && want_sign && want_dist;   // TET4 flow
+    const bool fork = HEX && overlap_env && want_sign && want_dist && n_chunks && n_schunks;      // HEX8 flow
+    HIP_TRY(hipStreamWaitEvent(st, P->ev2[3], 0));   // the sweep (second stream, started with the preparation)
     HIP_TRY(hipEventRecord(P->ev[3], st));
-    if (overlap) {   // fork: the sign pass follows the sweep on the second stream
+    if (overlap || fork) {   // fork: the sign pass follows the sweep on the second stream
         HIP_TRY(hipStreamWaitEvent(P->st2, P->ev[3], 0));
         HIP_TRY(hipEventRecord(P->ev2[1], P->st2));
     }
@@ -1389,58 +1638,101 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         A.dist = (mode & R2S_OUT_DIST) ? d_dist : nullptr;
         A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
         A.sdf = (mode & R2S_OUT_SDF) ? d_sdf : nullptr;
-        if (overlap) {
-            if (n_active_sign) {
-                MainArgs B = A;
-                B.active = P->active_sign.as<uint32_t>(); B.n_active = n_active_sign;
-                B.dist = nullptr; B.xp = nullptr; B.sign = nullptr;
-                B.sdf_mode = 3;
-                // one-wave workgroups: they take freed wave slots as readily as the projection kernel's
-                sdf_tiles_kernel<typename ET::Rec, false, true><<<n_active_sign, 64, 0, P->st2>>>(B);
+        A.sbox = P->sbox.p; A.s_chunk_off = P->s_chunk_off.as<uint32_t>(); A.sres = P->sres.as<double>();
+        A.hot = P->hot.as<uint8_t>();
+        if constexpr (HEX) {
+            // inverse maps of the sign pass (item-major), beside the iso-surface projection when both run
+            hipStream_t ss = fork ? P->st2 : st;
+            if (!fork) HIP_TRY(hipEventRecord(P->ev2[1], ss));
+            if (want_sign && n_schunks) {
+                static const int scpw_env = getenv("R2S_SIGN_CPW") ? atoi(getenv("R2S_SIGN_CPW")) : 8;
+                const uint32_t cpw = (uint32_t)(scpw_env > 0 ? scpw_env : 8), nwaves = (n_schunks + cpw - 1) / cpw;
+                sign_project_kernel<<<nwaves, 64, 0, ss>>>(P->sbox.as<SignBox>(), (uint32_t)nel, P->s_chunk_off.as<uint32_t>(), n_schunks, cpw,
+                                                          P->erec.as<ElemRec>(), g, s, rho_t, P->hot.as<uint8_t>(), P->sres.as<double>());
             }
-            HIP_TRY(hipEventRecord(P->ev2[2], P->st2));
-        }
-        // item-major iso-surface projections, then the ordered gather over the band tiles
-        A.iso_res = P->iso_res.as<double>();
-        A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
-        if (want_dist && n_chunks) {
-            if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
+            HIP_TRY(hipEventRecord(P->ev2[2], ss));
+            A.iso_res = P->iso_res.as<double>();
+            A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
+            HIP_TRY(hipEventRecord(P->ev[7], st));
+            if (want_dist && n_chunks) {
                 static const int cpw_env = getenv("R2S_ISO_CPW") ? atoi(getenv("R2S_ISO_CPW")) : 8;
-                if (cpw_env > 0) {
-                    const uint32_t cpw = (uint32_t)cpw_env, nwaves = (n_chunks + cpw - 1) / cpw;
-                    iso_project_hex_kernel<<<nwaves, 64, 0, st>>>(
-                        P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, cpw, P->erec.as<ElemRec>(), g,
-                        s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
-                } else {
-                    iso_project_kernel<ElemRec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
-                        P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<ElemRec>(), g,
-                        s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
-                }
-            } else {
-                iso_project_kernel<typename ET::Rec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
-                    P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
+                const uint32_t cpw = (uint32_t)(cpw_env > 0 ? cpw_env : 8), nwaves = (n_chunks + cpw - 1) / cpw;
+                iso_project_hex_kernel<<<nwaves, 64, 0, st>>>(
+                    P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, cpw, P->erec.as<ElemRec>(), g,
                     s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
             }
-        }
-        HIP_TRY(hipEventRecord(P->ev[6], st));
-        if (want_dist && n_active) {
-            A.active = P->active.as<uint32_t>(); A.n_active = n_active;
-            A.sign = nullptr;
+            HIP_TRY(hipEventRecord(P->ev[6], st));
+            if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
+            // ordered per-voxel gather: band items (distance) and candidate elements (sign) of every tile
             A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
-            A.sdf_mode = overlap ? 4 : 2;
-            if (overlap) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
-            sdf_tiles_kernel<typename ET::Rec, true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
-        } else if (overlap) {
-            HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
-        }
-        HIP_TRY(hipEventRecord(P->ev[4], st));
-        // sign pass over the tiles whose candidate elements reach rho_t
-        if (!overlap && want_sign && n_active_sign) {
-            A.active = P->active_sign.as<uint32_t>(); A.n_active = n_active_sign;
-            A.dist = nullptr; A.xp = nullptr;
-            A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
-            A.sdf_mode = 3;
-            sdf_tiles_kernel<typename ET::Rec, false, true><<<(n_active_sign + 3) / 4, 256, 0, st>>>(A);
+            A.sdf_mode = 1;
+            if (want_dist && want_sign) {
+                const uint32_t n_any = P->h_pinned[8];
+                A.active = P->active_any.as<uint32_t>(); A.n_active = n_any;
+                if (n_any) sdf_tiles_kernel<ElemRec, true, true><<<(n_any + 3) / 4, 256, 0, st>>>(A);
+            } else if (want_dist) {
+                A.active = P->active.as<uint32_t>(); A.n_active = n_active;
+                if (n_active) sdf_tiles_kernel<ElemRec, true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+            } else if (want_sign) {
+                A.active = P->active_sign.as<uint32_t>(); A.n_active = n_active_sign;
+                if (n_active_sign) sdf_tiles_kernel<ElemRec, false, true><<<(n_active_sign + 3) / 4, 256, 0, st>>>(A);
+            }
+            HIP_TRY(hipEventRecord(P->ev[4], st));
+        } else {
+            HIP_TRY(hipEventRecord(P->ev[7], st));
+            if (overlap) {
+                if (n_active_sign) {
+                    MainArgs B = A;
+                    B.active = P->active_sign.as<uint32_t>(); B.n_active = n_active_sign;
+                    B.dist = nullptr; B.xp = nullptr; B.sign = nullptr;
+                    B.sdf_mode = 3;
+                    // one-wave workgroups: they take freed wave slots as readily as the projection kernel's
+                    sdf_tiles_kernel<typename ET::Rec, false, true><<<n_active_sign, 64, 0, P->st2>>>(B);
+                }
+                HIP_TRY(hipEventRecord(P->ev2[2], P->st2));
+            }
+            // item-major iso-surface projections, then the ordered gather over the band tiles
+            A.iso_res = P->iso_res.as<double>();
+            A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
+            if (want_dist && n_chunks) {
+                if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
+                    static const int cpw_env = getenv("R2S_ISO_CPW") ? atoi(getenv("R2S_ISO_CPW")) : 8;
+                    if (cpw_env > 0) {
+                        const uint32_t cpw = (uint32_t)cpw_env, nwaves = (n_chunks + cpw - 1) / cpw;
+                        iso_project_hex_kernel<<<nwaves, 64, 0, st>>>(
+                            P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, cpw, P->erec.as<ElemRec>(), g,
+                            s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+                    } else {
+                        iso_project_kernel<ElemRec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
+                            P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<ElemRec>(), g,
+                            s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+                    }
+                } else {
+                    iso_project_kernel<typename ET::Rec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
+                        P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
+                        s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+                }
+            }
+            HIP_TRY(hipEventRecord(P->ev[6], st));
+            if (want_dist && n_active) {
+                A.active = P->active.as<uint32_t>(); A.n_active = n_active;
+                A.sign = nullptr;
+                A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
+                A.sdf_mode = overlap ? 4 : 2;
+                if (overlap) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
+                sdf_tiles_kernel<typename ET::Rec, true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+            } else if (overlap) {
+                HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
+            }
+            HIP_TRY(hipEventRecord(P->ev[4], st));
+            // sign pass over the tiles whose candidate elements reach rho_t
+            if (!overlap && want_sign && n_active_sign) {
+                A.active = P->active_sign.as<uint32_t>(); A.n_active = n_active_sign;
+                A.dist = nullptr; A.xp = nullptr;
+                A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
+                A.sdf_mode = 3;
+                sdf_tiles_kernel<typename ET::Rec, false, true><<<(n_active_sign + 3) / 4, 256, 0, st>>>(A);
+            }
         }
     }
     HIP_TRY(hipEventRecord(P->ev[5], st));
@@ -1459,12 +1751,12 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         float ms = 0;
         if (hipEventElapsedTime(&ms, P->ev[0], P->ev[1]) == hipSuccess) stats->ms_prep = ms;
         if (hipEventElapsedTime(&ms, P->ev[1], P->ev[2]) == hipSuccess) stats->ms_bins = ms;
-        if (hipEventElapsedTime(&ms, P->ev[2], P->ev[3]) == hipSuccess) stats->ms_fill = ms;
-        if (hipEventElapsedTime(&ms, P->ev[3], P->ev[6]) == hipSuccess) stats->ms_main = ms;
+        if (hipEventElapsedTime(&ms, P->ev2[0], P->ev2[3]) == hipSuccess) stats->ms_fill = ms;   // beside prep + bins
+        if (hipEventElapsedTime(&ms, P->ev[7], P->ev[6]) == hipSuccess) stats->ms_main = ms;
         if (hipEventElapsedTime(&ms, P->ev[6], P->ev[4]) == hipSuccess) stats->ms_gather = ms;
         stats->n_iso_chunks = n_chunks;
         if (hipEventElapsedTime(&ms, P->ev[4], P->ev[5]) == hipSuccess) stats->ms_sign = ms;
-        if (overlap) {   // stages of the second stream (they overlap ms_main)
+        if (overlap || HEX) {   // sign stage on its own events (second stream: it overlaps ms_main)
             if (hipEventElapsedTime(&ms, P->ev2[1], P->ev2[2]) == hipSuccess) stats->ms_sign = ms;
         }
         (void)hipGetLastError();
