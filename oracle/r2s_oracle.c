@@ -233,6 +233,12 @@ static void hex8_monomials(double Xe[16][3], double re[16])
 }
 
 /* value and first derivatives of one scalar trilinear field with coefficients c[0..7] (stride st) */
+/* a0 b0 + a1 b1 + a2 b2 with a fixed fused evaluation order (one multiply, two FMAs) */
+static inline double dot3(double a0, double a1, double a2, double b0, double b1, double b2)
+{
+    return fma(a2, b2, fma(a1, b1, a0 * b0));
+}
+
 typedef struct { double v, d1, d2, d3, m12, m13, m23; } tri_eval;
 static inline tri_eval tri_eval_full(const double *c, int st, const double xi[3])
 {
@@ -286,20 +292,22 @@ static int inv_map_hex8(const double Xe[16][3] /* nodes + monomials */, const do
             R[i] = t.v - x[i];
             J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
         }
-        /* delta = -J^{-1} R by the adjugate */
-        double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-        double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-        double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-        double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-        double c10 = J[0][2] * J[2][1] - J[0][1] * J[2][2];
-        double c11 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
-        double c12 = J[0][1] * J[2][0] - J[0][0] * J[2][1];
-        double c20 = J[0][1] * J[1][2] - J[0][2] * J[1][1];
-        double c21 = J[0][2] * J[1][0] - J[0][0] * J[1][2];
-        double c22 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-        double d0 = -(c00 * R[0] + c10 * R[1] + c20 * R[2]) / det;
-        double d1 = -(c01 * R[0] + c11 * R[1] + c21 * R[2]) / det;
-        double d2 = -(c02 * R[0] + c12 * R[1] + c22 * R[2]) / det;
+        /* delta = -J^{-1} R by the adjugate; every a*b - c*d is fma(a, b, -(c*d)), sums of three
+         * products are dot3: the GPU kernels perform the identical IEEE operations */
+        double c00 = fma(J[1][1], J[2][2], -(J[1][2] * J[2][1]));
+        double c01 = fma(J[1][2], J[2][0], -(J[1][0] * J[2][2]));
+        double c02 = fma(J[1][0], J[2][1], -(J[1][1] * J[2][0]));
+        double det = dot3(J[0][0], J[0][1], J[0][2], c00, c01, c02);
+        double c10 = fma(J[0][2], J[2][1], -(J[0][1] * J[2][2]));
+        double c11 = fma(J[0][0], J[2][2], -(J[0][2] * J[2][0]));
+        double c12 = fma(J[0][1], J[2][0], -(J[0][0] * J[2][1]));
+        double c20 = fma(J[0][1], J[1][2], -(J[0][2] * J[1][1]));
+        double c21 = fma(J[0][2], J[1][0], -(J[0][0] * J[1][2]));
+        double c22 = fma(J[0][0], J[1][1], -(J[0][1] * J[1][0]));
+        double rdet = 1.0 / det;
+        double d0 = -dot3(c00, c10, c20, R[0], R[1], R[2]) * rdet;
+        double d1 = -dot3(c01, c11, c21, R[0], R[1], R[2]) * rdet;
+        double d2 = -dot3(c02, c12, c22, R[0], R[1], R[2]) * rdet;
         double n0 = fmin(fmax(xi[0] + d0, -1.1), 1.1);
         double n1 = fmin(fmax(xi[1] + d1, -1.1), 1.1);
         double n2 = fmin(fmax(xi[2] + d2, -1.1), 1.1);
@@ -347,13 +355,10 @@ static inline iso_fc iso_eval_fc(const double x[3], const double Xe[8][3], const
                                  double rt, const double xi[3])
 {
     iso_fc o;
-    double f = 0.0;
-    for (int i = 0; i < 3; ++i) {
-        double r = x[i] - tri_eval_value(&Xe[8][i], 3, xi);
-        f += r * r;
-    }
+    double r[3];
+    for (int i = 0; i < 3; ++i) r[i] = x[i] - tri_eval_value(&Xe[8][i], 3, xi);
     double rho = tri_eval_value(&re[8], 1, xi);
-    o.f = f;
+    o.f = dot3(r[0], r[1], r[2], r[0], r[1], r[2]);
     o.c = rho - rt;
     return o;
 }
@@ -374,44 +379,48 @@ static int qp_pattern(int pat, const double H[3][3], const double g[3], const do
     double ep = e;
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
-            ep -= a[i] * dB[i];
+            ep = fma(-a[i], dB[i], ep);
             aa[i] = 0.0;
             b[i] = 0.0;
         } else {
             aa[i] = a[i];
             double t = -g[i];
             for (int j = 0; j < 3; ++j)
-                if (s[j]) t -= H[i][j] * dB[j];
+                if (s[j]) t = fma(-H[i][j], dB[j], t);
             b[i] = t;
         }
         for (int j = 0; j < 3; ++j)
             M[i][j] = (s[i] || s[j]) ? ((i == j) ? 1.0 : 0.0) : H[i][j];
     }
-    /* LDL^T of the masked (SPD) matrix */
-    /* pivots are inverted once and multiplied (3 divisions instead of 9) */
-    double D0 = M[0][0], r0 = 1.0 / D0;
-    double l10 = M[1][0] * r0, l20 = M[2][0] * r0;
-    double D1 = M[1][1] - l10 * M[1][0], r1 = 1.0 / D1;
-    double l21 = (M[2][1] - l20 * M[1][0]) * r1;
-    double D2 = M[2][2] - l20 * M[2][0] - l21 * l21 * D1, r2 = 1.0 / D2;
-    if (!(D0 > 0.0 && D1 > 0.0 && D2 > 0.0)) return 0;
+    /* inverse of the masked symmetric matrix by its adjugate (one division); the leading minors
+     * double as the positive-definiteness test (Sylvester) */
+    const double M00 = M[0][0], M01 = M[0][1], M02 = M[0][2], M11 = M[1][1], M12 = M[1][2], M22 = M[2][2];
+    const double c00 = fma(M11, M22, -(M12 * M12));
+    const double c01 = fma(M02, M12, -(M01 * M22));
+    const double c02 = fma(M01, M12, -(M02 * M11));
+    const double c11 = fma(M00, M22, -(M02 * M02));
+    const double c12 = fma(M01, M02, -(M00 * M12));
+    const double c22 = fma(M00, M11, -(M01 * M01));
+    const double det = dot3(M00, M01, M02, c00, c01, c02);
+    if (!(M00 > 0.0 && c22 > 0.0 && det > 0.0)) return 0;
+    const double rdet = 1.0 / det;
     double u[3], v[3];
-    /* forward */
-    u[0] = aa[0]; u[1] = aa[1] - l10 * u[0]; u[2] = aa[2] - l20 * u[0] - l21 * u[1];
-    v[0] = b[0];  v[1] = b[1] - l10 * v[0];  v[2] = b[2] - l20 * v[0] - l21 * v[1];
-    /* diagonal + backward */
-    u[2] = u[2] * r2; u[1] = u[1] * r1 - l21 * u[2]; u[0] = u[0] * r0 - l10 * u[1] - l20 * u[2];
-    v[2] = v[2] * r2; v[1] = v[1] * r1 - l21 * v[2]; v[0] = v[0] * r0 - l10 * v[1] - l20 * v[2];
-    double den = aa[0] * u[0] + aa[1] * u[1] + aa[2] * u[2];
+    u[0] = dot3(c00, c01, c02, aa[0], aa[1], aa[2]) * rdet;
+    u[1] = dot3(c01, c11, c12, aa[0], aa[1], aa[2]) * rdet;
+    u[2] = dot3(c02, c12, c22, aa[0], aa[1], aa[2]) * rdet;
+    v[0] = dot3(c00, c01, c02, b[0], b[1], b[2]) * rdet;
+    v[1] = dot3(c01, c11, c12, b[0], b[1], b[2]) * rdet;
+    v[2] = dot3(c02, c12, c22, b[0], b[1], b[2]) * rdet;
+    double den = dot3(aa[0], aa[1], aa[2], u[0], u[1], u[2]);
     if (!(den > 0.0)) return 0;
-    double lam = (aa[0] * v[0] + aa[1] * v[1] + aa[2] * v[2] - ep) / den;
+    double lam = (dot3(aa[0], aa[1], aa[2], v[0], v[1], v[2]) - ep) / den;
     int ok = 1;
     double worst = 0.0;
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
             d[i] = dB[i];
         } else {
-            d[i] = v[i] - lam * u[i];
+            d[i] = fma(-lam, u[i], v[i]);
             if (!(d[i] >= lo[i] - QP_PTOL && d[i] <= hi[i] + QP_PTOL)) {
                 ok = 0;
                 double below = (lo[i] - QP_PTOL) - d[i], above = d[i] - (hi[i] + QP_PTOL);
@@ -432,14 +441,14 @@ static int qp_pattern(int pat, const double H[3][3], const double g[3], const do
     }
     double Hd[3], q = 0.0;
     for (int i = 0; i < 3; ++i) {
-        Hd[i] = H[i][0] * d[0] + H[i][1] * d[1] + H[i][2] * d[2];
-        q += d[i] * (0.5 * Hd[i] + g[i]);
+        Hd[i] = dot3(H[i][0], H[i][1], H[i][2], d[0], d[1], d[2]);
+        q = fma(d[i], fma(0.5, Hd[i], g[i]), q);
     }
     int kkt = 1;
     worst = 0.0;
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
-            double z = Hd[i] + g[i] + lam * a[i];
+            double z = fma(lam, a[i], Hd[i] + g[i]);
             double viol = (s[i] == 1) ? -z : z;
             if (s[i] == 1 && !(z >= 0.0)) kkt = 0;
             if (s[i] == 2 && !(z <= 0.0)) kkt = 0;
@@ -454,14 +463,13 @@ static int qp_pattern(int pat, const double H[3][3], const double g[3], const do
 
 static int spd3(const double H[3][3], double floor_)
 {
-    double D0 = H[0][0];
-    if (!(D0 > floor_)) return 0;
-    double l10 = H[1][0] / D0, l20 = H[2][0] / D0;
-    double D1 = H[1][1] - l10 * H[1][0];
-    if (!(D1 > floor_)) return 0;
-    double l21 = (H[2][1] - l20 * H[1][0]) / D1;
-    double D2 = H[2][2] - l20 * H[2][0] - l21 * l21 * D1;
-    return D2 > floor_;
+    /* Sylvester's criterion on the (symmetric) matrix: leading minors, no division */
+    const double c00 = fma(H[1][1], H[2][2], -(H[1][2] * H[1][2]));
+    const double c01 = fma(H[0][2], H[1][2], -(H[0][1] * H[2][2]));
+    const double c02 = fma(H[0][1], H[1][2], -(H[0][2] * H[1][1]));
+    const double m2 = fma(H[0][0], H[1][1], -(H[0][1] * H[0][1]));
+    const double det = dot3(H[0][0], H[0][1], H[0][2], c00, c01, c02);
+    return (H[0][0] > floor_) && (m2 > floor_) && (det > floor_);
 }
 
 /* returns number of iterations used (ISO_MAXIT+1 if not converged) */
@@ -486,28 +494,27 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
     int pat = 0;
     for (int it = 0; it < ISO_MAXIT; ++it) {
         double r[3], J[3][3], a[3], g[3], G[3][3], M2[3][3]; /* M2[i][q]: mixed derivatives of p_i */
-        double f = 0.0;
         for (int i = 0; i < 3; ++i) {
             tri_eval t = tri_eval_full(&Xe[8][i], 3, xi);
             r[i] = x[i] - t.v;
-            f += r[i] * r[i];
             J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
             M2[i][0] = t.m12; M2[i][1] = t.m13; M2[i][2] = t.m23;
         }
+        const double f = dot3(r[0], r[1], r[2], r[0], r[1], r[2]);
         tri_eval tr = tri_eval_full(&re[8], 1, xi);
         double c = tr.v - rt;
         a[0] = tr.d1; a[1] = tr.d2; a[2] = tr.d3;
-        for (int j = 0; j < 3; ++j) g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
+        for (int j = 0; j < 3; ++j) g[j] = -2.0 * dot3(r[0], r[1], r[2], J[0][j], J[1][j], J[2][j]);
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j)
-                G[i][j] = 2.0 * (J[0][i] * J[0][j] + J[1][i] * J[1][j] + J[2][i] * J[2][j]);
+            for (int j = i; j < 3; ++j)
+                G[i][j] = G[j][i] = 2.0 * dot3(J[0][i], J[1][i], J[2][i], J[0][j], J[1][j], J[2][j]);
         /* multiplier estimate for the Hessian: least squares over the variables
          * that were free in the last QP solution */
         {
             double num = 0.0, den = 0.0;
             int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
             for (int i = 0; i < 3; ++i)
-                if (!s[i]) { num += a[i] * g[i]; den += a[i] * a[i]; }
+                if (!s[i]) { num = fma(a[i], g[i], num); den = fma(a[i], a[i], den); }
             lam = (den > 0.0) ? -num / den : 0.0;
         }
         /* second-order part: S_jl = -2 sum_i r_i d2p_i/djdl + lam d2rho/djdl */
@@ -515,7 +522,7 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
         {
             const double mr[3] = {tr.m12, tr.m13, tr.m23};
             for (int q = 0; q < 3; ++q)
-                S[q] = -2.0 * (r[0] * M2[0][q] + r[1] * M2[1][q] + r[2] * M2[2][q]) + lam * mr[q];
+                S[q] = fma(lam, mr[q], -2.0 * dot3(r[0], r[1], r[2], M2[0][q], M2[1][q], M2[2][q]));
         }
         double lo[3], hi[3], d[3];
         for (int i = 0; i < 3; ++i) {
@@ -529,7 +536,7 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
             mminus += fmin(p, q);
         }
         double trG = G[0][0] + G[1][1] + G[2][2];
-        double aa2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+        double aa2 = dot3(a[0], a[1], a[2], a[0], a[1], a[2]);
         double sigma = 100.0 * trG / aa2;
         int use_exact = 1, corner = 0, stop = 0; (void)use_exact;
         double lam_new = lam, alpha = 1.0;
@@ -543,18 +550,22 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
             /* convexified QP data: H' = H + sigma a a^T, g' = g - sigma e a (identical to (H,g) on
              * the plane a.d = e).  Exact Lagrangian Hessian when H' is positive definite, else
              * Gauss-Newton (always positive definite): the QP is strictly convex either way. */
-            double H[3][3], gp[3];
+            double H[3][3], Hgn[3][3], gp[3];   /* both symmetric by construction */
+            const double se = sigma * e;
             for (int i = 0; i < 3; ++i) {
-                for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
-                gp[i] = g[i] - sigma * e * a[i];
+                const double sa = sigma * a[i];
+                for (int j = i; j < 3; ++j) Hgn[i][j] = Hgn[j][i] = fma(sa, a[j], G[i][j]);
+                gp[i] = fma(-se, a[i], g[i]);
             }
-            H[0][1] += S[0]; H[1][0] += S[0];
-            H[0][2] += S[1]; H[2][0] += S[1];
-            H[1][2] += S[2]; H[2][1] += S[2];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) H[i][j] = Hgn[i][j];
+            H[0][1] += S[0]; H[1][0] = H[0][1];
+            H[0][2] += S[1]; H[2][0] = H[0][2];
+            H[1][2] += S[2]; H[2][1] = H[1][2];
             if (!spd3(H, 0.0)) {
                 use_exact = 0;
                 for (int i = 0; i < 3; ++i)
-                    for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
+                    for (int j = 0; j < 3; ++j) H[i][j] = Hgn[i][j];
             }
             double q, dd[3], l2;
             int kkt, found = 0, nxt;
@@ -609,23 +620,23 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
             if (!(dmax > ISO_TOL)) { /* converged (or stuck at an infeasible corner) */
                 stop = corner ? 2 : 1;
             } else {
-                double ad = a[0] * d[0] + a[1] * d[1] + a[2] * d[2];
+                double ad = dot3(a[0], a[1], a[2], d[0], d[1], d[2]);
                 double pred_c = fabs(c) - fabs(c + ad);
-                double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+                double gd = dot3(g[0], g[1], g[2], d[0], d[1], d[2]);
                 double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
-                if (!(gd - mu_t * pred_c < 0.0)) {
+                if (!(fma(-mu_t, pred_c, gd) < 0.0)) {
                     if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
                     else stop = 2; /* no descent on the merit function */
                 }
                 if (!stop) {
                     mu = mu_t;
-                    double D = gd - mu * pred_c;
-                    double phi0 = f + mu * fabs(c);
+                    double D = fma(-mu, pred_c, gd);
+                    double phi0 = fma(mu, fabs(c), f);
                     for (int ls = 0; ls < 30; ++ls) {
                         double xt[3];
-                        for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
+                        for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(fma(alpha, d[i], xi[i]), -1.0), 1.0);
                         iso_fc t = iso_eval_fc(x, Xe, re, rt, xt);
-                        if (t.f + mu * fabs(t.c) <= phi0 + 1e-4 * alpha * D) break;
+                        if (fma(mu, fabs(t.c), t.f) <= fma(1e-4 * alpha, D, phi0)) break;
                         alpha *= 0.5;
                     }
                 }
@@ -640,7 +651,7 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
                it, xi[0], xi[1], xi[2], f, c, d[0], d[1], d[2], alpha, pat, corner, use_exact, lam, mu);
 #endif
         if (stop == 2) return ISO_MAXIT + 1;
-        for (int i = 0; i < 3; ++i) xi[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
+        for (int i = 0; i < 3; ++i) xi[i] = fmin(fmax(fma(alpha, d[i], xi[i]), -1.0), 1.0);
         if (stop == 1) return it + 1;
     }
     return ISO_MAXIT + 1;

@@ -245,6 +245,13 @@ R2S_DEV double tri_eval_value(double c0, double c1, double c2, double c3, double
 #define R2S_CX(E, i) (E).C[0][i], (E).C[1][i], (E).C[2][i], (E).C[3][i], (E).C[4][i], (E).C[5][i], (E).C[6][i], (E).C[7][i]
 #define R2S_CR(E) (E).Cr[0], (E).Cr[1], (E).Cr[2], (E).Cr[3], (E).Cr[4], (E).Cr[5], (E).Cr[6], (E).Cr[7]
 
+// a0 b0 + a1 b1 + a2 b2 in a fixed fused order (one multiply, two FMAs) - the oracle evaluates the same
+// IEEE operations, so the solvers below stay bit-identical to it
+R2S_DEV double dot3(double a0, double a1, double a2, double b0, double b1, double b2)
+{
+    return fma(a2, b2, fma(a1, b1, a0 * b0));
+}
+
 template <class ER>
 R2S_DEV bool inv_map_hex8(const ER& E, const double x[3], double xi[3])
 {
@@ -257,19 +264,20 @@ R2S_DEV bool inv_map_hex8(const ER& E, const double x[3], double xi[3])
             R[i] = t.v - x[i];
             J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
         }
-        double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-        double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-        double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-        double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-        double c10 = J[0][2] * J[2][1] - J[0][1] * J[2][2];
-        double c11 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
-        double c12 = J[0][1] * J[2][0] - J[0][0] * J[2][1];
-        double c20 = J[0][1] * J[1][2] - J[0][2] * J[1][1];
-        double c21 = J[0][2] * J[1][0] - J[0][0] * J[1][2];
-        double c22 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-        double d0 = -(c00 * R[0] + c10 * R[1] + c20 * R[2]) / det;
-        double d1 = -(c01 * R[0] + c11 * R[1] + c21 * R[2]) / det;
-        double d2 = -(c02 * R[0] + c12 * R[1] + c22 * R[2]) / det;
+        double c00 = fma(J[1][1], J[2][2], -(J[1][2] * J[2][1]));
+        double c01 = fma(J[1][2], J[2][0], -(J[1][0] * J[2][2]));
+        double c02 = fma(J[1][0], J[2][1], -(J[1][1] * J[2][0]));
+        double det = dot3(J[0][0], J[0][1], J[0][2], c00, c01, c02);
+        double c10 = fma(J[0][2], J[2][1], -(J[0][1] * J[2][2]));
+        double c11 = fma(J[0][0], J[2][2], -(J[0][2] * J[2][0]));
+        double c12 = fma(J[0][1], J[2][0], -(J[0][0] * J[2][1]));
+        double c20 = fma(J[0][1], J[1][2], -(J[0][2] * J[1][1]));
+        double c21 = fma(J[0][2], J[1][0], -(J[0][0] * J[1][2]));
+        double c22 = fma(J[0][0], J[1][1], -(J[0][1] * J[1][0]));
+        double rdet = 1.0 / det;
+        double d0 = -dot3(c00, c10, c20, R[0], R[1], R[2]) * rdet;
+        double d1 = -dot3(c01, c11, c21, R[0], R[1], R[2]) * rdet;
+        double d2 = -dot3(c02, c12, c22, R[0], R[1], R[2]) * rdet;
         double n0 = fmin(fmax(xi[0] + d0, -1.1), 1.1);
         double n1 = fmin(fmax(xi[1] + d1, -1.1), 1.1);
         double n2 = fmin(fmax(xi[2] + d2, -1.1), 1.1);
@@ -311,7 +319,7 @@ R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const d
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
-            ep -= a[i] * dB[i];
+            ep = fma(-a[i], dB[i], ep);
             aa[i] = 0.0;
             b[i] = 0.0;
         } else {
@@ -319,27 +327,34 @@ R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const d
             double t = -g[i];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                if (s[j]) t -= H[i][j] * dB[j];
+                if (s[j]) t = fma(-H[i][j], dB[j], t);
             b[i] = t;
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) M[i][j] = (s[i] || s[j]) ? ((i == j) ? 1.0 : 0.0) : H[i][j];
     }
-    // pivots are inverted once and multiplied (3 divisions instead of 9)
-    double D0 = M[0][0], r0 = 1.0 / D0;
-    double l10 = M[1][0] * r0, l20 = M[2][0] * r0;
-    double D1 = M[1][1] - l10 * M[1][0], r1 = 1.0 / D1;
-    double l21 = (M[2][1] - l20 * M[1][0]) * r1;
-    double D2 = M[2][2] - l20 * M[2][0] - l21 * l21 * D1, r2 = 1.0 / D2;
-    if (!(D0 > 0.0 && D1 > 0.0 && D2 > 0.0)) return 0;
+    // inverse of the masked symmetric matrix by its adjugate (one division); the leading minors double as
+    // the positive-definiteness test (Sylvester)
+    const double M00 = M[0][0], M01 = M[0][1], M02 = M[0][2], M11 = M[1][1], M12 = M[1][2], M22 = M[2][2];
+    const double c00 = fma(M11, M22, -(M12 * M12));
+    const double c01 = fma(M02, M12, -(M01 * M22));
+    const double c02 = fma(M01, M12, -(M02 * M11));
+    const double c11 = fma(M00, M22, -(M02 * M02));
+    const double c12 = fma(M01, M02, -(M00 * M12));
+    const double c22 = fma(M00, M11, -(M01 * M01));
+    const double det = dot3(M00, M01, M02, c00, c01, c02);
+    if (!(M00 > 0.0 && c22 > 0.0 && det > 0.0)) return 0;
+    const double rdet = 1.0 / det;
     double u[3], v[3];
-    u[0] = aa[0]; u[1] = aa[1] - l10 * u[0]; u[2] = aa[2] - l20 * u[0] - l21 * u[1];
-    v[0] = b[0];  v[1] = b[1] - l10 * v[0];  v[2] = b[2] - l20 * v[0] - l21 * v[1];
-    u[2] = u[2] * r2; u[1] = u[1] * r1 - l21 * u[2]; u[0] = u[0] * r0 - l10 * u[1] - l20 * u[2];
-    v[2] = v[2] * r2; v[1] = v[1] * r1 - l21 * v[2]; v[0] = v[0] * r0 - l10 * v[1] - l20 * v[2];
-    double den = aa[0] * u[0] + aa[1] * u[1] + aa[2] * u[2];
+    u[0] = dot3(c00, c01, c02, aa[0], aa[1], aa[2]) * rdet;
+    u[1] = dot3(c01, c11, c12, aa[0], aa[1], aa[2]) * rdet;
+    u[2] = dot3(c02, c12, c22, aa[0], aa[1], aa[2]) * rdet;
+    v[0] = dot3(c00, c01, c02, b[0], b[1], b[2]) * rdet;
+    v[1] = dot3(c01, c11, c12, b[0], b[1], b[2]) * rdet;
+    v[2] = dot3(c02, c12, c22, b[0], b[1], b[2]) * rdet;
+    double den = dot3(aa[0], aa[1], aa[2], u[0], u[1], u[2]);
     if (!(den > 0.0)) return 0;
-    double lam = (aa[0] * v[0] + aa[1] * v[1] + aa[2] * v[2] - ep) / den;
+    double lam = (dot3(aa[0], aa[1], aa[2], v[0], v[1], v[2]) - ep) / den;
     bool ok = true;
     double worst = 0.0;
     const int pw[3] = {1, 3, 9};
@@ -348,7 +363,7 @@ R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const d
         if (s[i]) {
             o.d[i] = dB[i];
         } else {
-            o.d[i] = v[i] - lam * u[i];
+            o.d[i] = fma(-lam, u[i], v[i]);
             if (!(o.d[i] >= lo[i] - 1e-12 && o.d[i] <= hi[i] + 1e-12)) {
                 ok = false;
                 const double below = (lo[i] - 1e-12) - o.d[i], above = o.d[i] - (hi[i] + 1e-12);
@@ -371,15 +386,15 @@ R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const d
     double Hd[3], q = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        Hd[i] = H[i][0] * o.d[0] + H[i][1] * o.d[1] + H[i][2] * o.d[2];
-        q += o.d[i] * (0.5 * Hd[i] + g[i]);
+        Hd[i] = dot3(H[i][0], H[i][1], H[i][2], o.d[0], o.d[1], o.d[2]);
+        q = fma(o.d[i], fma(0.5, Hd[i], g[i]), q);
     }
     bool kkt = true;
     worst = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
-            const double z = Hd[i] + g[i] + lam * a[i];
+            const double z = fma(lam, a[i], Hd[i] + g[i]);
             const double viol = (s[i] == 1) ? -z : z;
             if (s[i] == 1 && !(z >= 0.0)) kkt = false;
             if (s[i] == 2 && !(z <= 0.0)) kkt = false;
@@ -396,27 +411,24 @@ static __constant__ int c_pat_order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8, 10,
 
 R2S_DEV bool spd3(const double H[3][3])
 {
-    const double D0 = H[0][0];
-    if (!(D0 > 0.0)) return false;
-    const double l10 = H[1][0] / D0, l20 = H[2][0] / D0;
-    const double D1 = H[1][1] - l10 * H[1][0];
-    if (!(D1 > 0.0)) return false;
-    const double l21 = (H[2][1] - l20 * H[1][0]) / D1;
-    const double D2 = H[2][2] - l20 * H[2][0] - l21 * l21 * D1;
-    return D2 > 0.0;
+    // Sylvester's criterion on the (symmetric) matrix: leading minors, no division
+    const double c00 = fma(H[1][1], H[2][2], -(H[1][2] * H[1][2]));
+    const double c01 = fma(H[0][2], H[1][2], -(H[0][1] * H[2][2]));
+    const double c02 = fma(H[0][1], H[1][2], -(H[0][2] * H[1][1]));
+    const double m2 = fma(H[0][0], H[1][1], -(H[0][1] * H[0][1]));
+    const double det = dot3(H[0][0], H[0][1], H[0][2], c00, c01, c02);
+    return (H[0][0] > 0.0) && (m2 > 0.0) && (det > 0.0);
 }
 
-R2S_DEV void iso_eval_fc(const ElemRec& E, const double x[3], double rt, const double xi[3], double& f,
+template <class ER>   // any record with C[8][3], Cr[8] (ElemRec in SGPRs, IsoElemLds per lane)
+R2S_DEV void iso_eval_fc(const ER& E, const double x[3], double rt, const double xi[3], double& f,
                          double& c)
 {
-    double ff = 0.0;
+    double r[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double r = x[i] - tri_eval_value(R2S_CX(E, i), xi);
-        ff += r * r;
-    }
+    for (int i = 0; i < 3; ++i) r[i] = x[i] - tri_eval_value(R2S_CX(E, i), xi);
     const double rho = tri_eval_value(R2S_CR(E), xi);
-    f = ff;
+    f = dot3(r[0], r[1], r[2], r[0], r[1], r[2]);
     c = rho - rt;
 }
 
@@ -424,187 +436,11 @@ R2S_DEV void iso_eval_fc(const ElemRec& E, const double x[3], double rt, const d
 #define R2S_ISO_MAXIT 60
 #define R2S_ISO_TOL 1e-8
 
-// returns iterations used (R2S_ISO_MAXIT+1 when not converged)
-R2S_DEV int iso_project_hex8(const ElemRec& E, const double x[3], double rt, double xi[3])
-{
-    xi[0] = xi[1] = xi[2] = 0.0;
-    double mu = 0.0, lam = 0.0, Delta = 2.0;
-    int pat = 0;
-    for (int it = 0; it < R2S_ISO_MAXIT; ++it) {
-        double r[3], J[3][3], a[3], g[3], G[3][3], M2[3][3];   // M2[i][q]: mixed derivatives of p_i
-        double f = 0.0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const TriEval t = tri_eval_full(R2S_CX(E, i), xi);
-            r[i] = x[i] - t.v;
-            f += r[i] * r[i];
-            J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
-            M2[i][0] = t.m12; M2[i][1] = t.m13; M2[i][2] = t.m23;
-        }
-        const TriEval tr = tri_eval_full(R2S_CR(E), xi);
-        const double c = tr.v - rt;
-        a[0] = tr.d1; a[1] = tr.d2; a[2] = tr.d3;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                G[i][j] = 2.0 * (J[0][i] * J[0][j] + J[1][i] * J[1][j] + J[2][i] * J[2][j]);
-        {
-            double num = 0.0, den = 0.0;
-            const int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (!s[i]) { num += a[i] * g[i]; den += a[i] * a[i]; }
-            lam = (den > 0.0) ? -num / den : 0.0;
-        }
-        double S[3];
-        {
-            const double mr[3] = {tr.m12, tr.m13, tr.m23};
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                S[q] = -2.0 * (r[0] * M2[0][q] + r[1] * M2[1][q] + r[2] * M2[2][q]) + lam * mr[q];
-        }
-        double lo[3], hi[3], d[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            lo[i] = fmax(-1.0 - xi[i], -Delta);
-            hi[i] = fmin(1.0 - xi[i], Delta);
-        }
-        const double e = -c;
-        double mplus = 0.0, mminus = 0.0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double p = a[i] * lo[i], q = a[i] * hi[i];
-            mplus += fmax(p, q);
-            mminus += fmin(p, q);
-        }
-        const double trG = G[0][0] + G[1][1] + G[2][2];
-        const double aa2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
-        const double sigma = 100.0 * trG / aa2;
-        bool corner = false;
-        int stop = 0;
-        double lam_new = lam, alpha = 1.0;
-        if (e >= mplus) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
-            corner = true;
-        } else if (e <= mminus) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
-            corner = true;
-        } else {
-            // convexified QP data: H' = H + sigma a a^T, g' = g - sigma e a (identical to (H,g) on the
-            // plane a.d = e).  Exact Lagrangian Hessian when H' is positive definite, else Gauss-Newton
-            // (always positive definite): the QP is strictly convex either way.
-            double H[3][3], gp[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
-                gp[i] = g[i] - sigma * e * a[i];
-            }
-            H[0][1] += S[0]; H[1][0] += S[0];
-            H[0][2] += S[1]; H[2][0] += S[1];
-            H[1][2] += S[2]; H[2][1] += S[2];
-            if (!spd3(H)) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) H[i][j] = G[i][j] + sigma * a[i] * a[j];
-            }
-            QpOut o;
-            bool found = false;
-            {
-                // active-set walk from the previous pattern: the first pattern that is primal feasible
-                // and satisfies KKT is the minimiser of the strictly convex QP
-                int p = pat;
-                for (int step = 0; step < R2S_QP_WALK && p >= 0; ++step) {
-                    const int rc = qp_pattern(p, H, gp, a, e, lo, hi, o);
-                    if (rc == 0) break;
-                    if (rc == 1 && o.kkt) {
-                        found = true;
-                        pat = p;
-                        d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
-                        lam_new = o.lam;
-                        break;
-                    }
-                    p = o.next;
-                }
-            }
-            if (!found) {
-                // exhaustive fallback: patterns with 0, 1, 2 fixed variables; first KKT pattern,
-                // failing that (rounding) the feasible one of least value
-                double bestq = INFINITY;
-                for (int ip = 0; ip < 19; ++ip) {
-                    const int p = c_pat_order[ip];
-                    if (qp_pattern(p, H, gp, a, e, lo, hi, o) == 1) {
-                        if (o.kkt || o.q < bestq) {
-                            bestq = o.q;
-                            found = true;
-                            pat = p;
-                            d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
-                            lam_new = o.lam;
-                        }
-                        if (o.kkt) break;
-                    }
-                }
-            }
-            if (!found) {   // numerically degenerate: corner move towards feasibility
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    d[i] = (e > 0.0) ? ((a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0))
-                                     : ((a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0));
-                corner = true;
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
-        }
-        {
-            const double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
-            if (!(dmax > R2S_ISO_TOL)) {   // converged (or stuck at an infeasible corner)
-                stop = corner ? 2 : 1;
-            } else {
-                const double ad = a[0] * d[0] + a[1] * d[1] + a[2] * d[2];
-                const double pred_c = fabs(c) - fabs(c + ad);
-                const double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
-                double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
-                if (!(gd - mu_t * pred_c < 0.0)) {
-                    if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
-                    else stop = 2;   // no descent on the merit function
-                }
-                if (!stop) {
-                    mu = mu_t;
-                    const double D = gd - mu * pred_c;
-                    const double phi0 = f + mu * fabs(c);
-                    for (int ls = 0; ls < 30; ++ls) {
-                        double xt[3], ft, ct;
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
-                        iso_eval_fc(E, x, rt, xt, ft, ct);
-                        if (ft + mu * fabs(ct) <= phi0 + 1e-4 * alpha * D) break;
-                        alpha *= 0.5;
-                    }
-                }
-            }
-        }
-        {
-            const double dm = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
-            Delta = (alpha < 1.0) ? alpha * dm : fmin(2.0, fmax(Delta, 2.0 * dm));
-        }
-        if (stop == 2) return R2S_ISO_MAXIT + 1;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) xi[i] = fmin(fmax(xi[i] + alpha * d[i], -1.0), 1.0);
-        if (stop == 1) return it + 1;
-    }
-    return R2S_ISO_MAXIT + 1;
-}
-
-// ---- the same SQP as a per-lane state machine ---------------------------------------
-// iso_project_hex8 cut into phases so that the lanes of a wavefront can sit in different phases /
-// iterations / voxels (iso_project_hex_kernel): every phase performs exactly the arithmetic of the
-// corresponding part of iso_project_hex8, in the same order, so the results are bit-identical.
+// ---- the SQP as a per-lane state machine ---------------------------------------------
+// The oracle's iso_project_hex8 (oracle/r2s_oracle.c) cut into phases so that the lanes of a wavefront can
+// sit in different phases / iterations / voxels (iso_project_hex*_kernel): every phase performs exactly
+// the IEEE operations of the corresponding part of that loop, in the same order (explicit fma / dot3 on
+// both sides, -ffp-contract=off), so the results are bit-identical.
 //   EVAL  fields, QP data, corner test            -> QP | POST
 //   QP    ONE active-set pattern (walk or exhaustive fallback) per visit -> QP | POST
 //   POST  step test, merit parameter               -> LS | UPD
@@ -630,35 +466,35 @@ R2S_DEV void iso_lane_start(IsoLane& s, const double x[3])
     s.phase = ISO_EVAL;
 }
 
-R2S_DEV void iso_lane_eval(const ElemRec& E, double rt, IsoLane& s)
+template <class ER>
+R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
 {
     double r[3], J[3][3], G[3][3], M2[3][3];
-    double f = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const TriEval t = tri_eval_full(R2S_CX(E, i), s.xi);
         r[i] = s.x[i] - t.v;
-        f += r[i] * r[i];
         J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
         M2[i][0] = t.m12; M2[i][1] = t.m13; M2[i][2] = t.m23;
     }
+    const double f = dot3(r[0], r[1], r[2], r[0], r[1], r[2]);
     const TriEval tr = tri_eval_full(R2S_CR(E), s.xi);
     const double c = tr.v - rt;
     s.a[0] = tr.d1; s.a[1] = tr.d2; s.a[2] = tr.d3;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) s.g[j] = -2.0 * (r[0] * J[0][j] + r[1] * J[1][j] + r[2] * J[2][j]);
+    for (int j = 0; j < 3; ++j) s.g[j] = -2.0 * dot3(r[0], r[1], r[2], J[0][j], J[1][j], J[2][j]);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            G[i][j] = 2.0 * (J[0][i] * J[0][j] + J[1][i] * J[1][j] + J[2][i] * J[2][j]);
+        for (int j = i; j < 3; ++j)
+            G[i][j] = G[j][i] = 2.0 * dot3(J[0][i], J[1][i], J[2][i], J[0][j], J[1][j], J[2][j]);
     double lam;
     {
         double num = 0.0, den = 0.0;
         const int sp[3] = {s.pat % 3, (s.pat / 3) % 3, s.pat / 9};
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if (!sp[i]) { num += s.a[i] * s.g[i]; den += s.a[i] * s.a[i]; }
+            if (!sp[i]) { num = fma(s.a[i], s.g[i], num); den = fma(s.a[i], s.a[i], den); }
         lam = (den > 0.0) ? -num / den : 0.0;
     }
     double S[3];
@@ -666,7 +502,7 @@ R2S_DEV void iso_lane_eval(const ElemRec& E, double rt, IsoLane& s)
         const double mr[3] = {tr.m12, tr.m13, tr.m23};
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            S[q] = -2.0 * (r[0] * M2[0][q] + r[1] * M2[1][q] + r[2] * M2[2][q]) + lam * mr[q];
+            S[q] = fma(lam, mr[q], -2.0 * dot3(r[0], r[1], r[2], M2[0][q], M2[1][q], M2[2][q]));
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -682,7 +518,7 @@ R2S_DEV void iso_lane_eval(const ElemRec& E, double rt, IsoLane& s)
         mminus += fmin(p, q);
     }
     const double trG = G[0][0] + G[1][1] + G[2][2];
-    const double aa2 = s.a[0] * s.a[0] + s.a[1] * s.a[1] + s.a[2] * s.a[2];
+    const double aa2 = dot3(s.a[0], s.a[1], s.a[2], s.a[0], s.a[1], s.a[2]);
     const double sigma = 100.0 * trG / aa2;
     s.corner = false;
     s.stop = 0;
@@ -700,20 +536,27 @@ R2S_DEV void iso_lane_eval(const ElemRec& E, double rt, IsoLane& s)
         s.corner = true;
         s.phase = ISO_POST;
     } else {
+        double Hgn[3][3];   // Gauss-Newton + sigma a a^T (symmetric by construction, like H)
+        const double se = sigma * e;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
+            const double sa = sigma * s.a[i];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) s.H[i][j] = G[i][j] + sigma * s.a[i] * s.a[j];
-            s.gp[i] = s.g[i] - sigma * e * s.a[i];
+            for (int j = i; j < 3; ++j) Hgn[i][j] = Hgn[j][i] = fma(sa, s.a[j], G[i][j]);
+            s.gp[i] = fma(-se, s.a[i], s.g[i]);
         }
-        s.H[0][1] += S[0]; s.H[1][0] += S[0];
-        s.H[0][2] += S[1]; s.H[2][0] += S[1];
-        s.H[1][2] += S[2]; s.H[2][1] += S[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s.H[i][j] = Hgn[i][j];
+        s.H[0][1] += S[0]; s.H[1][0] = s.H[0][1];
+        s.H[0][2] += S[1]; s.H[2][0] = s.H[0][2];
+        s.H[1][2] += S[2]; s.H[2][1] = s.H[1][2];
         if (!spd3(s.H)) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) s.H[i][j] = G[i][j] + sigma * s.a[i] * s.a[j];
+                for (int j = 0; j < 3; ++j) s.H[i][j] = Hgn[i][j];
         }
         s.p = s.pat;
         s.step = 0;
@@ -781,31 +624,32 @@ R2S_DEV void iso_lane_post(IsoLane& s)
     if (!(dmax > R2S_ISO_TOL)) {
         s.stop = s.corner ? 2 : 1;
     } else {
-        const double ad = s.a[0] * s.d[0] + s.a[1] * s.d[1] + s.a[2] * s.d[2];
+        const double ad = dot3(s.a[0], s.a[1], s.a[2], s.d[0], s.d[1], s.d[2]);
         const double pred_c = fabs(s.c) - fabs(s.c + ad);
-        const double gd = s.g[0] * s.d[0] + s.g[1] * s.d[1] + s.g[2] * s.d[2];
+        const double gd = dot3(s.g[0], s.g[1], s.g[2], s.d[0], s.d[1], s.d[2]);
         double mu_t = s.corner ? s.mu : fmax(0.5 * s.mu, 2.0 * fabs(s.lam_new));
-        if (!(gd - mu_t * pred_c < 0.0)) {
+        if (!(fma(-mu_t, pred_c, gd) < 0.0)) {
             if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
             else s.stop = 2;
         }
         if (!s.stop) {
             s.mu = mu_t;
-            s.D = gd - s.mu * pred_c;
-            s.phi0 = s.f + s.mu * fabs(s.c);
+            s.D = fma(-s.mu, pred_c, gd);
+            s.phi0 = fma(s.mu, fabs(s.c), s.f);
             s.ls = 0;
         }
     }
     s.phase = s.stop ? ISO_UPD : ISO_LS;
 }
 
-R2S_DEV void iso_lane_ls(const ElemRec& E, double rt, IsoLane& s)
+template <class ER>
+R2S_DEV void iso_lane_ls(const ER& E, double rt, IsoLane& s)
 {
     double xt[3], ft, ct;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(s.xi[i] + s.alpha * s.d[i], -1.0), 1.0);
+    for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(fma(s.alpha, s.d[i], s.xi[i]), -1.0), 1.0);
     iso_eval_fc(E, s.x, rt, xt, ft, ct);
-    if (ft + s.mu * fabs(ct) <= s.phi0 + 1e-4 * s.alpha * s.D) {
+    if (fma(s.mu, fabs(ct), ft) <= fma(1e-4 * s.alpha, s.D, s.phi0)) {
         s.phase = ISO_UPD;
     } else {
         s.alpha *= 0.5;
@@ -820,7 +664,7 @@ R2S_DEV void iso_lane_update(IsoLane& s)
     s.Delta = (s.alpha < 1.0) ? s.alpha * dm : fmin(2.0, fmax(s.Delta, 2.0 * dm));
     if (s.stop == 2) { s.phase = ISO_DONE; return; }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) s.xi[i] = fmin(fmax(s.xi[i] + s.alpha * s.d[i], -1.0), 1.0);
+    for (int i = 0; i < 3; ++i) s.xi[i] = fmin(fmax(fma(s.alpha, s.d[i], s.xi[i]), -1.0), 1.0);
     if (s.stop == 1) { s.phase = ISO_DONE; return; }
     s.it += 1;
     s.phase = (s.it == R2S_ISO_MAXIT) ? ISO_DONE : ISO_EVAL;
@@ -932,60 +776,6 @@ R2S_DEV void process_triangle(VoxState& s, const BandItem& T, const Rec& E, doub
     }
 }
 
-// iso-surface candidate of one voxel (process_isocontour_element!, :612-623)
-R2S_DEV double iso_candidate(const ElemRec& E0, double rt, const double x[3], double xp[3])
-{
-    double xi[3], N[8];
-    iso_project_hex8(E0, x, rt, xi);
-    hex8_shape(xi, N);
-    // the nodal coordinates are only needed now: hide the (wave-uniform) pointer from the optimiser so
-    // their scalar loads are issued here instead of occupying 48 SGPRs during the whole solve
-    const ElemRec* Ep = &E0;
-    asm volatile("" : "+s"(Ep));
-    const ElemRec& E = *Ep;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += E.X[k][i] * N[k];
-        xp[i] = t;
-    }
-    return norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]);
-}
-
-R2S_DEV void process_iso(VoxState& s, const ElemRec& E, double rt, const double x[3])
-{
-    double xi[3], N[8], xp[3];
-    iso_project_hex8(E, x, rt, xi);
-    hex8_shape(xi, N);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += E.X[k][i] * N[k];
-        xp[i] = t;
-    }
-    write_value(s, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), xp);
-}
-
-// per-voxel state machine of Sign_Detection_HEX8 for one candidate (SignDetection.jl:41-70)
-template <class ER>
-R2S_DEV void sign_visit(const ER& E, double rt, const double x[3], double& max_local, double& sign,
-                        bool& done)
-{
-    double xi[3], N[8];
-    inv_map_hex8(E, x, xi);
-    const double m = fmax(fabs(xi[0]), fmax(fabs(xi[1]), fabs(xi[2])));
-    if (m < 1.01 && max_local > m) {
-        hex8_shape(xi, N);
-        double rho = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) rho += N[k] * E.r[k];
-        if (rho >= rt) sign = 1.0;
-        if (m < 0.95) done = true;
-        else max_local = m;
-    }
-}
 
 // =====================================================================================
 // TET4

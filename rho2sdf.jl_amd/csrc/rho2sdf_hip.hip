@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -758,6 +759,135 @@ __global__ void sign_bin_kernel(const Rec* __restrict__ erec, uint32_t nel, Grid
             }
 }
 
+// Persistent variant: the element record of a lane sits in LDS (a few slots per wavefront), so the lanes
+// of one wavefront may work on voxels of DIFFERENT items.  Nothing drains at item boundaries any more, and
+// the work is handed out dynamically (atomic counter over small chunk groups), which also removes the
+// tail that a few slowly converging elements used to cause.
+struct IsoElemLds {
+    double C[8][3];
+    double Cr[8];
+    double X[8][3];
+};
+#define R2S_ISO_SLOTS 4
+__global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
+    const BandItem* __restrict__ items, uint32_t nitems, const uint32_t* __restrict__ chunk_off, uint32_t nchunks,
+    uint32_t group, const ElemRec* __restrict__ erec, GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
+    double* __restrict__ res_xp, uint32_t* __restrict__ counter)
+{
+    __shared__ IsoElemLds slots[R2S_ISO_SLOTS];
+    const uint32_t lane = threadIdx.x;
+    // wave-uniform bookkeeping
+    uint32_t c = 0, c_end = 0;        // rest of the fetched chunk group
+    uint32_t it = 0, co = 0, cn = 0;  // newest item and its chunk range
+    bool have_item = false, exhausted = false;
+    uint32_t next = 0, v_end = 0, vol = 0;   // rest of the current segment (box voxels of item `it`)
+    int cur_slot = 0, lo0 = 0, lo1 = 0, lo2 = 0;
+    BoxDecode dec = box_decode_make(1u, 1u, 1u);
+    // per lane
+    IsoLane s;
+    s.phase = ISO_IDLE;
+    size_t my = 0;
+    int eslot = 0;
+
+    for (;;) {
+        const uint64_t m_done = __ballot(s.phase == ISO_DONE);
+        const uint64_t m_busy = __ballot(s.phase != ISO_DONE && s.phase != ISO_IDLE);
+        if (m_busy == 0 || __popcll(m_done) >= R2S_ISO_REFILL_MIN) {
+            if (s.phase == ISO_DONE) {
+                const IsoElemLds& E = slots[eslot];
+                double N[8], xp[3];
+                hex8_shape(s.xi, N);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t += E.X[k][i] * N[k];
+                    xp[i] = t;
+                }
+                res[my] = norm3(s.x[0] - xp[0], s.x[1] - xp[1], s.x[2] - xp[2]);
+                if (res_xp) {
+                    res_xp[3 * my] = xp[0];
+                    res_xp[3 * my + 1] = xp[1];
+                    res_xp[3 * my + 2] = xp[2];
+                }
+                s.phase = ISO_IDLE;
+            }
+            // hand out voxels; open new segments / items / chunk groups as needed
+            for (;;) {
+                const uint64_t m_idle = __ballot(s.phase == ISO_IDLE);
+                if (m_idle == 0) break;
+                if (next >= v_end) {
+                    if (exhausted) break;
+                    if (c >= c_end) {
+                        uint32_t cc = 0;
+                        if (lane == 0) cc = atomicAdd(counter, group);
+                        c = __builtin_amdgcn_readfirstlane(cc);
+                        if (c >= nchunks) { exhausted = true; break; }
+                        c_end = (c + group < nchunks) ? c + group : nchunks;
+                    }
+                    if (!(have_item && c >= co && c < cn)) {
+                        // another item: its record needs an LDS slot no lane is working from
+                        int fs = -1;
+#pragma unroll
+                        for (int q = 0; q < R2S_ISO_SLOTS; ++q)
+                            if (fs < 0 && __ballot(s.phase != ISO_IDLE && eslot == q) == 0) fs = q;
+                        if (fs < 0) break;   // all slots busy: the idle lanes wait
+                        uint32_t lo = 0, hi = nitems;   // last item with chunk_off[it] <= c
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (chunk_off[mid] <= c) lo = mid; else hi = mid;
+                        }
+                        it = lo; co = chunk_off[lo]; cn = chunk_off[lo + 1];
+                        have_item = true;
+                        const BandItem& T = items[it];
+                        const double* src = reinterpret_cast<const double*>(&erec[T.el]);
+                        double* dst = reinterpret_cast<double*>(&slots[fs]);
+                        if (lane < 24) dst[lane] = src[offsetof(ElemRec, C) / 8 + lane];
+                        else if (lane < 32) dst[lane] = src[offsetof(ElemRec, Cr) / 8 + (lane - 24)];
+                        else if (lane < 56) dst[lane] = src[offsetof(ElemRec, X) / 8 + (lane - 32)];
+                        __syncthreads();
+                        cur_slot = fs;
+                        dec = box_decode_make((uint32_t)T.dim[0], (uint32_t)T.dim[1], (uint32_t)T.dim[2]);
+                        vol = dec.bxy * (uint32_t)T.dim[2];
+                        lo0 = T.lo[0]; lo1 = T.lo[1]; lo2 = T.lo[2];
+                    }
+                    const uint32_t seg_end = (cn < c_end) ? cn : c_end;
+                    next = (c - co) * 64u;
+                    v_end = ((seg_end - co) * 64u < vol) ? (seg_end - co) * 64u : vol;
+                    c = seg_end;
+                    if (next >= v_end) continue;
+                }
+                if (s.phase == ISO_IDLE) {
+                    const uint32_t v = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                    if (v < v_end) {
+                        uint32_t li, lj, lk;
+                        box_decode(dec, v, li, lj, lk);
+                        double x[3];
+                        x[0] = grid_coord(g, 0, lo0 + (int)li);
+                        x[1] = grid_coord(g, 1, lo1 + (int)lj);
+                        x[2] = grid_coord(g, 2, slab_global_k(sl, lo2 + (int)lk));   // T.lo[2] is a local plane
+                        iso_lane_start(s, x);
+                        my = (size_t)co * 64u + v;
+                        eslot = cur_slot;
+                    }
+                }
+                next += (uint32_t)__popcll(m_idle);
+            }
+            if (exhausted && __ballot(s.phase != ISO_IDLE) == 0) break;
+        }
+        // ---- one visit of each phase ----
+        {
+            const IsoElemLds& E = slots[eslot];
+            if (s.phase == ISO_EVAL) iso_lane_eval(E, rho_t, s);
+            if (s.phase == ISO_QP) iso_lane_qp(s);
+            if (s.phase == ISO_POST) iso_lane_post(s);
+            if (s.phase == ISO_LS) iso_lane_ls(E, rho_t, s);
+            if (s.phase == ISO_UPD) iso_lane_update(s);
+        }
+    }
+}
+
 // ---- item-major inverse maps for Sign_Detection_HEX8 ----------------------------------------
 // The reference walks, per grid point, the elements whose AABB holds the point and runs the Newton
 // inverse map for each (SignDetection.jl:27-70).  Here the inverse maps are computed element-major
@@ -1252,6 +1382,7 @@ __global__ void __launch_bounds__(256) unpack_tiles_kernel(const double* __restr
 // ------------------------------------------------------------------------------------
 struct r2s_plan {
     int device = 0;
+    int n_cu = 256;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
     DevBuf active, active_sign, active_any, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
@@ -1382,6 +1513,10 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     HIP_TRY(hipSetDevice(device));
     r2s_plan* P = new r2s_plan();
     P->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) P->n_cu = prop.multiProcessorCount;
+    }
     HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocDefault));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
@@ -1657,6 +1792,15 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             if (want_dist && n_chunks) {
                 static const int cpw_env = getenv("R2S_ISO_CPW") ? atoi(getenv("R2S_ISO_CPW")) : 8;
                 const uint32_t cpw = (uint32_t)(cpw_env > 0 ? cpw_env : 8), nwaves = (n_chunks + cpw - 1) / cpw;
+                static const int pl_env = getenv("R2S_ISO_PL") ? atoi(getenv("R2S_ISO_PL")) : 2;   // chunks per fetch; 0: per-item kernel
+                if (pl_env > 0) {
+                    const uint32_t group = (uint32_t)pl_env, ngroups = (n_chunks + group - 1) / group;
+                    const uint32_t resident = (uint32_t)P->n_cu * 4u * 3u;   // CUs x SIMDs x waves/SIMD of this kernel
+                    HIP_TRY(hipMemsetAsync(counters + 8, 0, 4, st));
+                    iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
+                        P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
+                        s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, counters + 8);
+                } else
                 iso_project_hex_kernel<<<nwaves, 64, 0, st>>>(
                     P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, cpw, P->erec.as<ElemRec>(), g,
                     s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
