@@ -49,8 +49,8 @@ struct alignas(16) BandItem {
     // Z-slab) that the item-major projection kernel sweeps, and its result slots
     int32_t lo[3];
     int32_t dim[3];      // 0 in any axis = empty
-    uint32_t chunk_off;  // first 64-voxel chunk of this item in the result array
-    int32_t pad[1];
+    uint32_t chunk_off;  // first 64-voxel WORK chunk of this item (dense enumeration of the box)
+    uint32_t store_off;  // first 64-slot STORAGE chunk: results are stored per 4x4x4 voxel tile of the box
     double tri[3][3];  // vertices x1,x2,x3
     double n[3];       // unit normal
     double L[3];       // edge lengths

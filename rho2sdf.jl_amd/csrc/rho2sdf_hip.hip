@@ -312,11 +312,41 @@ __device__ __forceinline__ void mini_range(const GridDev& g, int ax, double mn, 
 
 // 1 thread / element with items: writes its triangles (face order sg, fan order a) and then the
 // iso item - the reference's processing order inside one element (:584-624).
+// ---- storage of item-major results ---------------------------------------------------------
+// Results of an item (iso projections, inverse maps of the sign pass) are stored per 4x4x4 voxel tile of
+// the item's lattice box, in the lane order of the per-tile gather kernel (x + 4 y + 16 z inside the tile):
+// the gather reads one contiguous 512 B line per (tile, item), with a wave-uniform base address.
+struct TileBox {
+    int32_t t0[3];   // first tile per axis (Z: tiles of LOCAL planes)
+    int32_t td[3];   // tiles per axis
+};
+__host__ __device__ __forceinline__ TileBox tile_box(const int32_t lo[3], const int32_t dim[3])
+{
+    TileBox b;
+    for (int ax = 0; ax < 3; ++ax) {
+        b.t0[ax] = lo[ax] >> 2;
+        b.td[ax] = (dim[ax] > 0) ? (((lo[ax] + dim[ax] - 1) >> 2) - b.t0[ax] + 1) : 0;
+    }
+    return b;
+}
+__device__ __forceinline__ size_t tile_slot(uint32_t store_off, const TileBox& b, int i, int j, int k)
+{
+    const uint32_t tile = (uint32_t)((((k >> 2) - b.t0[2]) * b.td[1] + ((j >> 2) - b.t0[1])) * b.td[0] + ((i >> 2) - b.t0[0]));
+    return ((size_t)store_off + tile) * 64u + (uint32_t)((i & 3) | ((j & 3) << 2) | ((k & 3) << 4));
+}
+
+// wave-uniform form for the per-tile gather: storage chunk of tile (tx,ty,tz) inside an item's tile box
+__device__ __forceinline__ uint32_t tile_chunk(uint32_t store_off, const TileBox& b, int tx, int ty, int tz)
+{
+    return store_off + (uint32_t)(((tz - b.t0[2]) * b.td[1] + (ty - b.t0[1])) * b.td[0] + (tx - b.t0[0]));
+}
+
 template <class ET>
 __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, const uint8_t* __restrict__ cls,
                                   const uint8_t* __restrict__ fmask, const uint32_t* __restrict__ item_off,
                                   int64_t nel, GridDev g, SlabInfo sl, double delta,
-                                  BandItem* __restrict__ items, uint32_t* __restrict__ nchunks)
+                                  BandItem* __restrict__ items, uint32_t* __restrict__ nchunks,
+                                  uint32_t* __restrict__ nstore)
 {
     int64_t el = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nel) return;
@@ -407,8 +437,9 @@ __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, con
             T.lo[0] = T.lo[1] = T.lo[2] = 0;
             T.dim[0] = T.dim[1] = T.dim[2] = 0;
             T.chunk_off = 0;
-            T.pad[0] = 0;
+            T.store_off = 0;
             nchunks[w] = 0;
+            nstore[w] = 0;
             items[w++] = T;
         }
     }
@@ -442,16 +473,23 @@ __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, con
             vol *= (uint64_t)T.dim[ax];
         }
         nchunks[w] = (uint32_t)((vol + 63) / 64);
+        {
+            const TileBox tb = tile_box(T.lo, T.dim);
+            nstore[w] = vol ? (uint32_t)(tb.td[0] * tb.td[1] * tb.td[2]) : 0u;
+        }
         items[w++] = T;
     }
 }
 
 // writes the scanned chunk offsets back into the items
 __global__ void item_chunks_kernel(BandItem* __restrict__ items, const uint32_t* __restrict__ chunk_off,
-                                   uint32_t nitems)
+                                   const uint32_t* __restrict__ store_off, uint32_t nitems)
 {
     uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
-    if (it < nitems) items[it].chunk_off = chunk_off[it];
+    if (it < nitems) {
+        items[it].chunk_off = chunk_off[it];
+        items[it].store_off = store_off[it];
+    }
 }
 
 // Item-major projection onto the iso-surface (process_isocontour_element!, :606-624): one
@@ -493,7 +531,8 @@ __global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __rest
     if (!in) return;
     double xp[3];
     const double d = iso_candidate(E, rho_t, x, xp);
-    const size_t slot = (size_t)chunk_off[lo] * 64u + local;
+    const TileBox tb = tile_box(T.lo, T.dim);
+    const size_t slot = tile_slot(T.store_off, tb, T.lo[0] + li, T.lo[1] + lj, T.lo[2] + lk);
     res[slot] = d;
     if (res_xp) {
         res_xp[3 * slot] = xp[0];
@@ -539,111 +578,16 @@ __device__ __forceinline__ void box_decode(const BoxDecode& d, uint32_t v, uint3
     }
 }
 
-// HEX8 variant with lane refill (DESIGN.md "iso_project"): one wavefront works off `cpw` consecutive
-// 64-voxel chunks; every lane runs the SQP state machine of r2s_device_math.hpp (IsoLane) on its own
-// voxel and, when it has finished, takes the next voxel of the item, so that slowly converging voxels,
-// extra active-set steps and line-search trials of one lane no longer stall the other 63.  The element
-// record stays wave-uniform (SGPRs): lanes are only refilled from the same item.
+// HEX8 iso-surface projection with lane refill (DESIGN.md "iso_project"): every lane runs the SQP state
+// machine of r2s_device_math.hpp (IsoLane) on its own voxel and, when it has finished, takes the next
+// voxel, so that slowly converging voxels, extra active-set steps and line-search trials of one lane do not
+// stall the other 63.
 #ifndef R2S_ISO_LB2
-#define R2S_ISO_LB2 , 3   // 168 VGPRs, 12 B/lane of scratch: 3 waves/SIMD measured 3-7 % faster than 2
+#define R2S_ISO_LB2 , 3   // <= 168 VGPRs: 3 waves/SIMD measured 3-7 % faster than 2
 #endif
 #ifndef R2S_ISO_REFILL_MIN
-#define R2S_ISO_REFILL_MIN 16
-#endif //   // finished lanes wait until this many can be finalised + refilled together
-__global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_kernel(const BandItem* __restrict__ items, uint32_t nitems,
-                                                              const uint32_t* __restrict__ chunk_off,
-                                                              uint32_t nchunks, uint32_t cpw,
-                                                              const ElemRec* __restrict__ erec, GridDev g,
-                                                              SlabInfo sl, double rho_t, double* __restrict__ res,
-                                                              double* __restrict__ res_xp)
-{
-    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    uint32_t c = w * cpw;
-    if (c >= nchunks) return;
-    const uint32_t c_end = (c + cpw < nchunks) ? c + cpw : nchunks;
-    // last item with chunk_off[it] <= c  (chunk_off has nitems+1 entries, non-decreasing)
-    uint32_t lo = 0, hi = nitems;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (chunk_off[mid] <= c) lo = mid; else hi = mid;
-    }
-    while (c < c_end) {
-        lo = __builtin_amdgcn_readfirstlane(lo);
-        const BandItem& T = items[lo];
-        const ElemRec& E = erec[T.el];
-        const uint32_t co = chunk_off[lo], cn = chunk_off[lo + 1];
-        const uint32_t seg_end = (cn < c_end) ? cn : c_end;
-        const BoxDecode dec = box_decode_make((uint32_t)T.dim[0], (uint32_t)T.dim[1], (uint32_t)T.dim[2]);
-        const uint32_t vol = dec.bxy * (uint32_t)T.dim[2];
-        uint32_t next = (c - co) * 64u;
-        const uint32_t v_end = ((seg_end - co) * 64u < vol) ? (seg_end - co) * 64u : vol;
-        const int lo0 = T.lo[0], lo1 = T.lo[1], lo2 = T.lo[2];
-        const size_t base = (size_t)co * 64u;
-
-        IsoLane s;
-        s.phase = ISO_IDLE;
-        uint32_t my = 0;
-        for (;;) {
-            // ---- finalise finished lanes, hand out new voxels ----
-            const uint64_t m_done = __ballot(s.phase == ISO_DONE);
-            const uint64_t m_busy = __ballot(s.phase != ISO_DONE && s.phase != ISO_IDLE);
-            if (m_busy == 0 || __popcll(m_done) >= R2S_ISO_REFILL_MIN) {
-                if (s.phase == ISO_DONE) {
-                    double N[8], xp[3];
-                    hex8_shape(s.xi, N);
-                    const ElemRec* Ep = &E;
-                    asm volatile("" : "+s"(Ep));   // nodal coordinates: scalar loads here, not live in the solve
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        double t = 0.0;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) t += Ep->X[k][i] * N[k];
-                        xp[i] = t;
-                    }
-                    const size_t slot = base + my;
-                    res[slot] = norm3(s.x[0] - xp[0], s.x[1] - xp[1], s.x[2] - xp[2]);
-                    if (res_xp) {
-                        res_xp[3 * slot] = xp[0];
-                        res_xp[3 * slot + 1] = xp[1];
-                        res_xp[3 * slot + 2] = xp[2];
-                    }
-                    s.phase = ISO_IDLE;
-                }
-                const uint64_t m_idle = __ballot(s.phase == ISO_IDLE);
-                if (next < v_end) {
-                    if (s.phase == ISO_IDLE) {
-                        const uint32_t v = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
-                        if (v < v_end) {
-                            my = v;
-                            uint32_t li, lj, lk;
-                            box_decode(dec, v, li, lj, lk);
-                            double x[3];
-                            x[0] = grid_coord(g, 0, lo0 + (int)li);
-                            x[1] = grid_coord(g, 1, lo1 + (int)lj);
-                            x[2] = grid_coord(g, 2, slab_global_k(sl, lo2 + (int)lk));   // T.lo[2] is a local plane
-                            iso_lane_start(s, x);
-                        }
-                    }
-                    next += (uint32_t)__popcll(m_idle);
-                } else if (m_busy == 0) {
-                    break;      // every lane idle, nothing left in this segment
-                }
-            }
-            // ---- one visit of each phase ----
-            if (s.phase == ISO_EVAL) iso_lane_eval(E, rho_t, s);
-            if (s.phase == ISO_QP) iso_lane_qp(s);
-            if (s.phase == ISO_POST) iso_lane_post(s);
-            if (s.phase == ISO_LS) iso_lane_ls(E, rho_t, s);
-            if (s.phase == ISO_UPD) iso_lane_update(s);
-        }
-        c = seg_end;
-        if (c < c_end) {
-            do { ++lo; } while (chunk_off[lo + 1] <= c);
-        }
-    }
-}
-
+#define R2S_ISO_REFILL_MIN 16   // finished lanes wait until this many can be finalised + refilled together
+#endif
 // ------------------------------------------------------------------------------------
 // tile binning.  A tile is a 4x4x4 block of VOXELS (lattice indices); a voxel's cell
 // index (Grid.jl:58) is its lattice index or one less, so an item with cell box
@@ -737,29 +681,43 @@ __global__ void band_bin_kernel(const BandItem* __restrict__ items, uint32_t nit
             }
 }
 
+// a voxel is only examined when some candidate reaches rho_t (SignDetection.jl:36): tiles whose lists
+// would hold no such element keep sign = -1 without any work ("hot" = the others).  Pass 1 marks them.
+template <class Rec>
+__global__ void sign_hot_kernel(const Rec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s, double rho_t,
+                                uint8_t* __restrict__ hot)
+{
+    uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
+    if (el >= nel) return;
+    if (erec[el].rmax < rho_t) return;
+    int lo[3], hi[3];
+    if (!sign_tile_range(erec[el], g, s, lo, hi)) return;
+    for (int tz = lo[2]; tz <= hi[2]; ++tz)
+        for (int ty = lo[1]; ty <= hi[1]; ++ty)
+            for (int tx = lo[0]; tx <= hi[0]; ++tx) hot[((uint32_t)tz * s.nty + ty) * s.ntx + tx] = 1;
+}
+
+// candidate lists of the hot tiles only (count pass, then fill pass)
 template <class Rec, bool FILL>
 __global__ void sign_bin_kernel(const Rec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s,
-                                double rho_t, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
-                                uint32_t* __restrict__ entries, uint8_t* __restrict__ hot)
+                                uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                uint32_t* __restrict__ entries, const uint8_t* __restrict__ hot)
 {
     uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nel) return;
     int lo[3], hi[3];
     if (!sign_tile_range(erec[el], g, s, lo, hi)) return;
-    // a voxel is only examined when some candidate reaches rho_t (SignDetection.jl:36):
-    // tiles whose lists hold no such element keep sign = -1 without running the kernel
-    const bool is_hot = !FILL && !(erec[el].rmax < rho_t);
     for (int tz = lo[2]; tz <= hi[2]; ++tz)
         for (int ty = lo[1]; ty <= hi[1]; ++ty)
             for (int tx = lo[0]; tx <= hi[0]; ++tx) {
                 const uint32_t t = ((uint32_t)tz * s.nty + ty) * s.ntx + tx;
+                if (!hot[t]) continue;
                 const uint32_t pos = atomicAdd(&cnt[t], 1u);
                 if (FILL) entries[off[t] + pos] = el;
-                else if (is_hot) hot[t] = 1;
             }
 }
 
-// Persistent variant: the element record of a lane sits in LDS (a few slots per wavefront), so the lanes
+// Persistent kernel: the element record of a lane sits in LDS (a few slots per wavefront), so the lanes
 // of one wavefront may work on voxels of DIFFERENT items.  Nothing drains at item boundaries any more, and
 // the work is handed out dynamically (atomic counter over small chunk groups), which also removes the
 // tail that a few slowly converging elements used to cause.
@@ -782,6 +740,8 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
     bool have_item = false, exhausted = false;
     uint32_t next = 0, v_end = 0, vol = 0;   // rest of the current segment (box voxels of item `it`)
     int cur_slot = 0, lo0 = 0, lo1 = 0, lo2 = 0;
+    uint32_t st_off = 0;
+    TileBox tb = {{0, 0, 0}, {0, 0, 0}};
     BoxDecode dec = box_decode_make(1u, 1u, 1u);
     // per lane
     IsoLane s;
@@ -850,6 +810,8 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
                         dec = box_decode_make((uint32_t)T.dim[0], (uint32_t)T.dim[1], (uint32_t)T.dim[2]);
                         vol = dec.bxy * (uint32_t)T.dim[2];
                         lo0 = T.lo[0]; lo1 = T.lo[1]; lo2 = T.lo[2];
+                        st_off = T.store_off;
+                        tb = tile_box(T.lo, T.dim);
                     }
                     const uint32_t seg_end = (cn < c_end) ? cn : c_end;
                     next = (c - co) * 64u;
@@ -863,12 +825,13 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
                     if (v < v_end) {
                         uint32_t li, lj, lk;
                         box_decode(dec, v, li, lj, lk);
+                        const int i = lo0 + (int)li, j = lo1 + (int)lj, kl = lo2 + (int)lk;   // kl: local plane
                         double x[3];
-                        x[0] = grid_coord(g, 0, lo0 + (int)li);
-                        x[1] = grid_coord(g, 1, lo1 + (int)lj);
-                        x[2] = grid_coord(g, 2, slab_global_k(sl, lo2 + (int)lk));   // T.lo[2] is a local plane
+                        x[0] = grid_coord(g, 0, i);
+                        x[1] = grid_coord(g, 1, j);
+                        x[2] = grid_coord(g, 2, slab_global_k(sl, kl));
                         iso_lane_start(s, x);
-                        my = (size_t)co * 64u + v;
+                        my = tile_slot(st_off, tb, i, j, kl);
                         eslot = cur_slot;
                     }
                 }
@@ -916,7 +879,7 @@ __device__ __forceinline__ bool coord_range(const GridDev& g, int ax, double mn,
 // one thread per element: relevant (its tile range holds a hot tile) -> lattice box + chunk count
 __global__ void sign_box_kernel(const ElemRec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s,
                                 const uint8_t* __restrict__ hot, SignBox* __restrict__ sbox,
-                                uint32_t* __restrict__ nchunks)
+                                uint32_t* __restrict__ nchunks, uint32_t* __restrict__ nstore)
 {
     const uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nel) return;
@@ -949,6 +912,8 @@ __global__ void sign_box_kernel(const ElemRec* __restrict__ erec, uint32_t nel, 
         }
         if (vol == 0) B.dim[0] = B.dim[1] = B.dim[2] = 0;
         nchunks[el] = (uint32_t)((vol + 63) / 64);
+        const TileBox tb = tile_box(B.lo, B.dim);
+        nstore[el] = vol ? (uint32_t)(tb.td[0] * tb.td[1] * tb.td[2]) : 0u;
     }
     B.rmax = E.rmax;
     sbox[el] = B;
@@ -961,6 +926,7 @@ __global__ void sign_box_kernel(const ElemRec* __restrict__ erec, uint32_t nel, 
 // it does not, +inf when the candidate has no effect.
 __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restrict__ sbox, uint32_t nel,
                                                           const uint32_t* __restrict__ chunk_off, uint32_t nchunks,
+                                                          const uint32_t* __restrict__ store_off,
                                                           uint32_t cpw, const ElemRec* __restrict__ erec, GridDev g,
                                                           SlabInfo sl, double rho_t, const uint8_t* __restrict__ hot,
                                                           double* __restrict__ res)
@@ -987,7 +953,8 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
         const uint32_t v_begin = (c - co) * 64u;
         const uint32_t v_end = ((seg_end - co) * 64u < vol) ? (seg_end - co) * 64u : vol;
         const int lo0 = B.lo[0], lo1 = B.lo[1], lo2 = B.lo[2];
-        const size_t base = (size_t)co * 64u;
+        const uint32_t st_off = store_off[lo];
+        const TileBox tb = tile_box(B.lo, B.dim);
         uint32_t qn = 0;   // wave-uniform queue length
         for (uint32_t v0 = v_begin; v0 < v_end || qn > 0; v0 += 64u) {
             if (v0 < v_end) {
@@ -1003,7 +970,7 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
                     x[2] = grid_coord(g, 2, slab_global_k(sl, kl));
                     const uint32_t t = ((uint32_t)(kl >> 2) * sl.nty + (uint32_t)(j >> 2)) * sl.ntx + (uint32_t)(i >> 2);
                     pass = hot[t] && !hex8_outside(E, x);
-                    if (!pass) res[base + v] = INFINITY;
+                    if (!pass) res[tile_slot(st_off, tb, i, j, kl)] = INFINITY;
                 }
                 const uint64_t m = __ballot(pass);
                 if (pass) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = v;
@@ -1023,10 +990,11 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
                 if (have) {
                     uint32_t li, lj, lk;
                     box_decode(dec, v, li, lj, lk);
+                    const int i = lo0 + (int)li, j = lo1 + (int)lj, kl = lo2 + (int)lk;
                     double x[3], xi[3], N[8];
-                    x[0] = grid_coord(g, 0, lo0 + (int)li);
-                    x[1] = grid_coord(g, 1, lo1 + (int)lj);
-                    x[2] = grid_coord(g, 2, slab_global_k(sl, lo2 + (int)lk));
+                    x[0] = grid_coord(g, 0, i);
+                    x[1] = grid_coord(g, 1, j);
+                    x[2] = grid_coord(g, 2, slab_global_k(sl, kl));
                     inv_map_hex8(E, x, xi);
                     const double m = fmax(fabs(xi[0]), fmax(fabs(xi[1]), fabs(xi[2])));
                     double val = INFINITY;
@@ -1037,7 +1005,7 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
                         for (int k = 0; k < 8; ++k) rho += N[k] * E.r[k];
                         val = (rho >= rho_t) ? m : -m;
                     }
-                    res[base + v] = val;
+                    res[tile_slot(st_off, tb, i, j, kl)] = val;
                 }
             }
         }
@@ -1185,7 +1153,7 @@ struct MainArgs {
     const double* iso_res;     // per (iso item, box voxel) distances from iso_project_kernel
     const double* iso_res_xp;  // projection points (only when xp is requested)
     const void* sbox;          // HEX8: per-element boxes / chunk offsets / results of sign_project_kernel
-    const uint32_t* s_chunk_off;
+    const uint32_t* s_store_off;
     const double* sres;
     const uint8_t* hot;        // per tile: some candidate reaches rho_t
     int sdf_mode;  // 1: sdf = dist*sign in one kernel; 2: dist pass stores -dist; 3: sign pass flips;
@@ -1225,8 +1193,7 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                 const Rec& E = erec[T.el];
                 if (T.kind == 0) {
                     // WriteValue of the pre-computed iso candidate (sdfOnDensityField.jl:617-621)
-                    const size_t slot = (size_t)T.chunk_off * 64u +
-                                        ((size_t)(kl - T.lo[2]) * T.dim[1] + (j - T.lo[1])) * T.dim[0] + (i - T.lo[0]);
+                    const size_t slot = (size_t)tile_chunk(T.store_off, tile_box(T.lo, T.dim), tx, ty, tz) * 64u + (uint32_t)lane;
                     const double d = A.iso_res[slot];
                     if (fabs(d) < st.cur) {
                         st.cur = d;
@@ -1265,7 +1232,7 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) el[q] = A.sign_ent[(p + q < e) ? p + q : e - 1];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { B[q] = sbox[el[q]]; co[q] = A.s_chunk_off[el[q]]; }
+                    for (int q = 0; q < 4; ++q) { B[q] = sbox[el[q]]; co[q] = A.s_store_off[el[q]]; }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const uint32_t di = (uint32_t)(i - B[q].lo[0]), dj = (uint32_t)(j - B[q].lo[1]),
@@ -1274,7 +1241,7 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                                 dk < (uint32_t)B[q].dim[2];
                         v[q] = INFINITY;
                         if (in[q])
-                            v[q] = A.sres[(size_t)co[q] * 64u + ((size_t)dk * B[q].dim[1] + dj) * B[q].dim[0] + di];
+                            v[q] = A.sres[(size_t)tile_chunk(co[q], tile_box(B[q].lo, B[q].dim), tx, ty, tz) * 64u + (uint32_t)lane];
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -1387,6 +1354,7 @@ struct r2s_plan {
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
     DevBuf active, active_sign, active_any, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
     DevBuf sbox, s_nchunks, s_chunk_off, sres;   // item-major inverse maps of the sign pass (HEX8)
+    DevBuf nstore, store_off, s_nstore, s_store_off;   // storage (tile) chunk counts / offsets
     // state of the last run, for r2s_plan_pack_tiles_dev
     SlabInfo last_s;
     GridDev last_g;
@@ -1540,7 +1508,7 @@ void r2s_plan_destroy(r2s_plan* P)
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
                      &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any,
                      &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp,
-                     &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres,
+                     &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres, &P->nstore, &P->store_off, &P->s_nstore, &P->s_store_off,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
     for (DevBuf* b : all) b->release();
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
@@ -1672,15 +1640,21 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->items, sizeof(BandItem) * (size_t)std::max<uint32_t>(n_items, 1));
     ENSURE(P->nchunks, sizeof(uint32_t) * (size_t)(n_items + 1));
     ENSURE(P->chunk_off, sizeof(uint32_t) * (size_t)(n_items + 1));
+    ENSURE(P->nstore, sizeof(uint32_t) * (size_t)(n_items + 1));
+    ENSURE(P->store_off, sizeof(uint32_t) * (size_t)(n_items + 1));
     if (n_items) {
         HIP_TRY(hipMemsetAsync(P->nchunks.p, 0, sizeof(uint32_t) * (size_t)(n_items + 1), st));
+        HIP_TRY(hipMemsetAsync(P->nstore.p, 0, sizeof(uint32_t) * (size_t)(n_items + 1), st));
         item_build_kernel<ET><<<(unsigned)((nel + 63) / 64), 64, 0, st>>>(
             P->erec.as<typename ET::Rec>(), P->cls.as<uint8_t>(), P->fmask.as<uint8_t>(), P->item_off.as<uint32_t>(), nel,
-            g, s, delta, P->items.as<BandItem>(), P->nchunks.as<uint32_t>());
+            g, s, delta, P->items.as<BandItem>(), P->nchunks.as<uint32_t>(), P->nstore.as<uint32_t>());
         int rc = scan_exclusive(P, P->nchunks.as<uint32_t>(), P->chunk_off.as<uint32_t>(), (int64_t)n_items + 1, st);
         if (rc) return rc;
-        item_chunks_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(P->items.as<BandItem>(), P->chunk_off.as<uint32_t>(), n_items);
+        rc = scan_exclusive(P, P->nstore.as<uint32_t>(), P->store_off.as<uint32_t>(), (int64_t)n_items + 1, st);
+        if (rc) return rc;
+        item_chunks_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(P->items.as<BandItem>(), P->chunk_off.as<uint32_t>(), P->store_off.as<uint32_t>(), n_items);
         HIP_TRY(hipMemcpyAsync(&P->h_pinned[10], P->chunk_off.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&P->h_pinned[12], P->store_off.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(P->ev[1], st));
 
@@ -1691,7 +1665,10 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     if (n_items)
         band_bin_kernel<false><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr);
     if (want_sign)
-        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>());
+    {
+        sign_hot_kernel<typename ET::Rec><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
+        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>());
+    }
     {
         int rc = scan_exclusive(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
         if (rc) return rc;
@@ -1706,11 +1683,17 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             ENSURE(P->sbox, sizeof(SignBox) * (size_t)nel);
             ENSURE(P->s_nchunks, sizeof(uint32_t) * (size_t)(nel + 1));
             ENSURE(P->s_chunk_off, sizeof(uint32_t) * (size_t)(nel + 1));
+            ENSURE(P->s_nstore, sizeof(uint32_t) * (size_t)(nel + 1));
+            ENSURE(P->s_store_off, sizeof(uint32_t) * (size_t)(nel + 1));
             HIP_TRY(hipMemsetAsync(P->s_nchunks.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
-            sign_box_kernel<<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>());
+            HIP_TRY(hipMemsetAsync(P->s_nstore.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
+            sign_box_kernel<<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>(), P->s_nstore.as<uint32_t>());
             int rc = scan_exclusive(P, P->s_nchunks.as<uint32_t>(), P->s_chunk_off.as<uint32_t>(), nel + 1, st);
             if (rc) return rc;
+            rc = scan_exclusive(P, P->s_nstore.as<uint32_t>(), P->s_store_off.as<uint32_t>(), nel + 1, st);
+            if (rc) return rc;
             HIP_TRY(hipMemcpyAsync(&P->h_pinned[11], P->s_chunk_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&P->h_pinned[13], P->s_store_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
         }
     }
     active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), counters);
@@ -1722,10 +1705,12 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                    n_active_sign = P->h_pinned[5];
     P->last_s = s; P->last_g = g; P->last_n_any = P->h_pinned[8]; P->has_last = true;
     const uint32_t n_chunks = n_items ? P->h_pinned[10] : 0;
-    ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_chunks, 1));
+    const uint32_t n_store = n_items ? P->h_pinned[12] : 0;     // storage chunks (4x4x4 tiles of the item boxes)
+    ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_store, 1));
     const uint32_t n_schunks = sign_items ? P->h_pinned[11] : 0;
-    if (sign_items) ENSURE(P->sres, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_schunks, 1));
-    if (mode & R2S_OUT_XP) ENSURE(P->iso_res_xp, sizeof(double) * 192 * (size_t)std::max<uint32_t>(n_chunks, 1));
+    const uint32_t n_sstore = sign_items ? P->h_pinned[13] : 0;
+    if (sign_items) ENSURE(P->sres, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_sstore, 1));
+    if (mode & R2S_OUT_XP) ENSURE(P->iso_res_xp, sizeof(double) * 192 * (size_t)std::max<uint32_t>(n_store, 1));
     ENSURE(P->band_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
     ENSURE(P->band_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
     ENSURE(P->sign_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_sign, 1));
@@ -1735,7 +1720,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     if (n_items)
         band_bin_kernel<true><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>());
     if (want_sign)
-        sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), nullptr);
+        sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->hot.as<uint8_t>());
     // lists longer than 64 entries only occur when the grid is coarse relative to the mesh (few tiles)
     if (n_active) {
         bin_sort_small_kernel<<<(n_active + 255) / 256, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
@@ -1773,7 +1758,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         A.dist = (mode & R2S_OUT_DIST) ? d_dist : nullptr;
         A.sign = (mode & R2S_OUT_SIGN) ? d_sign : nullptr;
         A.sdf = (mode & R2S_OUT_SDF) ? d_sdf : nullptr;
-        A.sbox = P->sbox.p; A.s_chunk_off = P->s_chunk_off.as<uint32_t>(); A.sres = P->sres.as<double>();
+        A.sbox = P->sbox.p; A.s_store_off = P->s_store_off.as<uint32_t>(); A.sres = P->sres.as<double>();
         A.hot = P->hot.as<uint8_t>();
         if constexpr (HEX) {
             // inverse maps of the sign pass (item-major), beside the iso-surface projection when both run
@@ -1782,7 +1767,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             if (want_sign && n_schunks) {
                 static const int scpw_env = getenv("R2S_SIGN_CPW") ? atoi(getenv("R2S_SIGN_CPW")) : 8;
                 const uint32_t cpw = (uint32_t)(scpw_env > 0 ? scpw_env : 8), nwaves = (n_schunks + cpw - 1) / cpw;
-                sign_project_kernel<<<nwaves, 64, 0, ss>>>(P->sbox.as<SignBox>(), (uint32_t)nel, P->s_chunk_off.as<uint32_t>(), n_schunks, cpw,
+                sign_project_kernel<<<nwaves, 64, 0, ss>>>(P->sbox.as<SignBox>(), (uint32_t)nel, P->s_chunk_off.as<uint32_t>(), n_schunks, P->s_store_off.as<uint32_t>(), cpw,
                                                           P->erec.as<ElemRec>(), g, s, rho_t, P->hot.as<uint8_t>(), P->sres.as<double>());
             }
             HIP_TRY(hipEventRecord(P->ev2[2], ss));
@@ -1790,20 +1775,13 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
             HIP_TRY(hipEventRecord(P->ev[7], st));
             if (want_dist && n_chunks) {
-                static const int cpw_env = getenv("R2S_ISO_CPW") ? atoi(getenv("R2S_ISO_CPW")) : 8;
-                const uint32_t cpw = (uint32_t)(cpw_env > 0 ? cpw_env : 8), nwaves = (n_chunks + cpw - 1) / cpw;
-                static const int pl_env = getenv("R2S_ISO_PL") ? atoi(getenv("R2S_ISO_PL")) : 2;   // chunks per fetch; 0: per-item kernel
-                if (pl_env > 0) {
-                    const uint32_t group = (uint32_t)pl_env, ngroups = (n_chunks + group - 1) / group;
-                    const uint32_t resident = (uint32_t)P->n_cu * 4u * 3u;   // CUs x SIMDs x waves/SIMD of this kernel
-                    HIP_TRY(hipMemsetAsync(counters + 8, 0, 4, st));
-                    iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
-                        P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
-                        s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, counters + 8);
-                } else
-                iso_project_hex_kernel<<<nwaves, 64, 0, st>>>(
-                    P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, cpw, P->erec.as<ElemRec>(), g,
-                    s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
+                static const int pl_env = getenv("R2S_ISO_GROUP") ? atoi(getenv("R2S_ISO_GROUP")) : 4;   // chunks per fetch
+                const uint32_t group = (uint32_t)(pl_env > 0 ? pl_env : 4), ngroups = (n_chunks + group - 1) / group;
+                const uint32_t resident = (uint32_t)P->n_cu * 4u * 3u;   // CUs x SIMDs x waves/SIMD of this kernel
+                HIP_TRY(hipMemsetAsync(counters + 8, 0, 4, st));
+                iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
+                    P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
+                    s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, counters + 8);
             }
             HIP_TRY(hipEventRecord(P->ev[6], st));
             if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
@@ -1838,25 +1816,10 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             // item-major iso-surface projections, then the ordered gather over the band tiles
             A.iso_res = P->iso_res.as<double>();
             A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
-            if (want_dist && n_chunks) {
-                if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
-                    static const int cpw_env = getenv("R2S_ISO_CPW") ? atoi(getenv("R2S_ISO_CPW")) : 8;
-                    if (cpw_env > 0) {
-                        const uint32_t cpw = (uint32_t)cpw_env, nwaves = (n_chunks + cpw - 1) / cpw;
-                        iso_project_hex_kernel<<<nwaves, 64, 0, st>>>(
-                            P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, cpw, P->erec.as<ElemRec>(), g,
-                            s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
-                    } else {
-                        iso_project_kernel<ElemRec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
-                            P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<ElemRec>(), g,
-                            s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
-                    }
-                } else {
-                    iso_project_kernel<typename ET::Rec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
-                        P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
-                        s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
-                }
-            }
+            if (want_dist && n_chunks)
+                iso_project_kernel<typename ET::Rec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
+                    P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
+                    s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr);
             HIP_TRY(hipEventRecord(P->ev[6], st));
             if (want_dist && n_active) {
                 A.active = P->active.as<uint32_t>(); A.n_active = n_active;
