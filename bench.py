@@ -30,6 +30,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_VOXEL = 8.0      # one Float64 store per voxel; + mesh bytes / ngp
+DOMINANT_KERNEL = "iso_project_hex_pl_kernel"
 
 
 def cpu_baseline(X, IEN, rho_n, rho_t, n_max, stride):
@@ -156,11 +157,21 @@ def main():
         # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are
         # collected in separate rocprofv3 runs - tools/collect_traffic.py); only valid for the default workload
         traffic = None
+        valu = None
         tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        vfile = os.path.join(ROOT, "profiles", "r01_valu_counters.json")
         if os.path.exists(tfile) and args.grid == 512 and args.mesh == 46 and world == 1:
-            k = json.load(open(tfile))["kernels"].get("iso_project_kernel<r2s::ElemRec>")
+            k = json.load(open(tfile))["kernels"].get(DOMINANT_KERNEL)
             if k and k.get("FETCH_SIZE_KB") is not None and k.get("WRITE_SIZE_KB") is not None:
                 traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+        if os.path.exists(vfile) and args.grid == 512 and args.mesh == 46 and world == 1:
+            k = json.load(open(vfile)).get(DOMINANT_KERNEL)
+            if k:
+                # the kernel's real limiter (committed SQ counter passes, profiles/r01_valu_counters.json):
+                # FP64 VALU instructions per launch and the fraction of lanes doing useful work in them
+                valu = {"valu_insts_per_launch": k.get("SQ_INSTS_VALU"),
+                        "lane_utilisation": (k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"])
+                                             if k.get("SQ_ACTIVE_INST_VALU") else None)}
         out = {
             "metric": "Mvoxels/s SDF extract on 512^3 grid over 100k HEX8; max|err| vs ref",
             "value": value, "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,12 +182,14 @@ def main():
                                    f"fused dist*sign, Z-slabs over {world} GPU(s)",
                        "elements": int(len(IEN)), "voxels": int(ngp), "parallelism": (f"z-{args.partition}-{'sparse' if sg.sparse else 'dense'}-allgather-{world}"
                                        if world > 1 else "single-gpu")},
-            "roofline": {"bound": "hbm", "kernel": "iso_project_kernel<r2s::ElemRec>",
+            "roofline": {"bound": "hbm", "kernel": DOMINANT_KERNEL,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["ms_main"],
-                         "note": "FP64-VALU/latency-bound kernel (SURVEY.md 0.7); algorithmic bytes = 8 B/voxel "
-                                 "of the slab + mesh bytes; see DESIGN.md"},
+                         "valu": valu,
+                         "note": "FP64-VALU-bound kernel (SURVEY.md 0.7), co-running with sign_project_kernel on "
+                                 "a second stream; algorithmic bytes = 8 B/voxel of the slab + mesh bytes; "
+                                 "see DESIGN.md section 4"},
             "stages_ms": avg,
             "fill_kernel": {"GBps": (8.0 * nvox_rank) / (avg["ms_fill"] * 1e-3) / 1e9 if avg["ms_fill"] > 0 else None,
                             "frac_of_hbm_peak": (8.0 * nvox_rank) / (avg["ms_fill"] * 1e-3) / 1e9 / HBM_PEAK_GBS
