@@ -1024,14 +1024,15 @@ __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __res
                                                            uint32_t* __restrict__ active_band,
                                                            uint32_t* __restrict__ active_sign,
                                                            uint32_t* __restrict__ active_any,
+                                                           uint32_t* __restrict__ active_sonly,
                                                            uint32_t* __restrict__ counters)
 {
     // block-aggregated append: the three lists are collected in LDS (wave-aggregated LDS atomics), then ONE
     // global atomic per block and list reserves the output range (2.1 M tiles used to mean ~100 k same-address
     // atomics = 0.49 ms)
-    __shared__ uint32_t s_cnt[3], s_base[3], s_max[2];
-    __shared__ uint32_t s_list[3][256 * AT_ITEMS];
-    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+    __shared__ uint32_t s_cnt[4], s_base[4], s_max[2];
+    __shared__ uint32_t s_list[4][256 * AT_ITEMS];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_max[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -1043,9 +1044,11 @@ __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __res
         const bool in = t < ntiles;
         const uint32_t bc = in ? band_cnt[t] : 0u, sc = in ? sign_cnt[t] : 0u;
         const bool f[3] = {bc != 0, sc != 0 && hot[t] != 0, false};
-        const bool fl[3] = {f[0], f[1], f[0] || f[1]};   // [2]: union = what a sparse all-gather has to move
+        // [2]: union = what a sparse all-gather has to move; [3]: sign-only tiles (gathered as soon as the
+        // inverse maps are there, beside the iso-surface projection)
+        const bool fl[4] = {f[0], f[1], f[0] || f[1], f[1] && !f[0]};
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
+        for (int l = 0; l < 4; ++l) {
             const unsigned long long m = __ballot(fl[l]);
             if (m) {
                 uint32_t base = 0;
@@ -1061,18 +1064,18 @@ __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __res
     if (mxb > 64u) atomicMax(&s_max[0], mxb);
     if (mxs > 64u) atomicMax(&s_max[1], mxs);
     __syncthreads();
-    if (threadIdx.x < 3) {
-        const int idx[3] = {1, 2, 5};
+    if (threadIdx.x < 4) {
+        const int idx[4] = {1, 2, 5, 6};
         const uint32_t n = s_cnt[threadIdx.x];
         s_base[threadIdx.x] = n ? atomicAdd(&counters[idx[threadIdx.x]], n) : 0u;
-    } else if (threadIdx.x < 5) {
-        const uint32_t v = s_max[threadIdx.x - 3];
-        if (v > 64u) atomicMax(&counters[threadIdx.x], v);
+    } else if (threadIdx.x < 6) {
+        const uint32_t v = s_max[threadIdx.x - 4];
+        if (v > 64u) atomicMax(&counters[threadIdx.x - 1], v);
     }
     __syncthreads();
-    uint32_t* const out[3] = {active_band, active_sign, active_any};
+    uint32_t* const out[4] = {active_band, active_sign, active_any, active_sonly};
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < 4; ++l)
         for (uint32_t j = threadIdx.x; j < s_cnt[l]; j += 256u) out[l][s_base[l] + j] = s_list[l][j];
 }
 
@@ -1352,7 +1355,7 @@ struct r2s_plan {
     int n_cu = 256;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
-    DevBuf active, active_sign, active_any, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
+    DevBuf active, active_sign, active_any, active_sonly, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
     DevBuf sbox, s_nchunks, s_chunk_off, sres;   // item-major inverse maps of the sign pass (HEX8)
     DevBuf nstore, store_off, s_nstore, s_store_off;   // storage (tile) chunk counts / offsets
     // state of the last run, for r2s_plan_pack_tiles_dev
@@ -1489,12 +1492,13 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
     {
-        // lowest priority: the sign pass fills the wave slots the projection kernel leaves free and its tail
-        // (measured: equal priority 9.1 ms/step, high 9.6, low 8.5 on the north-star workload)
+        // high priority: the short stages of the second stream (sentinel sweep, inverse maps of the sign pass,
+        // sign-only gather) get wave slots ahead of the long persistent projection kernel.  Measured on the
+        // north-star workload: high 6.1-6.2 ms/step, normal / low 6.3-6.45.
         int prio_lo = 0, prio_hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        (void)prio_hi;
-        HIP_TRY(hipStreamCreateWithPriority(&P->st2, hipStreamNonBlocking, prio_lo));
+        static const int pr_env = getenv("R2S_ST2_PRIO") ? atoi(getenv("R2S_ST2_PRIO")) : 2;   // 0 low, 1 normal, 2 high
+        HIP_TRY(hipStreamCreateWithPriority(&P->st2, hipStreamNonBlocking, pr_env == 2 ? prio_hi : (pr_env == 1 ? (prio_lo + prio_hi) / 2 : prio_lo)));
     }
     *out = P;
     return 0;
@@ -1506,7 +1510,7 @@ void r2s_plan_destroy(r2s_plan* P)
     (void)hipSetDevice(P->device);
     DevBuf* all[] = {&P->deg, &P->ine_ptr, &P->ine, &P->cursor, &P->erec, &P->cls, &P->fmask, &P->nitems,
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
-                     &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any,
+                     &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any, &P->active_sonly,
                      &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp,
                      &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres, &P->nstore, &P->store_off, &P->s_nstore, &P->s_store_off,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
@@ -1595,6 +1599,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->active, sizeof(uint32_t) * (size_t)ntiles);
     ENSURE(P->active_sign, sizeof(uint32_t) * (size_t)ntiles);
     ENSURE(P->active_any, sizeof(uint32_t) * (size_t)ntiles);
+    ENSURE(P->active_sonly, sizeof(uint32_t) * (size_t)ntiles);
     ENSURE(P->hot, (size_t)ntiles + 1);
     ENSURE(P->counters, 64);
     uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] band tiles, [2] sign tiles
@@ -1696,10 +1701,10 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             HIP_TRY(hipMemcpyAsync(&P->h_pinned[13], P->s_store_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
         }
     }
-    active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), counters);
+    active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), P->active_sonly.as<uint32_t>(), counters);
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[2], P->band_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[3], P->sign_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 20, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 24, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4],
                    n_active_sign = P->h_pinned[5];
@@ -1770,6 +1775,17 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 sign_project_kernel<<<nwaves, 64, 0, ss>>>(P->sbox.as<SignBox>(), (uint32_t)nel, P->s_chunk_off.as<uint32_t>(), n_schunks, P->s_store_off.as<uint32_t>(), cpw,
                                                           P->erec.as<ElemRec>(), g, s, rho_t, P->hot.as<uint8_t>(), P->sres.as<double>());
             }
+            A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
+            A.sdf_mode = 1;
+            const uint32_t n_sonly = P->h_pinned[9];
+            const bool early_sign_tiles = want_dist && want_sign && !(mode & R2S_OUT_XP);
+            if (early_sign_tiles && n_sonly) {
+                // tiles without band items only need the inverse maps: gathered right behind sign_project,
+                // beside the iso-surface projection
+                MainArgs B = A;
+                B.active = P->active_sonly.as<uint32_t>(); B.n_active = n_sonly;
+                sdf_tiles_kernel<ElemRec, false, true><<<(n_sonly + 3) / 4, 256, 0, ss>>>(B);
+            }
             HIP_TRY(hipEventRecord(P->ev2[2], ss));
             A.iso_res = P->iso_res.as<double>();
             A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
@@ -1777,7 +1793,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             if (want_dist && n_chunks) {
                 static const int pl_env = getenv("R2S_ISO_GROUP") ? atoi(getenv("R2S_ISO_GROUP")) : 4;   // chunks per fetch
                 const uint32_t group = (uint32_t)(pl_env > 0 ? pl_env : 4), ngroups = (n_chunks + group - 1) / group;
-                const uint32_t resident = (uint32_t)P->n_cu * 4u * 3u;   // CUs x SIMDs x waves/SIMD of this kernel
+                static const int wps_env = getenv("R2S_ISO_WPS") ? atoi(getenv("R2S_ISO_WPS")) : 3;
+                const uint32_t resident = (uint32_t)P->n_cu * 4u * (uint32_t)(wps_env > 0 ? wps_env : 3);   // CUs x SIMDs x waves/SIMD of this kernel
                 HIP_TRY(hipMemsetAsync(counters + 8, 0, 4, st));
                 iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
                     P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
@@ -1786,9 +1803,10 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             HIP_TRY(hipEventRecord(P->ev[6], st));
             if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
             // ordered per-voxel gather: band items (distance) and candidate elements (sign) of every tile
-            A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
-            A.sdf_mode = 1;
-            if (want_dist && want_sign) {
+            if (want_dist && want_sign && early_sign_tiles) {
+                A.active = P->active.as<uint32_t>(); A.n_active = n_active;    // band tiles; the others are done
+                if (n_active) sdf_tiles_kernel<ElemRec, true, true><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+            } else if (want_dist && want_sign) {
                 const uint32_t n_any = P->h_pinned[8];
                 A.active = P->active_any.as<uint32_t>(); A.n_active = n_any;
                 if (n_any) sdf_tiles_kernel<ElemRec, true, true><<<(n_any + 3) / 4, 256, 0, st>>>(A);
