@@ -663,22 +663,36 @@ __device__ __forceinline__ bool sign_tile_range(const TetRec& E, const GridDev& 
     return true;
 }
 
+// the binning kernels spread the tile box of one item / element over a small lane group (the boxes hold
+// ~50-100 tiles; one thread per box left most of the GPU waiting on a serial chain of atomics)
+#define BIN_LANES 8
+__device__ __forceinline__ uint32_t tile_of(const int lo[3], const int hi[3], uint32_t q, const SlabInfo& s)
+{
+    const uint32_t n0 = (uint32_t)(hi[0] - lo[0] + 1), n1 = (uint32_t)(hi[1] - lo[1] + 1);
+    const uint32_t tz = q / (n0 * n1), r = q - tz * (n0 * n1), ty = r / n0, tx = r - ty * n0;
+    return ((uint32_t)(lo[2] + (int)tz) * s.nty + (uint32_t)(lo[1] + (int)ty)) * s.ntx + (uint32_t)(lo[0] + (int)tx);
+}
+__device__ __forceinline__ uint32_t tile_count(const int lo[3], const int hi[3])
+{
+    return (uint32_t)(hi[0] - lo[0] + 1) * (uint32_t)(hi[1] - lo[1] + 1) * (uint32_t)(hi[2] - lo[2] + 1);
+}
+
 template <bool FILL>
 __global__ void band_bin_kernel(const BandItem* __restrict__ items, uint32_t nitems, GridDev g, SlabInfo s,
                                 uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                 uint32_t* __restrict__ entries)
 {
-    uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t it = gid / BIN_LANES, sub = gid % BIN_LANES;
     if (it >= nitems) return;
     int lo[3], hi[3];
     if (!band_tile_range(items[it], g, s, lo, hi)) return;
-    for (int tz = lo[2]; tz <= hi[2]; ++tz)
-        for (int ty = lo[1]; ty <= hi[1]; ++ty)
-            for (int tx = lo[0]; tx <= hi[0]; ++tx) {
-                const uint32_t t = ((uint32_t)tz * s.nty + ty) * s.ntx + tx;
-                const uint32_t pos = atomicAdd(&cnt[t], 1u);
-                if (FILL) entries[off[t] + pos] = it;
-            }
+    const uint32_t n = tile_count(lo, hi);
+    for (uint32_t q = sub; q < n; q += BIN_LANES) {
+        const uint32_t t = tile_of(lo, hi, q, s);
+        const uint32_t pos = atomicAdd(&cnt[t], 1u);
+        if (FILL) entries[off[t] + pos] = it;
+    }
 }
 
 // a voxel is only examined when some candidate reaches rho_t (SignDetection.jl:36): tiles whose lists
@@ -687,14 +701,14 @@ template <class Rec>
 __global__ void sign_hot_kernel(const Rec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s, double rho_t,
                                 uint8_t* __restrict__ hot)
 {
-    uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t el = gid / BIN_LANES, sub = gid % BIN_LANES;
     if (el >= nel) return;
     if (erec[el].rmax < rho_t) return;
     int lo[3], hi[3];
     if (!sign_tile_range(erec[el], g, s, lo, hi)) return;
-    for (int tz = lo[2]; tz <= hi[2]; ++tz)
-        for (int ty = lo[1]; ty <= hi[1]; ++ty)
-            for (int tx = lo[0]; tx <= hi[0]; ++tx) hot[((uint32_t)tz * s.nty + ty) * s.ntx + tx] = 1;
+    const uint32_t n = tile_count(lo, hi);
+    for (uint32_t q = sub; q < n; q += BIN_LANES) hot[tile_of(lo, hi, q, s)] = 1;
 }
 
 // candidate lists of the hot tiles only (count pass, then fill pass)
@@ -703,18 +717,18 @@ __global__ void sign_bin_kernel(const Rec* __restrict__ erec, uint32_t nel, Grid
                                 uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                 uint32_t* __restrict__ entries, const uint8_t* __restrict__ hot)
 {
-    uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t el = gid / BIN_LANES, sub = gid % BIN_LANES;
     if (el >= nel) return;
     int lo[3], hi[3];
     if (!sign_tile_range(erec[el], g, s, lo, hi)) return;
-    for (int tz = lo[2]; tz <= hi[2]; ++tz)
-        for (int ty = lo[1]; ty <= hi[1]; ++ty)
-            for (int tx = lo[0]; tx <= hi[0]; ++tx) {
-                const uint32_t t = ((uint32_t)tz * s.nty + ty) * s.ntx + tx;
-                if (!hot[t]) continue;
-                const uint32_t pos = atomicAdd(&cnt[t], 1u);
-                if (FILL) entries[off[t] + pos] = el;
-            }
+    const uint32_t n = tile_count(lo, hi);
+    for (uint32_t q = sub; q < n; q += BIN_LANES) {
+        const uint32_t t = tile_of(lo, hi, q, s);
+        if (!hot[t]) continue;
+        const uint32_t pos = atomicAdd(&cnt[t], 1u);
+        if (FILL) entries[off[t] + pos] = el;
+    }
 }
 
 // Persistent kernel: the element record of a lane sits in LDS (a few slots per wavefront), so the lanes
@@ -881,19 +895,22 @@ __global__ void sign_box_kernel(const ElemRec* __restrict__ erec, uint32_t nel, 
                                 const uint8_t* __restrict__ hot, SignBox* __restrict__ sbox,
                                 uint32_t* __restrict__ nchunks, uint32_t* __restrict__ nstore)
 {
-    const uint32_t el = blockIdx.x * blockDim.x + threadIdx.x;
-    if (el >= nel) return;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t el = gid / BIN_LANES, sub = gid % BIN_LANES;
+    const bool live = el < nel;
     SignBox B;
     memset(&B, 0, sizeof B);
-    const ElemRec& E = erec[el];
+    const ElemRec& E = erec[live ? el : 0];
     int lo[3], hi[3];
-    bool rel = false;
-    if (sign_tile_range(E, g, s, lo, hi)) {
-        for (int tz = lo[2]; tz <= hi[2] && !rel; ++tz)
-            for (int ty = lo[1]; ty <= hi[1] && !rel; ++ty)
-                for (int tx = lo[0]; tx <= hi[0]; ++tx)
-                    if (hot[((uint32_t)tz * s.nty + ty) * s.ntx + tx]) { rel = true; break; }
+    bool found = false;
+    if (live && sign_tile_range(E, g, s, lo, hi)) {
+        const uint32_t n = tile_count(lo, hi);
+        for (uint32_t q = sub; q < n && !found; q += BIN_LANES) found = hot[tile_of(lo, hi, q, s)] != 0;
     }
+    // any lane of the element's group
+    const unsigned long long m = __ballot(found);
+    const bool rel = ((m >> ((threadIdx.x & 63u) & ~(unsigned)(BIN_LANES - 1))) & ((1ull << BIN_LANES) - 1ull)) != 0;
+    if (!live || sub != 0) return;
     if (rel) {
         const int nmax[3] = {g.nx - 1, g.ny - 1, g.nz - 1};
         uint64_t vol = 1;
@@ -1605,18 +1622,6 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] band tiles, [2] sign tiles
 
     HIP_TRY(hipEventRecord(P->ev[0], st));
-    // ---- sentinel sweep: on the second stream, beside the mesh preparation and the binning ----
-    // (HBM-bound, needs only the outputs; the first kernel that writes a voxel waits for ev2[3])
-    {
-        const unsigned fill_grid = 256 * 8;
-        HIP_TRY(hipStreamWaitEvent(P->st2, P->ev[0], 0));
-        HIP_TRY(hipEventRecord(P->ev2[0], P->st2));
-        if (mode & R2S_OUT_DIST) fill_kernel<<<fill_grid, 256, 0, P->st2>>>(d_dist, nvox, 1.0e10);
-        if (mode & R2S_OUT_SIGN) fill_kernel<<<fill_grid, 256, 0, P->st2>>>(d_sign, nvox, -1.0);
-        if (mode & R2S_OUT_SDF) fill_kernel<<<fill_grid, 256, 0, P->st2>>>(d_sdf, nvox, -1.0e10);
-        if (mode & R2S_OUT_XP) HIP_TRY(hipMemsetAsync(d_xp, 0, sizeof(double) * 3 * (size_t)nvox, P->st2));
-        HIP_TRY(hipEventRecord(P->ev2[3], P->st2));
-    }
     // ---- node -> element CSR ----
     HIP_TRY(hipMemsetAsync(P->deg.p, 0, sizeof(uint32_t) * (size_t)(nnp + 1), st));
     HIP_TRY(hipMemsetAsync(P->cursor.p, 0, sizeof(uint32_t) * (size_t)(nnp + 1), st));
@@ -1668,11 +1673,11 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipMemsetAsync(P->sign_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
     HIP_TRY(hipMemsetAsync(P->hot.p, 0, (size_t)ntiles + 1, st));
     if (n_items)
-        band_bin_kernel<false><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr);
+        band_bin_kernel<false><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr);
     if (want_sign)
     {
-        sign_hot_kernel<typename ET::Rec><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
-        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>());
+        sign_hot_kernel<typename ET::Rec><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
+        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>());
     }
     {
         int rc = scan_exclusive(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
@@ -1692,7 +1697,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             ENSURE(P->s_store_off, sizeof(uint32_t) * (size_t)(nel + 1));
             HIP_TRY(hipMemsetAsync(P->s_nchunks.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
             HIP_TRY(hipMemsetAsync(P->s_nstore.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
-            sign_box_kernel<<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>(), P->s_nstore.as<uint32_t>());
+            sign_box_kernel<<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>(), P->s_nstore.as<uint32_t>());
             int rc = scan_exclusive(P, P->s_nchunks.as<uint32_t>(), P->s_chunk_off.as<uint32_t>(), nel + 1, st);
             if (rc) return rc;
             rc = scan_exclusive(P, P->s_nstore.as<uint32_t>(), P->s_store_off.as<uint32_t>(), nel + 1, st);
@@ -1723,9 +1728,9 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipMemsetAsync(P->band_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
     HIP_TRY(hipMemsetAsync(P->sign_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
     if (n_items)
-        band_bin_kernel<true><<<(n_items + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>());
+        band_bin_kernel<true><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>());
     if (want_sign)
-        sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->hot.as<uint8_t>());
+        sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->hot.as<uint8_t>());
     // lists longer than 64 entries only occur when the grid is coarse relative to the mesh (few tiles)
     if (n_active) {
         bin_sort_small_kernel<<<(n_active + 255) / 256, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
@@ -1746,11 +1751,22 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     static const bool overlap_env = !(getenv("R2S_NO_OVERLAP") && atoi(getenv("R2S_NO_OVERLAP")));
     const bool overlap = !HEX && overlap_env && mode == R2S_OUT_SDF && want_sign && want_dist;   // TET4 flow
     const bool fork = HEX && overlap_env && want_sign && want_dist && n_chunks && n_schunks;      // HEX8 flow
-    HIP_TRY(hipStreamWaitEvent(st, P->ev2[3], 0));   // the sweep (second stream, started with the preparation)
-    HIP_TRY(hipEventRecord(P->ev[3], st));
-    if (overlap || fork) {   // fork: the sign pass follows the sweep on the second stream
-        HIP_TRY(hipStreamWaitEvent(P->st2, P->ev[3], 0));
-        HIP_TRY(hipEventRecord(P->ev2[1], P->st2));
+    // ---- sentinel sweep ----
+    // HBM-bound and only needed by the gathers: with two streams it goes first on the second stream, beside
+    // the start of the (FP64-bound) projection kernel; the sign stages follow it there.
+    {
+        const bool two_streams = overlap || fork;
+        hipStream_t fs = two_streams ? P->st2 : st;
+        const unsigned fill_grid = 256 * 8;
+        if (two_streams) HIP_TRY(hipStreamWaitEvent(P->st2, P->ev[2], 0));
+        HIP_TRY(hipEventRecord(P->ev2[0], fs));
+        if (mode & R2S_OUT_DIST) fill_kernel<<<fill_grid, 256, 0, fs>>>(d_dist, nvox, 1.0e10);
+        if (mode & R2S_OUT_SIGN) fill_kernel<<<fill_grid, 256, 0, fs>>>(d_sign, nvox, -1.0);
+        if (mode & R2S_OUT_SDF) fill_kernel<<<fill_grid, 256, 0, fs>>>(d_sdf, nvox, -1.0e10);
+        if (mode & R2S_OUT_XP) HIP_TRY(hipMemsetAsync(d_xp, 0, sizeof(double) * 3 * (size_t)nvox, fs));
+        HIP_TRY(hipEventRecord(P->ev2[3], fs));
+        HIP_TRY(hipEventRecord(P->ev[3], st));
+        if (two_streams) HIP_TRY(hipEventRecord(P->ev2[1], P->st2));
     }
 
     // ---- projection / sign kernel over the active tiles ----
@@ -1876,7 +1892,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         float ms = 0;
         if (hipEventElapsedTime(&ms, P->ev[0], P->ev[1]) == hipSuccess) stats->ms_prep = ms;
         if (hipEventElapsedTime(&ms, P->ev[1], P->ev[2]) == hipSuccess) stats->ms_bins = ms;
-        if (hipEventElapsedTime(&ms, P->ev2[0], P->ev2[3]) == hipSuccess) stats->ms_fill = ms;   // beside prep + bins
+        if (hipEventElapsedTime(&ms, P->ev2[0], P->ev2[3]) == hipSuccess) stats->ms_fill = ms;   // second stream: beside the projection kernel
         if (hipEventElapsedTime(&ms, P->ev[7], P->ev[6]) == hipSuccess) stats->ms_main = ms;
         if (hipEventElapsedTime(&ms, P->ev[6], P->ev[4]) == hipSuccess) stats->ms_gather = ms;
         stats->n_iso_chunks = n_chunks;
