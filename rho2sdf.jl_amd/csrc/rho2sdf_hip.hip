@@ -1205,26 +1205,68 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
         const int ci = (int)cell_of(A.g, 0, x[0]), cj = (int)cell_of(A.g, 1, x[1]),
                   ck = (int)cell_of(A.g, 2, x[2]);
         const uint32_t b = A.band_off[t], e = A.band_off[t + 1];
-        for (uint32_t p = b; p < e; ++p) {
-            const BandItem& T = A.items[A.band_ent[p]];
-            const bool in = valid && ci >= T.imin[0] && ci <= T.imax[0] && cj >= T.imin[1] &&
-                            cj <= T.imax[1] && ck >= T.imin[2] && ck <= T.imax[2];
-            if (in) {
-                const Rec& E = erec[T.el];
-                if (T.kind == 0) {
-                    // WriteValue of the pre-computed iso candidate (sdfOnDensityField.jl:617-621)
-                    const size_t slot = (size_t)tile_chunk(T.store_off, tile_box(T.lo, T.dim), tx, ty, tz) * 64u + (uint32_t)lane;
-                    const double d = A.iso_res[slot];
-                    if (fabs(d) < st.cur) {
-                        st.cur = d;
-                        if (A.iso_res_xp) {
-                            st.xp[0] = A.iso_res_xp[3 * slot];
-                            st.xp[1] = A.iso_res_xp[3 * slot + 1];
-                            st.xp[2] = A.iso_res_xp[3 * slot + 2];
+        // Lane l fetches the header of list entry l (two dependent vector loads for the whole list instead of
+        // two dependent scalar loads per item); the headers are then broadcast item by item (v_readlane) and
+        // the iso look-ups of four items are issued together.  Items are consumed in list order, which is all
+        // the update rules depend on.
+        for (uint32_t p0 = b; p0 < e; p0 += 64u) {
+            const uint32_t n = (e - p0 < 64u) ? e - p0 : 64u;
+            int32_t my_it = 0;
+            int32_t h[15];   // imin[3], imax[3], el, kind, lo[3], dim[3], store_off
+#pragma unroll
+            for (int q = 0; q < 15; ++q) h[q] = 0;
+            if ((uint32_t)lane < n) {
+                my_it = (int32_t)A.band_ent[p0 + lane];
+                const int32_t* w = reinterpret_cast<const int32_t*>(&A.items[my_it]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h[q] = w[q];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) h[8 + q] = w[offsetof(BandItem, lo) / 4 + q];
+                h[14] = w[offsetof(BandItem, store_off) / 4];
+            }
+            for (uint32_t q0 = 0; q0 < n; q0 += 4u) {
+                bool in[4];
+                int kind[4];
+                size_t slot[4];
+                double d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = q0 + u < n;
+                    const int qq = (int)(ok ? q0 + u : n - 1u);
+                    int32_t hh[15];
+#pragma unroll
+                    for (int q = 0; q < 15; ++q) hh[q] = __builtin_amdgcn_readlane(h[q], qq);
+                    in[u] = valid && ok && ci >= hh[0] && ci <= hh[3] && cj >= hh[1] && cj <= hh[4] && ck >= hh[2] &&
+                            ck <= hh[5];
+                    kind[u] = hh[7];
+                    slot[u] = 0;
+                    d[u] = INFINITY;
+                    if (kind[u] == 0) {
+                        const int32_t lo3[3] = {hh[8], hh[9], hh[10]}, dim3[3] = {hh[11], hh[12], hh[13]};
+                        slot[u] = (size_t)tile_chunk((uint32_t)hh[14], tile_box(lo3, dim3), tx, ty, tz) * 64u + (uint32_t)lane;
+                        if (in[u]) d[u] = A.iso_res[slot[u]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (in[u]) {
+                        if (kind[u] == 0) {
+                            // WriteValue of the pre-computed iso candidate (sdfOnDensityField.jl:617-621)
+                            if (fabs(d[u]) < st.cur) {
+                                st.cur = d[u];
+                                if (A.iso_res_xp) {
+                                    st.xp[0] = A.iso_res_xp[3 * slot[u]];
+                                    st.xp[1] = A.iso_res_xp[3 * slot[u] + 1];
+                                    st.xp[2] = A.iso_res_xp[3 * slot[u] + 2];
+                                }
+                            }
+                        } else {
+#ifndef R2S_NO_TRI
+                            const BandItem& T = A.items[__builtin_amdgcn_readlane(my_it, (int)(q0 + u))];
+                            process_triangle(st, T, erec[T.el], A.rho_t, x);
+#endif
                         }
                     }
-                } else {
-                    process_triangle(st, T, E, A.rho_t, x);
                 }
             }
         }
@@ -1241,38 +1283,50 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                 const SignBox* __restrict__ sbox = static_cast<const SignBox*>(A.sbox);
                 bool any = false, done = false;
                 double cmax = -INFINITY, max_local = 10.0;
-                // four candidates per trip: their records and lookups are independent loads (issued together),
-                // the state machine then consumes them in order.  "Point inside the element's AABB"
+                // lane l fetches the record of candidate l; records are broadcast one by one (v_readlane), four
+                // look-ups are issued together, and the state machine consumes them in order.  "Point inside the element's AABB"
                 // (SignDetection.jl:30) == "lattice index inside the element's box" by construction of the box.
-                for (uint32_t p = b; p < e; p += 4) {
-                    uint32_t el[4], co[4];
-                    SignBox B[4];
-                    bool in[4];
-                    double v[4];
+                for (uint32_t p0 = b; p0 < e; p0 += 64u) {
+                    const uint32_t n = (e - p0 < 64u) ? e - p0 : 64u;
+                    int32_t hs[9];   // lo[3], dim[3], rmax (2 words), store_off of candidate l
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) el[q] = A.sign_ent[(p + q < e) ? p + q : e - 1];
+                    for (int q = 0; q < 9; ++q) hs[q] = 0;
+                    if ((uint32_t)lane < n) {
+                        const uint32_t el = A.sign_ent[p0 + lane];
+                        const int32_t* w = reinterpret_cast<const int32_t*>(&sbox[el]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { B[q] = sbox[el[q]]; co[q] = A.s_store_off[el[q]]; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t di = (uint32_t)(i - B[q].lo[0]), dj = (uint32_t)(j - B[q].lo[1]),
-                                       dk = (uint32_t)(kl - B[q].lo[2]);
-                        in[q] = valid && (p + q < e) && di < (uint32_t)B[q].dim[0] && dj < (uint32_t)B[q].dim[1] &&
-                                dk < (uint32_t)B[q].dim[2];
-                        v[q] = INFINITY;
-                        if (in[q])
-                            v[q] = A.sres[(size_t)tile_chunk(co[q], tile_box(B[q].lo, B[q].dim), tx, ty, tz) * 64u + (uint32_t)lane];
+                        for (int q = 0; q < 8; ++q) hs[q] = w[q];
+                        hs[8] = (int32_t)A.s_store_off[el];
                     }
+                    for (uint32_t q0 = 0; q0 < n; q0 += 4u) {
+                        bool in[4];
+                        double v[4], rmax[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (in[q]) {
-                            any = true;
-                            if (B[q].rmax > cmax) cmax = B[q].rmax;
-                            const double m = fabs(v[q]);
-                            if (!done && m < 1.01 && max_local > m) {
-                                if (!__builtin_signbit(v[q])) sg = 1.0;
-                                if (m < 0.95) done = true;
-                                else max_local = m;
+                        for (int u = 0; u < 4; ++u) {
+                            const bool ok = q0 + u < n;
+                            const int qq = (int)(ok ? q0 + u : n - 1u);
+                            int32_t hh[9];
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) hh[q] = __builtin_amdgcn_readlane(hs[q], qq);
+                            const int32_t lo3[3] = {hh[0], hh[1], hh[2]}, dim3[3] = {hh[3], hh[4], hh[5]};
+                            const uint32_t di = (uint32_t)(i - lo3[0]), dj = (uint32_t)(j - lo3[1]), dk = (uint32_t)(kl - lo3[2]);
+                            in[u] = valid && ok && di < (uint32_t)dim3[0] && dj < (uint32_t)dim3[1] && dk < (uint32_t)dim3[2];
+                            rmax[u] = __hiloint2double(hh[7], hh[6]);
+                            v[u] = INFINITY;
+                            if (in[u])
+                                v[u] = A.sres[(size_t)tile_chunk((uint32_t)hh[8], tile_box(lo3, dim3), tx, ty, tz) * 64u + (uint32_t)lane];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (in[u]) {
+                                any = true;
+                                if (rmax[u] > cmax) cmax = rmax[u];
+                                const double m = fabs(v[u]);
+                                if (!done && m < 1.01 && max_local > m) {
+                                    if (!__builtin_signbit(v[u])) sg = 1.0;
+                                    if (m < 0.95) done = true;
+                                    else max_local = m;
+                                }
                             }
                         }
                     }
@@ -1384,7 +1438,7 @@ struct r2s_plan {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // second stream: sentinel sweep + sign pass run beside the iso-surface projection (fused SDF output)
     hipStream_t st2 = nullptr;
-    hipEvent_t ev2[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static int scan_exclusive(r2s_plan* P, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st, int level = 0)
@@ -1507,7 +1561,7 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     }
     HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocDefault));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
-    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
+    for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
     {
         // high priority: the short stages of the second stream (sentinel sweep, inverse maps of the sign pass,
         // sign-only gather) get wave slots ahead of the long persistent projection kernel.  Measured on the
@@ -1535,7 +1589,7 @@ void r2s_plan_destroy(r2s_plan* P)
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
     for (int i = 0; i < 8; ++i)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
     if (P->st2) (void)hipStreamDestroy(P->st2);
     delete P;
@@ -1745,15 +1799,19 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipEventRecord(P->ev[2], st));
 
     // ---- fork ----
-    // Fused SDF output only: after the sweep the sign pass goes to a second stream and runs beside the iso-surface
-    // projection (both are latency-bound FP64 chains; together they fill the SIMDs better); the ordered
-    // gather then waits for both and keeps the sign already stored.
+    // HEX8, distance + sign wanted: the inverse maps of the sign pass (and the sign-only gather) run on a
+    // second stream beside the iso-surface projection; the band gather waits for both.  TET4, fused output:
+    // the in-gather sign pass runs on the second stream.
     static const bool overlap_env = !(getenv("R2S_NO_OVERLAP") && atoi(getenv("R2S_NO_OVERLAP")));
     const bool overlap = !HEX && overlap_env && mode == R2S_OUT_SDF && want_sign && want_dist;   // TET4 flow
     const bool fork = HEX && overlap_env && want_sign && want_dist && n_chunks && n_schunks;      // HEX8 flow
     // ---- sentinel sweep ----
     // HBM-bound and only needed by the gathers: with two streams it goes first on the second stream, beside
-    // the start of the (FP64-bound) projection kernel; the sign stages follow it there.
+    // the start of the (FP64-bound) projection kernel, and the sign stages follow it there.  Measured
+    // alternatives (north-star workload, ms/step): sweep at the start of the call beside prep + binning 5.9
+    // (its waves delay the short kernels, even with a quarter-size grid); sign_project before the sweep 6.5
+    // and sign_project starting together with the projection kernel 6.7 (the projection kernel is the long
+    // pole and should get its persistent waves placed first); this order 5.55.
     {
         const bool two_streams = overlap || fork;
         hipStream_t fs = two_streams ? P->st2 : st;
@@ -1791,6 +1849,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 sign_project_kernel<<<nwaves, 64, 0, ss>>>(P->sbox.as<SignBox>(), (uint32_t)nel, P->s_chunk_off.as<uint32_t>(), n_schunks, P->s_store_off.as<uint32_t>(), cpw,
                                                           P->erec.as<ElemRec>(), g, s, rho_t, P->hot.as<uint8_t>(), P->sres.as<double>());
             }
+            HIP_TRY(hipEventRecord(P->ev2[4], ss));   // inverse maps done: all the band gather waits for
             A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
             A.sdf_mode = 1;
             const uint32_t n_sonly = P->h_pinned[9];
@@ -1817,7 +1876,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                     s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, counters + 8);
             }
             HIP_TRY(hipEventRecord(P->ev[6], st));
-            if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
+            if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[4], 0));   // (the sweep precedes it on that stream)
             // ordered per-voxel gather: band items (distance) and candidate elements (sign) of every tile
             if (want_dist && want_sign && early_sign_tiles) {
                 A.active = P->active.as<uint32_t>(); A.n_active = n_active;    // band tiles; the others are done
@@ -1833,6 +1892,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 A.active = P->active_sign.as<uint32_t>(); A.n_active = n_active_sign;
                 if (n_active_sign) sdf_tiles_kernel<ElemRec, false, true><<<(n_active_sign + 3) / 4, 256, 0, st>>>(A);
             }
+            if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));   // sign-only gather (second stream), beside the band gather
             HIP_TRY(hipEventRecord(P->ev[4], st));
         } else {
             HIP_TRY(hipEventRecord(P->ev[7], st));
