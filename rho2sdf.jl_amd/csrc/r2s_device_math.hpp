@@ -31,6 +31,8 @@ struct alignas(16) ElemRec {
     // Sign_Detection's candidate test cannot accept it and the Newton solve is skipped (exact pruning)
     double pn[6][3];
     double po[6];
+    // first Newton step of the inverse map (xi = 0): rows of the adjugate of J(0) = [C1 C2 C3] and 1/det
+    double nw[10];
 };
 
 // band work item: one boundary-face triangle (process_triangle_projection!,
@@ -199,6 +201,29 @@ R2S_DEV void hex8_planes(ElemRec& R)
     }
 }
 
+// constants of the inverse map's first Newton step (see inv_map_hex8): the cofactor / det / reciprocal
+// expressions of its general iteration, evaluated at xi = 0 where J[i][q] = C[q+1][i]
+R2S_DEV void hex8_newton0(ElemRec& R)
+{
+    double J[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int q = 0; q < 3; ++q) J[i][q] = R.C[q + 1][i];
+    const double c00 = fma(J[1][1], J[2][2], -(J[1][2] * J[2][1]));
+    const double c01 = fma(J[1][2], J[2][0], -(J[1][0] * J[2][2]));
+    const double c02 = fma(J[1][0], J[2][1], -(J[1][1] * J[2][0]));
+    const double det = fma(J[0][2], c02, fma(J[0][1], c01, J[0][0] * c00));   // = dot3(J[0][:], c0:)
+    const double c10 = fma(J[0][2], J[2][1], -(J[0][1] * J[2][2]));
+    const double c11 = fma(J[0][0], J[2][2], -(J[0][2] * J[2][0]));
+    const double c12 = fma(J[0][1], J[2][0], -(J[0][0] * J[2][1]));
+    const double c20 = fma(J[0][1], J[1][2], -(J[0][2] * J[1][1]));
+    const double c21 = fma(J[0][2], J[1][0], -(J[0][0] * J[1][2]));
+    const double c22 = fma(J[0][0], J[1][1], -(J[0][1] * J[1][0]));
+    R.nw[0] = c00; R.nw[1] = c10; R.nw[2] = c20;
+    R.nw[3] = c01; R.nw[4] = c11; R.nw[5] = c21;
+    R.nw[6] = c02; R.nw[7] = c12; R.nw[8] = c22;
+    R.nw[9] = 1.0 / det;
+}
+
 // true when x lies outside one of the bounding half-spaces (no local coordinates with max|xi| < 1.01)
 template <class ER>
 R2S_DEV bool hex8_outside(const ER& E, const double x[3])
@@ -256,7 +281,25 @@ template <class ER>
 R2S_DEV bool inv_map_hex8(const ER& E, const double x[3], double xi[3])
 {
     xi[0] = xi[1] = xi[2] = 0.0;
-    for (int it = 0; it < 50; ++it) {
+    {
+        // iteration 0: at xi = 0 the map gives X = C[0] and J = [C1 C2 C3] exactly, so the adjugate and
+        // 1/det of that first Newton step are per-element constants (ElemRec::nw, hex8_newton0) - the same
+        // IEEE operations as the general iteration below, one sixth of its cost
+        const double R0 = E.C[0][0] - x[0], R1 = E.C[0][1] - x[1], R2 = E.C[0][2] - x[2];
+        const double d0 = -dot3(E.nw[0], E.nw[1], E.nw[2], R0, R1, R2) * E.nw[9];
+        const double d1 = -dot3(E.nw[3], E.nw[4], E.nw[5], R0, R1, R2) * E.nw[9];
+        const double d2 = -dot3(E.nw[6], E.nw[7], E.nw[8], R0, R1, R2) * E.nw[9];
+        const double n0 = fmin(fmax(xi[0] + d0, -1.1), 1.1);
+        const double n1 = fmin(fmax(xi[1] + d1, -1.1), 1.1);
+        const double n2 = fmin(fmax(xi[2] + d2, -1.1), 1.1);
+        const double step = fmax(fabs(n0 - xi[0]), fmax(fabs(n1 - xi[1]), fabs(n2 - xi[2])));
+        xi[0] = n0; xi[1] = n1; xi[2] = n2;
+        if (!(step > 1e-10)) {
+            if (step != step) { xi[0] = xi[1] = xi[2] = 10.0; return false; }
+            return true;
+        }
+    }
+    for (int it = 1; it < 50; ++it) {
         double R[3], J[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {

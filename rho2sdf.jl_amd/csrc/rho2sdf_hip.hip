@@ -38,7 +38,7 @@ __constant__ int c_hex_isn[6][4] = {{0, 3, 2, 1}, {0, 1, 5, 4}, {1, 2, 6, 5},
 // ------------------------------------------------------------------------------------
 // exclusive scan of uint32 (block = 256 threads x 4 items)
 // ------------------------------------------------------------------------------------
-#define SCAN_BLOCK 256
+#define SCAN_BLOCK 1024
 #define SCAN_ITEMS 4
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
 
@@ -192,7 +192,7 @@ struct HexT {
     using Rec = ElemRec;
     static constexpr int NEN = 8, NES = 6, NSN = 4;
     static __device__ __forceinline__ int face(int sg, int a) { return c_hex_isn[sg][a]; }
-    static __device__ void finish(Rec& R, const GridDev&) { hex8_monomials(R); hex8_planes(R); }
+    static __device__ void finish(Rec& R, const GridDev&) { hex8_monomials(R); hex8_planes(R); hex8_newton0(R); }
 };
 struct TetT {
     using Rec = TetRec;
@@ -1568,8 +1568,8 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
         // north-star workload: high 6.1-6.2 ms/step, normal / low 6.3-6.45.
         int prio_lo = 0, prio_hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        static const int pr_env = getenv("R2S_ST2_PRIO") ? atoi(getenv("R2S_ST2_PRIO")) : 2;   // 0 low, 1 normal, 2 high
-        HIP_TRY(hipStreamCreateWithPriority(&P->st2, hipStreamNonBlocking, pr_env == 2 ? prio_hi : (pr_env == 1 ? (prio_lo + prio_hi) / 2 : prio_lo)));
+        (void)prio_lo;
+        HIP_TRY(hipStreamCreateWithPriority(&P->st2, hipStreamNonBlocking, prio_hi));
     }
     *out = P;
     return 0;
@@ -1844,8 +1844,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             hipStream_t ss = fork ? P->st2 : st;
             if (!fork) HIP_TRY(hipEventRecord(P->ev2[1], ss));
             if (want_sign && n_schunks) {
-                static const int scpw_env = getenv("R2S_SIGN_CPW") ? atoi(getenv("R2S_SIGN_CPW")) : 8;
-                const uint32_t cpw = (uint32_t)(scpw_env > 0 ? scpw_env : 8), nwaves = (n_schunks + cpw - 1) / cpw;
+                const uint32_t cpw = 8, nwaves = (n_schunks + cpw - 1) / cpw;   // chunks per wavefront
                 sign_project_kernel<<<nwaves, 64, 0, ss>>>(P->sbox.as<SignBox>(), (uint32_t)nel, P->s_chunk_off.as<uint32_t>(), n_schunks, P->s_store_off.as<uint32_t>(), cpw,
                                                           P->erec.as<ElemRec>(), g, s, rho_t, P->hot.as<uint8_t>(), P->sres.as<double>());
             }
@@ -1866,10 +1865,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
             HIP_TRY(hipEventRecord(P->ev[7], st));
             if (want_dist && n_chunks) {
-                static const int pl_env = getenv("R2S_ISO_GROUP") ? atoi(getenv("R2S_ISO_GROUP")) : 4;   // chunks per fetch
-                const uint32_t group = (uint32_t)(pl_env > 0 ? pl_env : 4), ngroups = (n_chunks + group - 1) / group;
-                static const int wps_env = getenv("R2S_ISO_WPS") ? atoi(getenv("R2S_ISO_WPS")) : 3;
-                const uint32_t resident = (uint32_t)P->n_cu * 4u * (uint32_t)(wps_env > 0 ? wps_env : 3);   // CUs x SIMDs x waves/SIMD of this kernel
+                const uint32_t group = 4, ngroups = (n_chunks + group - 1) / group;   // chunks per fetch (1-8: +-2 %)
+                const uint32_t resident = (uint32_t)P->n_cu * 4u * 3u;   // CUs x SIMDs x waves/SIMD of this kernel
                 HIP_TRY(hipMemsetAsync(counters + 8, 0, 4, st));
                 iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
                     P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
