@@ -1004,7 +1004,7 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
                         hex8_shape(xi, N);
                         for (int i = 0; i < 3; ++i) {
                             double s = 0.0;
-                            for (int k = 0; k < 8; ++k) s += Xe[k][i] * N[k];
+                            for (int k = 0; k < 8; ++k) s = fma(Xe[k][i], N[k], s);
                             xp[i] = s;
                             dv[i] = x[i] - s;
                         }

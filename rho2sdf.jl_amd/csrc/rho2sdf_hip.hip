@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
                 for (int i = 0; i < 3; ++i) {
                     double t = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) t += E.X[k][i] * N[k];
+                    for (int k = 0; k < 8; ++k) t = fma(E.X[k][i], N[k], t);
                     xp[i] = t;
                 }
                 res[my] = norm3(s.x[0] - xp[0], s.x[1] - xp[1], s.x[2] - xp[2]);
