@@ -107,8 +107,9 @@ def main():
     plan = pkg.DevicePlan(dev_index)
 
     class TileOps:   # HIP kernels behind the sparse stitching (r2s_plan_pack_tiles_dev & co.)
-        pack = staticmethod(lambda local, payload, ids: plan.pack_tiles(local, payload, ids))
+        pack2 = staticmethod(lambda local, payload, ids, masks, mids: plan.pack_tiles2(local, payload, ids, masks, mids))
         unpack = staticmethod(lambda payload, ids, n, vol: plan.unpack_tiles(payload, ids, n, grid, vol))
+        unpack_masks = staticmethod(lambda masks, mids, n, vol: plan.unpack_masks(masks, mids, n, grid, vol))
         fill = staticmethod(lambda t, v: plan.fill(t, v))
 
     sg = slabs.SlabGather((nx, ny, nz), rank, world, dev,

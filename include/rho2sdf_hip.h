@@ -81,6 +81,7 @@ typedef struct {
      * tile bins, sentinel sweep, iso_project_kernel (ms_main), ordered gather
      * (sdf_tiles_kernel<dist>), sign kernel */
     double ms_prep, ms_bins, ms_fill, ms_main, ms_gather, ms_sign;
+    int64_t n_sign_only_tiles; /* tiles without band items whose voxels are all +-1e10 (compressed stitching) */
 } r2s_stats;
 
 int r2s_version(void);
@@ -147,6 +148,14 @@ int r2s_plan_pack_tiles_dev(r2s_plan *plan, const double *d_local_sdf, double *d
 int r2s_unpack_tiles_dev(const double *d_payload, const uint32_t *d_ids, int64_t n_tiles, const r2s_grid *grid,
                          double *d_volume, void *stream);
 int r2s_fill_dev(double *d, int64_t n, double value, void *stream);
+/* Compressed variant of the same exchange: tiles with band items (r2s_stats.n_active_tiles) travel as 64
+ * doubles; tiles that only carry the sign (r2s_stats.n_sign_only_tiles, every voxel +-1e10) travel as one
+ * 64-bit mask (bit l set = voxel l of the tile is +1e10) - 12 B instead of 516 B per tile. */
+int r2s_plan_pack_tiles2_dev(r2s_plan *plan, const double *d_local_sdf, double *d_payload, uint32_t *d_ids,
+                             int64_t capacity_full, uint64_t *d_masks, uint32_t *d_mask_ids, int64_t capacity_mask,
+                             int64_t *n_full_out, int64_t *n_mask_out, void *stream);
+int r2s_unpack_masks_dev(const uint64_t *d_masks, const uint32_t *d_mask_ids, int64_t n_tiles, const r2s_grid *grid,
+                         double magnitude, double *d_volume, void *stream);
 
 /* ---- pre-stage: mesh volume, nodal densities, volume-preserving threshold ------------- */
 

@@ -34,7 +34,8 @@ class R2SStats(ctypes.Structure):
                 ("n_any_tiles", ctypes.c_int64),
                 ("ms_prep", ctypes.c_double), ("ms_bins", ctypes.c_double),
                 ("ms_fill", ctypes.c_double), ("ms_main", ctypes.c_double),
-                ("ms_gather", ctypes.c_double), ("ms_sign", ctypes.c_double)]
+                ("ms_gather", ctypes.c_double), ("ms_sign", ctypes.c_double),
+                ("n_sign_only_tiles", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -64,6 +65,9 @@ SYMBOLS = [
     ("r2s_plan_pack_tiles_dev", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, c_int64_p, _P]),
     ("r2s_unpack_tiles_dev", ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.POINTER(R2SGrid), _P, _P]),
     ("r2s_fill_dev", ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_double, _P]),
+    ("r2s_plan_pack_tiles2_dev", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, c_int64_p,
+                                                c_int64_p, _P]),
+    ("r2s_unpack_masks_dev", ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.POINTER(R2SGrid), ctypes.c_double, _P, _P]),
     ("r2s_mesh_volume", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_int32, c_double_p, c_double_p]),
     ("r2s_dense_in_nodes", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_int32, c_double_p]),
     ("r2s_find_threshold", ctypes.c_int, _MESH + [c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int32,

@@ -211,6 +211,23 @@ class DevicePlan:
                                              ctypes.byref(grid.c), ctypes.c_void_p(volume.data_ptr()),
                                              DevicePlan._stream(stream)))
 
+    def pack_tiles2(self, local_sdf, payload, ids, masks, mask_ids, stream=None):
+        """compressed packing: band tiles -> payload (n,64) f64 / ids i32; sign-only tiles -> masks i64 / mask_ids i32.
+        Returns (n_full, n_mask)."""
+        nf, nm = ctypes.c_int64(), ctypes.c_int64()
+        L.check(L.lib().r2s_plan_pack_tiles2_dev(
+            self._h, ctypes.c_void_p(local_sdf.data_ptr()), ctypes.c_void_p(payload.data_ptr()),
+            ctypes.c_void_p(ids.data_ptr()), int(ids.numel()), ctypes.c_void_p(masks.data_ptr()),
+            ctypes.c_void_p(mask_ids.data_ptr()), int(mask_ids.numel()), ctypes.byref(nf), ctypes.byref(nm),
+            self._stream(stream)))
+        return int(nf.value), int(nm.value)
+
+    @staticmethod
+    def unpack_masks(masks, mask_ids, n, grid, volume, magnitude=1.0e10, stream=None):
+        L.check(L.lib().r2s_unpack_masks_dev(ctypes.c_void_p(masks.data_ptr()), ctypes.c_void_p(mask_ids.data_ptr()), int(n),
+                                             ctypes.byref(grid.c), float(magnitude), ctypes.c_void_p(volume.data_ptr()),
+                                             DevicePlan._stream(stream)))
+
     @staticmethod
     def fill(t, value, stream=None):
         L.check(L.lib().r2s_fill_dev(ctypes.c_void_p(t.data_ptr()), int(t.numel()), float(value), DevicePlan._stream(stream)))

@@ -1418,6 +1418,41 @@ __global__ void __launch_bounds__(256) unpack_tiles_kernel(const double* __restr
     if (i < nx && j < ny && k < nz) volume[((int64_t)k * ny + j) * nx + i] = payload[(size_t)w * 64 + lane];
 }
 
+// sign-only tiles: every voxel is +-1e10, one 64-bit mask per tile
+__global__ void __launch_bounds__(256) pack_masks_kernel(const uint32_t* __restrict__ tiles, uint32_t n, SlabInfo s,
+                                                        GridDev g, const double* __restrict__ local,
+                                                        uint64_t* __restrict__ masks, uint32_t* __restrict__ ids)
+{
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= n) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = tiles[w];
+    const int tx = t % s.ntx, ty = (t / s.ntx) % s.nty, tz = t / (s.ntx * s.nty);
+    const int i = tx * 4 + (lane & 3), j = ty * 4 + ((lane >> 2) & 3), kl = tz * 4 + (lane >> 4);
+    const int k = slab_global_k(s, kl);
+    const bool valid = (i < g.nx) && (j < g.ny) && (kl < s.nzl) && (k < s.k1);
+    const uint64_t m = __ballot(valid && local[((int64_t)kl * g.ny + j) * g.nx + i] > 0.0);
+    if (lane == 0) {
+        masks[w] = m;
+        ids[w] = ((uint32_t)(k >> 2) * s.nty + ty) * s.ntx + tx;
+    }
+}
+
+__global__ void __launch_bounds__(256) unpack_masks_kernel(const uint64_t* __restrict__ masks,
+                                                          const uint32_t* __restrict__ ids, uint32_t n, int nx, int ny,
+                                                          int nz, double magnitude, double* __restrict__ volume)
+{
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int ntx = (nx + 3) / 4, nty = (ny + 3) / 4;
+    const uint32_t t = ids[w];
+    const uint64_t m = masks[w];
+    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+    const int i = tx * 4 + (lane & 3), j = ty * 4 + ((lane >> 2) & 3), k = tz * 4 + (lane >> 4);
+    if (i < nx && j < ny && k < nz) volume[((int64_t)k * ny + j) * nx + i] = ((m >> lane) & 1ull) ? magnitude : -magnitude;
+}
+
 // ------------------------------------------------------------------------------------
 // plan: device workspace that survives across calls
 // ------------------------------------------------------------------------------------
@@ -1432,7 +1467,7 @@ struct r2s_plan {
     // state of the last run, for r2s_plan_pack_tiles_dev
     SlabInfo last_s;
     GridDev last_g;
-    uint32_t last_n_any = 0;
+    uint32_t last_n_any = 0, last_n_band = 0, last_n_sonly = 0;
     bool has_last = false;
     uint32_t* h_pinned = nullptr;  // 16 words
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1767,7 +1802,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4],
                    n_active_sign = P->h_pinned[5];
-    P->last_s = s; P->last_g = g; P->last_n_any = P->h_pinned[8]; P->has_last = true;
+    P->last_s = s; P->last_g = g; P->last_n_any = P->h_pinned[8]; P->last_n_band = P->h_pinned[4]; P->last_n_sonly = P->h_pinned[9]; P->has_last = true;
     const uint32_t n_chunks = n_items ? P->h_pinned[10] : 0;
     const uint32_t n_store = n_items ? P->h_pinned[12] : 0;     // storage chunks (4x4x4 tiles of the item boxes)
     ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_store, 1));
@@ -1946,6 +1981,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         stats->n_active_tiles = n_active;
         stats->n_active_sign_tiles = n_active_sign;
         stats->n_any_tiles = P->last_n_any;
+        stats->n_sign_only_tiles = P->last_n_sonly;
         float ms = 0;
         if (hipEventElapsedTime(&ms, P->ev[0], P->ev[1]) == hipSuccess) stats->ms_prep = ms;
         if (hipEventElapsedTime(&ms, P->ev[1], P->ev[2]) == hipSuccess) stats->ms_bins = ms;
@@ -2053,6 +2089,42 @@ int r2s_unpack_tiles_dev(const double* d_payload, const uint32_t* d_ids, int64_t
     if (n_tiles)
         unpack_tiles_kernel<<<(unsigned)((n_tiles + 3) / 4), 256, 0, (hipStream_t)stream>>>(
             d_payload, d_ids, (uint32_t)n_tiles, (int)grid->N[0] + 1, (int)grid->N[1] + 1, (int)grid->N[2] + 1, d_volume);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int r2s_plan_pack_tiles2_dev(r2s_plan* P, const double* d_local, double* d_payload, uint32_t* d_ids,
+                             int64_t capacity_full, uint64_t* d_masks, uint32_t* d_mask_ids, int64_t capacity_mask,
+                             int64_t* n_full_out, int64_t* n_mask_out, void* stream)
+{
+    if (!P || !P->has_last) return fail(R2S_ERR_ARG, "r2s_plan_pack_tiles2_dev: no previous r2s_plan_run_dev on this plan");
+    const uint32_t nf = P->last_n_band, nm = P->last_n_sonly;
+    if (n_full_out) *n_full_out = nf;
+    if (n_mask_out) *n_mask_out = nm;
+    if (!d_local || (nf && (!d_payload || !d_ids)) || (nm && (!d_masks || !d_mask_ids))) return fail(R2S_ERR_ARG, "null argument");
+    if ((int64_t)nf > capacity_full || (int64_t)nm > capacity_mask)
+        return fail(R2S_ERR_ARG, "capacity (%lld, %lld) < (%u, %u) tiles", (long long)capacity_full, (long long)capacity_mask, nf, nm);
+    if ((P->last_s.k0 & 3) != 0) return fail(R2S_ERR_ARG, "tile packing needs a Z partition aligned to 4-plane tile layers");
+    HIP_TRY(hipSetDevice(P->device));
+    if (nf)
+        pack_tiles_kernel<<<(nf + 3) / 4, 256, 0, (hipStream_t)stream>>>(P->active.as<uint32_t>(), nf, P->last_s, P->last_g, d_local,
+                                                                       -1.0e10, d_payload, d_ids);
+    if (nm)
+        pack_masks_kernel<<<(nm + 3) / 4, 256, 0, (hipStream_t)stream>>>(P->active_sonly.as<uint32_t>(), nm, P->last_s, P->last_g,
+                                                                       d_local, d_masks, d_mask_ids);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int r2s_unpack_masks_dev(const uint64_t* d_masks, const uint32_t* d_mask_ids, int64_t n_tiles, const r2s_grid* grid,
+                         double magnitude, double* d_volume, void* stream)
+{
+    if (!grid || !d_volume || (n_tiles > 0 && (!d_masks || !d_mask_ids)) || n_tiles < 0 || n_tiles >= ((int64_t)1 << 31))
+        return fail(R2S_ERR_ARG, "r2s_unpack_masks_dev: bad argument");
+    if (n_tiles)
+        unpack_masks_kernel<<<(unsigned)((n_tiles + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+            d_masks, d_mask_ids, (uint32_t)n_tiles, (int)grid->N[0] + 1, (int)grid->N[1] + 1, (int)grid->N[2] + 1, magnitude,
+            d_volume);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -10,9 +10,10 @@ Partitions (equal-sized contributions to ONE all_gather_into_tensor):
 
 Stitching:
   dense        the whole Float64 volume travels (8 B/voxel)
-  sparse       only the 4x4x4 tiles that can differ from the sentinel travel (64 values + a tile id);
-               every rank pre-fills its volume with the sentinel and scatters the tiles it receives.
-               Interleaved partition only (tile layers are aligned by construction).
+  sparse       only the 4x4x4 tiles that can differ from the sentinel travel, in ONE all_gather_into_tensor:
+               tiles with band items as 64 values + a tile id, tiles that only carry the sign (every voxel
+               +-1e10) as a 64-bit mask + a tile id; every rank pre-fills its volume with the sentinel and
+               scatters what it receives.  Interleaved partition only (tile layers are aligned by construction).
 """
 TILE = 4  # planes per tile layer (the kernels work on 4x4x4 voxel tiles)
 SENTINEL = -1.0e10   # dist = 1e10 (untouched) * sign = -1
@@ -38,9 +39,10 @@ class SlabGather:
 
     dense:  rank r writes its part in place at its offset of `gathered`; one all_gather_into_tensor.
     sparse: rank r computes into `local`, packs its non-sentinel tiles, one (padded) all_gather_into_tensor
-            of the tile payloads + ids, then every rank scatters all tiles into its pre-filled volume.
-            `ops` supplies pack(local, payload, ids) -> n, unpack(payload, ids, n, volume) and
-            fill(volume, value) (HIP kernels on the GPU, numpy stand-ins in the CPU tests).
+            of [payloads | ids | sign masks | mask ids], then every rank scatters everything into its
+            pre-filled volume.  `ops` supplies pack2(local, payload, ids, masks, mask_ids) -> (n_full, n_mask),
+            unpack(payload, ids, n, volume), unpack_masks(masks, mask_ids, n, volume) and fill(volume, value)
+            (HIP kernels on the GPU, numpy stand-ins in the CPU tests).
     """
 
     def __init__(self, dims, rank, world, device, dtype=None, interleaved=False, sparse=False, ops=None):
@@ -80,34 +82,54 @@ class SlabGather:
         """view of exactly the voxels this rank computes"""
         return self.mine[:self.my_planes * self.plane]
 
-    def gather(self, n_tiles=None):
+    @staticmethod
+    def _segment_views(seg, mf, mm):
+        """views into one rank's segment (a float64 tensor): band-tile payload (mf*64 f64), their ids (mf i32),
+        sign-only masks (mm i64), their ids (mm i32); every part starts on an 8-byte boundary"""
+        import torch
+        hf, hm = (mf + 1) // 2, (mm + 1) // 2
+        o = mf * 64
+        payload = seg[:o]
+        ids = seg[o:o + hf].view(torch.int32)[:mf]
+        o += hf
+        masks = seg[o:o + mm].view(torch.int64)
+        o += mm
+        mids = seg[o:o + hm].view(torch.int32)[:mm]
+        return payload, ids, masks, mids
+
+    def gather(self, counts=None):
+        """counts = (band tiles, sign-only tiles) of this rank's last run (sparse stitching only)"""
         import torch
         import torch.distributed as dist
         if not self.sparse:
             if self.world > 1:
                 dist.all_gather_into_tensor(self.gathered, self.mine)
             return
-        # ---- sparse: counts, padded payload gather, scatter ----
-        n_mine = int(n_tiles) if self.my_planes > 0 else 0
-        counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
-        mine_cnt = torch.tensor([n_mine], dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(counts, mine_cnt)
-        counts = [int(c) for c in counts.tolist()]
-        self.last_counts = counts
-        m = max(max(counts), 1)
-        payload = torch.empty(self.world * m * 64, dtype=self.dtype, device=self.device)
-        ids = torch.zeros(self.world * m, dtype=torch.int32, device=self.device)
-        my_payload = payload[self.rank * m * 64:(self.rank + 1) * m * 64]
-        my_ids = ids[self.rank * m:(self.rank + 1) * m]
-        if n_mine:
-            got = self.ops.pack(self.my_slab, my_payload, my_ids)
-            assert got == n_mine, (got, n_mine)
+        # ---- sparse: counts, ONE padded all-gather of [payload | ids | masks | mask ids], scatter ----
+        nf_mine, nm_mine = (int(counts[0]), int(counts[1])) if self.my_planes > 0 else (0, 0)
+        allc = torch.zeros(2 * self.world, dtype=torch.int64, device=self.device)
+        mine_cnt = torch.tensor([nf_mine, nm_mine], dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(allc, mine_cnt)
+        allc = allc.view(self.world, 2).tolist()
+        self.last_counts = allc
+        mf = max(max(int(c[0]) for c in allc), 1)
+        mm = max(max(int(c[1]) for c in allc), 1)
+        seglen = mf * 64 + (mf + 1) // 2 + mm + (mm + 1) // 2
+        buf = torch.empty(self.world * seglen, dtype=self.dtype, device=self.device)
+        seg = buf[self.rank * seglen:(self.rank + 1) * seglen]
+        payload, ids, masks, mids = self._segment_views(seg, mf, mm)
+        if nf_mine or nm_mine:
+            got = self.ops.pack2(self.my_slab, payload, ids, masks, mids)
+            assert tuple(got) == (nf_mine, nm_mine), (got, nf_mine, nm_mine)
         self.ops.fill(self.full, SENTINEL)
-        dist.all_gather_into_tensor(payload, my_payload)
-        dist.all_gather_into_tensor(ids, my_ids)
-        for r, c in enumerate(counts):
-            if c:
-                self.ops.unpack(payload[r * m * 64:(r * m + c) * 64], ids[r * m:r * m + c], c, self.full)
+        dist.all_gather_into_tensor(buf, seg)
+        self.last_bytes = buf.numel() * buf.element_size()
+        for r, (cf, cm) in enumerate(allc):
+            payload, ids, masks, mids = self._segment_views(buf[r * seglen:(r + 1) * seglen], mf, mm)
+            if cf:
+                self.ops.unpack(payload[:int(cf) * 64], ids[:int(cf)], int(cf), self.full)
+            if cm:
+                self.ops.unpack_masks(masks[:int(cm)], mids[:int(cm)], int(cm), self.full)
 
     def volume(self):
         """the stitched (nz, ny, nx) volume (padding trimmed, tile layers back in lattice order)"""
@@ -133,5 +155,6 @@ def run_step(sg, compute_slab):
             st = compute_slab(0, sg.nz, sg.my_slab, sg.world, sg.rank)
         else:
             st = compute_slab(sg.k0, sg.k1, sg.my_slab, 1, 0)
-    sg.gather(n_tiles=(st or {}).get("n_any_tiles", 0) if sg.sparse else None)
+    s = st or {}
+    sg.gather(counts=(s.get("n_active_tiles", 0), s.get("n_sign_only_tiles", 0)) if sg.sparse else None)
     return st

@@ -227,3 +227,44 @@ def test_sparse_tile_stitching_equals_full_volume(pkg, oracle):
             ntiles = ((nx + 3) // 4) * ((ny + 3) // 4) * ((nz + 3) // 4)
             assert moved < ntiles       # fewer tiles than the dense volume
     plan.close()
+
+
+def test_compressed_tile_stitching_equals_full_volume(pkg, oracle):
+    """compressed stitching (r2s_plan_pack_tiles2_dev / r2s_unpack_masks_dev): band tiles travel as 64 doubles,
+    sign-only tiles as one 64-bit mask; scattering every rank's share must reproduce the full-volume run bit for bit"""
+    import torch
+    from rho2sdf_jl_amd import slabs, synthetic
+    X, IEN, rn = synthetic.hex_mesh(8)
+    dev = torch.device("cuda:0")
+    dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rn))
+    plan = pkg.DevicePlan(0)
+    for npts in (120, 37):
+        pg = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(npts), 3)
+        nx, ny, nz = pg.dims
+        full = torch.empty(nz * ny * nx, dtype=torch.float64, device=dev)
+        plan.run(dX, dI, dR, 0.5, pg, sdf=full)
+        for world in (2, 3, 8):
+            vol = torch.empty_like(full)
+            plan.fill(vol, -1.0e10)
+            n_full = n_mask = 0
+            for r in range(world):
+                owned, _ = slabs.interleaved_layers(nz, world, r)
+                if not owned:
+                    continue
+                local = torch.empty(4 * owned * ny * nx, dtype=torch.float64, device=dev)
+                st = plan.run(dX, dI, dR, 0.5, pg, sdf=local, zstride=world, zphase=r)
+                nf, nm = st["n_active_tiles"], st["n_sign_only_tiles"]
+                assert nf + nm == st["n_any_tiles"]
+                payload = torch.empty(max(nf, 1) * 64, dtype=torch.float64, device=dev)
+                ids = torch.zeros(max(nf, 1), dtype=torch.int32, device=dev)
+                masks = torch.zeros(max(nm, 1), dtype=torch.int64, device=dev)
+                mids = torch.zeros(max(nm, 1), dtype=torch.int32, device=dev)
+                assert plan.pack_tiles2(local, payload, ids, masks, mids) == (nf, nm)
+                plan.unpack_tiles(payload, ids, nf, pg, vol)
+                plan.unpack_masks(masks, mids, nm, pg, vol)
+                n_full += nf
+                n_mask += nm
+            torch.cuda.synchronize()
+            assert torch.equal(vol, full), f"{world} ranks, {npts}^3: compressed stitching differs"
+            assert n_mask > 0 or npts < 100     # the finer grid has tiles deep inside the solid
+    plan.close()

@@ -14,7 +14,8 @@ from conftest import ROOT, load_fixture
 
 
 class NumpyTileOps:
-    """CPU stand-ins for r2s_plan_pack_tiles_dev / r2s_unpack_tiles_dev / r2s_fill_dev (same tile layout)"""
+    """CPU stand-ins for r2s_plan_pack_tiles2_dev / r2s_unpack_tiles_dev / r2s_unpack_masks_dev / r2s_fill_dev
+    (same tile layout)"""
 
     def __init__(self, dims, world, rank):
         self.nx, self.ny, self.nz = dims
@@ -36,15 +37,32 @@ class NumpyTileOps:
                         out.append((((tz * self.world + self.rank) * self.nty + ty) * self.ntx + tx, blk.reshape(-1)))
         return out
 
-    def count(self, local):
-        return len(self._tiles(local))
+    @staticmethod
+    def _sign_only(blk):
+        return bool((np.abs(blk) == 1.0e10).all())
 
-    def pack(self, local, payload, ids):
+    def counts(self, local):
+        """(tiles that travel as 64 values, tiles that travel as a sign mask)"""
         t = self._tiles(local)
-        for w, (tid, blk) in enumerate(t):
-            payload[w * 64:(w + 1) * 64] = torch.from_numpy(blk)
-            ids[w] = tid
-        return len(t)
+        nm = sum(1 for _, blk in t if self._sign_only(blk))
+        return len(t) - nm, nm
+
+    def pack2(self, local, payload, ids, masks, mask_ids):
+        nf = nm = 0
+        for tid, blk in self._tiles(local):
+            if self._sign_only(blk):
+                m = 0
+                for l in range(64):
+                    if blk[l] > 0:
+                        m |= 1 << l
+                masks[nm] = m - (1 << 64) if m >= (1 << 63) else m     # int64 storage of the 64-bit mask
+                mask_ids[nm] = tid
+                nm += 1
+            else:
+                payload[nf * 64:(nf + 1) * 64] = torch.from_numpy(blk)
+                ids[nf] = tid
+                nf += 1
+        return nf, nm
 
     def unpack(self, payload, ids, n, vol):
         v = vol.view(self.nz, self.ny, self.nx).numpy()
@@ -52,6 +70,15 @@ class NumpyTileOps:
             tid = int(ids[w])
             tx, ty, tz = tid % self.ntx, (tid // self.ntx) % self.nty, tid // (self.ntx * self.nty)
             blk = payload[w * 64:(w + 1) * 64].numpy().reshape(4, 4, 4)
+            sub = v[4 * tz:4 * tz + 4, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4]
+            sub[...] = blk[:sub.shape[0], :sub.shape[1], :sub.shape[2]]
+
+    def unpack_masks(self, masks, mask_ids, n, vol):
+        v = vol.view(self.nz, self.ny, self.nx).numpy()
+        for w in range(n):
+            tid, m = int(mask_ids[w]), int(masks[w]) & ((1 << 64) - 1)
+            tx, ty, tz = tid % self.ntx, (tid // self.ntx) % self.nty, tid // (self.ntx * self.nty)
+            blk = np.array([1.0e10 if (m >> l) & 1 else -1.0e10 for l in range(64)]).reshape(4, 4, 4)
             sub = v[4 * tz:4 * tz + 4, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4]
             sub[...] = blk[:sub.shape[0], :sub.shape[1], :sub.shape[2]]
 
@@ -86,7 +113,8 @@ def _worker(rank, world, port, ref_path, dims, interleaved, sparse=False):
                     if k < nz:
                         o[4 * i + l] = ref[k * plane:(k + 1) * plane]
             o[torch.isnan(o)] = -1.0e10      # planes beyond the grid
-            return {"n_any_tiles": ops.count(out)}
+            nf, nm = ops.counts(out)
+            return {"n_active_tiles": nf, "n_sign_only_tiles": nm}
 
     slabs.run_step(sg, compute_slab)
     ok = torch.equal(sg.volume().reshape(-1), ref)
@@ -129,7 +157,8 @@ def test_slab_bounds():
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sparse_tile_allgather(oracle, tmp_path, world):
-    """sparse stitching: only non-sentinel 4x4x4 tiles travel (counts + padded payload all-gather + scatter)"""
+    """sparse stitching: only non-sentinel 4x4x4 tiles travel, sign-only tiles as 64-bit masks (counts + ONE padded
+    all-gather + scatter)"""
     X, IEN, rho = load_fixture("sphere")
     rn = oracle.dense_in_nodes(X, IEN, rho)
     g = oracle.grid_make(X.min(0), X.max(0), 10)
