@@ -483,18 +483,84 @@ __global__ void __launch_bounds__(256) rbf_matvec_kernel(RbfGeom G, const float*
     y[t] = acc;
 }
 
+// The CG of compute_rbf_weights applies the same sparse matrix every iteration: when HBM has room its
+// entries are materialised once, tap-major ([tap][voxel] Float32, 288 GB make 512^3 x 81 taps = 43 GB
+// affordable), and each matvec becomes a coalesced stream instead of 81 exp() per voxel.  Taps are listed
+// in the loop order of rbf_matvec_kernel and absent entries are stored as 0, so the row sums are formed
+// in the same order from the same values (bit-identical results).
+#define RBF_MAX_TAPS 160
+struct RbfTaps {
+    int n;
+    signed char off[RBF_MAX_TAPS][3];
+};
+__global__ void __launch_bounds__(256) rbf_kbuild_kernel(RbfGeom G, RbfTaps T, float* __restrict__ kv)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
+    if (t >= n) return;
+    const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
+    const float px = G.cx[i], py = G.cy[j], pz = G.cz[k];
+    for (int q = 0; q < T.n; ++q) {
+        const int ci = i + T.off[q][0], cj = j + T.off[q][1], ck = k + T.off[q][2];
+        float v = 0.0f;
+        if (!(ci < 0 || cj < 0 || ck < 0 || ci >= G.nx || cj >= G.ny || ck >= G.nz)) {
+            const float dx = px - G.cx[ci], dy = py - G.cy[cj], dz = pz - G.cz[ck];
+            const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+            const double u = (double)r / G.sigma;
+            const double val = exp(-(u * u));
+            if (val > G.thr) v = (float)val;
+        }
+        kv[(int64_t)q * n + t] = v;
+    }
+}
+__global__ void __launch_bounds__(256) rbf_matvec_k_kernel(RbfGeom G, RbfTaps T, const float* __restrict__ kv,
+                                                          const float* __restrict__ x, float* __restrict__ y)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
+    if (t >= n) return;
+    float acc = 0.0f;
+    // eight taps per trip: their matrix entries and x values are independent loads in flight together; an
+    // absent entry is stored as 0 and its x index is clamped, so the products are added in tap order
+    // exactly as the on-the-fly kernel adds the present ones
+    for (int q0 = 0; q0 < T.n; q0 += 8) {
+        float v[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u;
+            v[u] = 0.0f;
+            xv[u] = 0.0f;
+            if (q < T.n) {
+                v[u] = kv[(int64_t)q * n + t];
+                int64_t o = t + ((int64_t)T.off[q][2] * G.ny + T.off[q][1]) * G.nx + T.off[q][0];
+                o = o < 0 ? 0 : (o >= n ? n - 1 : o);
+                xv[u] = x[o];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] != 0.0f) acc += v[u] * xv[u];
+    }
+    y[t] = acc;
+}
+
 // process_vector (:15-22), pass 1: max |v| over |v| < 1e9 (as Float32 bits, all non-negative)
 __global__ void pv_max_kernel(const double* __restrict__ v, int64_t n, float* __restrict__ f, uint32_t* __restrict__ maxbits,
                               uint32_t* __restrict__ any)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid-stride: a fixed grid keeps the number of same-address atomics at one per wavefront of the GRID
+    // (one per wavefront of the DATA was 2.1 M atomics = 19 ms at 512^3)
     uint32_t bits = 0;
     bool has = false;
-    if (i < n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float x = (float)v[i];
         f[i] = x;
         const float a = fabsf(x);
-        if (a < 1.0e9f) { bits = __float_as_uint(a); has = true; }
+        if (a < 1.0e9f) {
+            const uint32_t b = __float_as_uint(a);
+            bits = b > bits ? b : bits;
+            has = true;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -564,12 +630,12 @@ __global__ void cg_update_xr_kernel(float* __restrict__ x, float* __restrict__ r
 __global__ void minmax_kernel(const float* __restrict__ v, int64_t n, int* __restrict__ mm)
 {
     // order-preserving int encoding of floats
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lo = 0x7FFFFFFF, hi = (int)0x80000000;
-    if (i < n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int b = __float_as_int(v[i]);
         b = b >= 0 ? b : (b ^ 0x7FFFFFFF);
-        lo = hi = b;
+        lo = b < lo ? b : lo;
+        hi = b > hi ? b : hi;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -603,11 +669,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     const int fx = (int)g->N[0] * smooth + 1, fy = (int)g->N[1] * smooth + 1, fz = (int)g->N[2] * smooth + 1;
     const int64_t nf = (int64_t)fx * fy * fz;
     hipStream_t st = nullptr;
-    DevBuf d_sdf, d_f, d_w, d_lsf, d_fine, d_cx, d_cy, d_cz, d_tx, d_ty, d_tz, d_st, d_cnt, d_r, d_u, d_q, d_part, d_sum;
+    DevBuf d_sdf, d_f, d_w, d_lsf, d_fine, d_cx, d_cy, d_cz, d_tx, d_ty, d_tz, d_st, d_cnt, d_r, d_u, d_q, d_part, d_sum, d_kv;
     VolumeWork vw;
     auto cleanup = [&]() {
         DevBuf* all[] = {&d_sdf, &d_f, &d_w, &d_lsf, &d_fine, &d_cx, &d_cy, &d_cz, &d_tx, &d_ty, &d_tz, &d_st, &d_cnt,
-                         &d_r, &d_u, &d_q, &d_part, &d_sum};
+                         &d_r, &d_u, &d_q, &d_part, &d_sum, &d_kv};
         for (DevBuf* b : all) b->release();
         vw.release();
     };
@@ -635,7 +701,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     // ---- process_vector ----
     HIP_C(hipMemset(d_cnt.p, 0, 64));
     const unsigned nb = (unsigned)((n + 255) / 256);
-    pv_max_kernel<<<nb, 256, 0, st>>>(d_sdf.as<double>(), n, d_f.as<float>(), d_cnt.as<uint32_t>(), d_cnt.as<uint32_t>() + 1);
+    pv_max_kernel<<<(nb < 2048u ? nb : 2048u), 256, 0, st>>>(d_sdf.as<double>(), n, d_f.as<float>(), d_cnt.as<uint32_t>(), d_cnt.as<uint32_t>() + 1);
     uint32_t hc[2];
     HIP_C(hipMemcpy(hc, d_cnt.p, 8, hipMemcpyDeviceToHost));
     if (!hc[1]) { cleanup(); return fail(R2S_ERR_ARG, "every SDF value is a sentinel: nothing to smooth"); }   // A15
@@ -703,6 +769,27 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             *out = (float)h;
             return 0;
         };
+        // materialise K when it fits comfortably (see rbf_kbuild_kernel)
+        RbfTaps taps;
+        taps.n = 0;
+        bool taps_ok = true;
+        for (int dk = -G.tap_r; dk <= G.tap_r && taps_ok; ++dk)
+            for (int dj = -G.tap_r; dj <= G.tap_r && taps_ok; ++dj)
+                for (int di = -G.tap_r; di <= G.tap_r; ++di) {
+                    if (dk * dk + dj * dj + di * di > G.tap_d2) continue;
+                    if (taps.n == RBF_MAX_TAPS) { taps_ok = false; break; }
+                    taps.off[taps.n][0] = (signed char)di; taps.off[taps.n][1] = (signed char)dj; taps.off[taps.n][2] = (signed char)dk;
+                    taps.n++;
+                }
+        bool use_k = false;
+        if (taps_ok) {
+            size_t free_b = 0, total_b = 0;
+            const size_t need = sizeof(float) * (size_t)n * (size_t)taps.n;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 2 && d_kv.ensure(need) == 0) {
+                rbf_kbuild_kernel<<<nb, 256, 0, st>>>(G, taps, d_kv.as<float>());
+                use_k = true;
+            }
+        }
         HIP_C(hipMemcpy(d_r.p, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice));
         HIP_C(hipMemset(d_u.p, 0, sizeof(float) * (size_t)n));
         HIP_C(hipMemset(d_w.p, 0, sizeof(float) * (size_t)n));
@@ -713,7 +800,8 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         while (!(residual <= tol) && its < n) {
             const float beta = (residual * residual) / (prev * prev);
             cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
-            rbf_matvec_kernel<<<nb, 256, 0, st>>>(G, d_u.as<float>(), d_q.as<float>());
+            if (use_k) rbf_matvec_k_kernel<<<nb, 256, 0, st>>>(G, taps, d_kv.as<float>(), d_u.as<float>(), d_q.as<float>());
+            else rbf_matvec_kernel<<<nb, 256, 0, st>>>(G, d_u.as<float>(), d_q.as<float>());
             float uq;
             TRY_C(dot(d_u.as<float>(), d_q.as<float>(), &uq));
             const float alpha = (residual * residual) / uq;
@@ -723,6 +811,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             residual = std::sqrt(rr);
             its++;
         }
+        d_kv.release();
     } else {
         HIP_C(hipMemcpy(d_w.p, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice));   // :353
     }
@@ -733,7 +822,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     if (lsf_out) HIP_C(hipMemcpy(lsf_out, d_lsf.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     int mmh[2] = {0x7FFFFFFF, (int)0x80000000};
     HIP_C(hipMemcpy(d_cnt.p, mmh, 8, hipMemcpyHostToDevice));
-    minmax_kernel<<<nb, 256, 0, st>>>(d_lsf.as<float>(), n, d_cnt.as<int>());
+    minmax_kernel<<<(nb < 2048u ? nb : 2048u), 256, 0, st>>>(d_lsf.as<float>(), n, d_cnt.as<int>());
     HIP_C(hipMemcpy(mmh, d_cnt.p, 8, hipMemcpyDeviceToHost));
     auto dec = [](int b) { b = b >= 0 ? b : (b ^ 0x7FFFFFFF); float f; memcpy(&f, &b, 4); return f; };
     float lo = dec(mmh[0]), hi = dec(mmh[1]);
