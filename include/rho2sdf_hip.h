@@ -198,6 +198,16 @@ int r2s_rbf_smooth(const double *sdf, const r2s_grid *grid, int32_t is_interp, i
                    double kernel_threshold, double target_volume, int32_t device, float *fine_sdf_out,
                    float *level_shift_out, int32_t *cg_iters_out, float *lsf_out);
 
+/* device-resident variant (chaining the stages without PCIe): d_sdf (Float64) and d_fine_out (Float32) are
+ * device pointers on the current device; waits for `stream` first, synchronous on return. */
+int r2s_rbf_smooth_dev(const double *d_sdf, const r2s_grid *grid, int32_t is_interp, int32_t smooth,
+                       double kernel_threshold, double target_volume, float *d_fine_out, float *level_shift_out,
+                       int32_t *cg_iters_out, void *stream);
+
+/* frees the process-wide work buffers the library keeps between calls (the materialised RBF matrix of the CG:
+ * up to a quarter of the device memory, see r2s_post.hip) */
+void r2s_release_cache(void);
+
 #ifdef __cplusplus
 }
 #endif

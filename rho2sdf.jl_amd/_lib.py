@@ -81,6 +81,9 @@ SYMBOLS = [
     ("r2s_rbf_smooth", ctypes.c_int, [c_double_p, ctypes.POINTER(R2SGrid), ctypes.c_int32, ctypes.c_int32,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_int32, c_float_p, c_float_p,
                                       ctypes.POINTER(ctypes.c_int32), c_float_p]),
+    ("r2s_release_cache", None, []),
+    ("r2s_rbf_smooth_dev", ctypes.c_int, [_P, ctypes.POINTER(R2SGrid), ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
+                                          ctypes.c_double, _P, c_float_p, ctypes.POINTER(ctypes.c_int32), _P]),
 ]
 
 OUT_DIST, OUT_SIGN, OUT_SDF, OUT_XP = 1, 2, 4, 8

@@ -358,12 +358,31 @@ def rho2sdf(taskName, X, IEN, rho, *, options=None, sdf_grid=None, device=-1):
     rho_t = options.threshold_density                                                        # :151-156
     if rho_t is None:
         rho_t = find_threshold_for_volume(mesh, rho_n, V_domain * V_frac, device=device)
-    sdf_dists = sdf_fused(mesh, sdf_grid, rho_n, rho_t, device=device)                       # :169-171
-    if options.remove_artifacts:                                                             # :174-208
-        remove_sdf_artifacts(sdf_dists, sdf_grid, threshold=0.0,
-                             min_component_ratio=options.artifact_min_component_ratio, device=device)
     smooth = 1 if options.rbf_grid == "same" else 2                                          # :222
-    fine_sdf = RBFs_smoothing(sdf_dists, sdf_grid, options.rbf_interp, smooth, V_frac * V_domain, device=device)
+    # raw SDF -> artifact removal -> RBF smoothing stay in HBM (torch tensors only own the buffers); the two
+    # returned arrays are downloaded once each
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else int(device))
+    with torch.cuda.device(dev):
+        dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (mesh.X, mesh.IEN, np.ascontiguousarray(rho_n, dtype=np.float64)))
+        d_sdf = torch.empty(sdf_grid.ngp, dtype=torch.float64, device=dev)
+        plan = DevicePlan(dev.index)
+        try:
+            plan.run(dX, dI, dR, rho_t, sdf_grid, sdf=d_sdf, elem_type=mesh.element_type)    # :169-171
+        finally:
+            plan.close()
+        stream = DevicePlan._stream(None)
+        if options.remove_artifacts:                                                         # :174-208
+            n = ctypes.c_int64()
+            L.check(L.lib().r2s_remove_artifacts_dev(ctypes.c_void_p(d_sdf.data_ptr()), ctypes.byref(sdf_grid.c), 0.0,
+                                                     float(options.artifact_min_component_ratio), stream, ctypes.byref(n)))
+        dims = tuple(int(nn) * smooth + 1 for nn in sdf_grid.c.N)
+        d_fine = torch.empty(dims[0] * dims[1] * dims[2], dtype=torch.float32, device=dev)
+        L.check(L.lib().r2s_rbf_smooth_dev(ctypes.c_void_p(d_sdf.data_ptr()), ctypes.byref(sdf_grid.c),
+                                           int(bool(options.rbf_interp)), int(smooth), 1e-3, float(V_frac * V_domain),
+                                           ctypes.c_void_p(d_fine.data_ptr()), None, None, stream))
+        sdf_dists = d_sdf.cpu().numpy()
+        fine_sdf = d_fine.cpu().numpy().reshape(dims[2], dims[1], dims[0])
     xmin, xmax = np.float32(sdf_grid.AABB_min[0]), np.float32(sdf_grid.AABB_max[0])
     spacing = (xmax - xmin) / np.float32(fine_sdf.shape[2] - 1)
     fine_grid = (sdf_grid.AABB_min.astype(np.float32), float(spacing), fine_sdf.shape[::-1])

@@ -45,6 +45,19 @@ struct DevBuf {
         cap = want;
         return 0;
     }
+    int ensure_exact(size_t bytes)   // no growth margin (very large buffers)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        cap = bytes;
+        return 0;
+    }
     void release()
     {
         if (p) (void)hipFree(p);

@@ -488,6 +488,9 @@ __global__ void __launch_bounds__(256) rbf_matvec_kernel(RbfGeom G, const float*
 // affordable), and each matvec becomes a coalesced stream instead of 81 exp() per voxel.  Taps are listed
 // in the loop order of rbf_matvec_kernel and absent entries are stored as 0, so the row sums are formed
 // in the same order from the same values (bit-identical results).
+// The buffer is kept for the life of the process (r2s_release_cache frees it): giving tens of GB back to the
+// driver and asking for them again costs seconds per call (freed VRAM is scrubbed), far more than it saves.
+static DevBuf g_rbf_kv;
 #define RBF_MAX_TAPS 160
 struct RbfTaps {
     int n;
@@ -658,8 +661,10 @@ static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
     c[n - 1] = (float)mx;
 }
 
+// sdf_dev / out_dev: `sdf` / `fine_out` are device pointers (device-resident chaining of the stages)
 static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, int smooth, double kthr,
-                           double target_volume, float* fine_out, float* th_out, int* cg_iters, float* lsf_out)
+                           double target_volume, float* fine_out, float* th_out, int* cg_iters, float* lsf_out,
+                           bool sdf_dev = false, bool out_dev = false)
 {
     if (!sdf || !g || !fine_out) return fail(R2S_ERR_ARG, "null argument");
     if (smooth < 1 || smooth > 4) return fail(R2S_ERR_ARG, "smooth must be 1..4");
@@ -669,11 +674,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     const int fx = (int)g->N[0] * smooth + 1, fy = (int)g->N[1] * smooth + 1, fz = (int)g->N[2] * smooth + 1;
     const int64_t nf = (int64_t)fx * fy * fz;
     hipStream_t st = nullptr;
-    DevBuf d_sdf, d_f, d_w, d_lsf, d_fine, d_cx, d_cy, d_cz, d_tx, d_ty, d_tz, d_st, d_cnt, d_r, d_u, d_q, d_part, d_sum, d_kv;
+    DevBuf d_sdf, d_f, d_w, d_lsf, d_fine, d_cx, d_cy, d_cz, d_tx, d_ty, d_tz, d_st, d_cnt, d_r, d_u, d_q, d_part, d_sum;
     VolumeWork vw;
     auto cleanup = [&]() {
         DevBuf* all[] = {&d_sdf, &d_f, &d_w, &d_lsf, &d_fine, &d_cx, &d_cy, &d_cz, &d_tx, &d_ty, &d_tz, &d_st, &d_cnt,
-                         &d_r, &d_u, &d_q, &d_part, &d_sum, &d_kv};
+                         &d_r, &d_u, &d_q, &d_part, &d_sum};
         for (DevBuf* b : all) b->release();
         vw.release();
     };
@@ -691,17 +696,19 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     do {                                                                              \
         if ((buf).ensure(bytes)) { cleanup(); return fail(R2S_ERR_NOMEM, "hipMalloc of %zu bytes failed", (size_t)(bytes)); } \
     } while (0)
-    ENSURE_C(d_sdf, sizeof(double) * (size_t)n);
+    if (!sdf_dev) ENSURE_C(d_sdf, sizeof(double) * (size_t)n);
     ENSURE_C(d_f, sizeof(float) * (size_t)n);
     ENSURE_C(d_w, sizeof(float) * (size_t)n);
     ENSURE_C(d_lsf, sizeof(float) * (size_t)n);
-    ENSURE_C(d_fine, sizeof(float) * (size_t)nf);
+    if (!out_dev) ENSURE_C(d_fine, sizeof(float) * (size_t)nf);
     ENSURE_C(d_cnt, 64);
-    HIP_C(hipMemcpy(d_sdf.p, sdf, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    if (!sdf_dev) HIP_C(hipMemcpy(d_sdf.p, sdf, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    const double* dsdf = sdf_dev ? sdf : d_sdf.as<double>();
+    float* dfine = out_dev ? fine_out : d_fine.as<float>();
     // ---- process_vector ----
     HIP_C(hipMemset(d_cnt.p, 0, 64));
     const unsigned nb = (unsigned)((n + 255) / 256);
-    pv_max_kernel<<<(nb < 2048u ? nb : 2048u), 256, 0, st>>>(d_sdf.as<double>(), n, d_f.as<float>(), d_cnt.as<uint32_t>(), d_cnt.as<uint32_t>() + 1);
+    pv_max_kernel<<<(nb < 2048u ? nb : 2048u), 256, 0, st>>>(dsdf, n, d_f.as<float>(), d_cnt.as<uint32_t>(), d_cnt.as<uint32_t>() + 1);
     uint32_t hc[2];
     HIP_C(hipMemcpy(hc, d_cnt.p, 8, hipMemcpyDeviceToHost));
     if (!hc[1]) { cleanup(); return fail(R2S_ERR_ARG, "every SDF value is a sentinel: nothing to smooth"); }   // A15
@@ -785,8 +792,9 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         if (taps_ok) {
             size_t free_b = 0, total_b = 0;
             const size_t need = sizeof(float) * (size_t)n * (size_t)taps.n;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 2 && d_kv.ensure(need) == 0) {
-                rbf_kbuild_kernel<<<nb, 256, 0, st>>>(G, taps, d_kv.as<float>());
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= total_b / 4 &&
+                (need <= g_rbf_kv.cap || need <= free_b / 2) && g_rbf_kv.ensure_exact(need) == 0) {
+                rbf_kbuild_kernel<<<nb, 256, 0, st>>>(G, taps, g_rbf_kv.as<float>());
                 use_k = true;
             }
         }
@@ -800,7 +808,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         while (!(residual <= tol) && its < n) {
             const float beta = (residual * residual) / (prev * prev);
             cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
-            if (use_k) rbf_matvec_k_kernel<<<nb, 256, 0, st>>>(G, taps, d_kv.as<float>(), d_u.as<float>(), d_q.as<float>());
+            if (use_k) rbf_matvec_k_kernel<<<nb, 256, 0, st>>>(G, taps, g_rbf_kv.as<float>(), d_u.as<float>(), d_q.as<float>());
             else rbf_matvec_kernel<<<nb, 256, 0, st>>>(G, d_u.as<float>(), d_q.as<float>());
             float uq;
             TRY_C(dot(d_u.as<float>(), d_q.as<float>(), &uq));
@@ -811,7 +819,6 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             residual = std::sqrt(rr);
             its++;
         }
-        d_kv.release();
     } else {
         HIP_C(hipMemcpy(d_w.p, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice));   // :353
     }
@@ -844,9 +851,10 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     // ---- fine grid (:363-366) ----
     const unsigned nbf = (unsigned)((nf + 255) / 256);
     rbf_apply_kernel<<<nbf, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
-                                         d_tz.as<float>(), d_st.as<Stencil>() + 1, th, d_fine.as<float>());
+                                         d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine);
     HIP_C(hipGetLastError());
-    HIP_C(hipMemcpy(fine_out, d_fine.p, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost));
+    if (out_dev) HIP_C(hipDeviceSynchronize());
+    else HIP_C(hipMemcpy(fine_out, d_fine.p, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost));
     cleanup();
     return 0;
 }
@@ -910,6 +918,26 @@ int r2s_rbf_smooth(const double* sdf, const r2s_grid* grid, int32_t is_interp, i
                          &its, lsf_out);
     if (cg_iters_out) *cg_iters_out = its;
     return rc;
+}
+
+/* device-resident variant: d_sdf (Float64, grid points) and d_fine_out (Float32, fine grid points) are device
+ * pointers on the current device; work queued on `stream` is waited for first; synchronous on return */
+int r2s_rbf_smooth_dev(const double* d_sdf, const r2s_grid* grid, int32_t is_interp, int32_t smooth, double kernel_threshold,
+                       double target_volume, float* d_fine_out, float* level_shift_out, int32_t* cg_iters_out, void* stream)
+{
+    if (!d_sdf || !grid || !d_fine_out) return fail(R2S_ERR_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    int its = 0;
+    int rc = rbf_smooth_host(d_sdf, grid, is_interp, smooth, kernel_threshold, target_volume, d_fine_out, level_shift_out,
+                             &its, nullptr, true, true);
+    if (cg_iters_out) *cg_iters_out = its;
+    return rc;
+}
+
+/* frees the process-wide work buffers kept between calls (the materialised RBF matrix) */
+void r2s_release_cache(void)
+{
+    g_rbf_kv.release();
 }
 
 }  // extern "C"

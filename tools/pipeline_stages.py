@@ -33,3 +33,11 @@ fine = timed("RBFs_smoothing(%s, smooth=%d)" % ("interp" if a.interp else "appro
              lambda: pkg.RBFs_smoothing(sdf, grid, a.interp, a.smooth, vd * vf, info=info))
 print(json.dumps({"grid": grid.dims, "elements": int(len(IEN)), "rho_t": rt, "flipped": nf, "th": info["th"],
                   "cg_iterations": info["cg_iterations"], "ms": T}))
+
+# whole rho2sdf() with the stages chained in HBM (api.rho2sdf)
+opts = pkg.Rho2sdfOptions(threshold_density=rt, sdf_grid_setup="automatic", rbf_interp=a.interp,
+                          rbf_grid="same" if a.smooth == 1 else "fine")
+pkg.rho2sdf("bench", X, IEN, rho_e, options=opts, sdf_grid=grid)      # warm-up
+t = time.perf_counter()
+pkg.rho2sdf("bench", X, IEN, rho_e, options=opts, sdf_grid=grid)
+print(json.dumps({"rho2sdf_device_chain_ms": round((time.perf_counter() - t) * 1e3, 1)}))
