@@ -268,3 +268,20 @@ def test_compressed_tile_stitching_equals_full_volume(pkg, oracle):
             assert torch.equal(vol, full), f"{world} ranks, {npts}^3: compressed stitching differs"
             assert n_mask > 0 or npts < 100     # the finer grid has tiles deep inside the solid
     plan.close()
+
+
+@pytest.mark.parametrize("seed,jitter,bf", [(1, 0.30, 1.1), (2, 0.35, 2.5), (3, 0.25, 1.1)])
+def test_distorted_hex_random_density(pkg, oracle, seed, jitter, bf):
+    """stress case for the restated solvers and the exact pruning of the sign pass: strongly distorted HEX8
+    (node jitter up to 35 % of the cell, warped faces) with RANDOM nodal densities - iso-surfaces cut elements
+    at arbitrary angles, many projections end on faces / edges / corners of the reference cube, the
+    active-set walk and the line search take their rare paths.  Distances, signs and the sentinel set must
+    still equal the oracle's bit for bit."""
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, _ = synthetic.hex_mesh(7, jitter=jitter, seed=20240501 + seed)
+    rng = np.random.default_rng(seed)
+    rn = np.clip(rng.normal(0.5, 0.35, len(X)), 0.0, 1.0)
+    nmax = synthetic.grid_n_max_for_points(48)
+    pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
+    _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, bf, f"distorted hex, seed {seed}")
