@@ -170,9 +170,12 @@ def main():
             if k:
                 # the kernel's real limiter (committed SQ counter passes, profiles/r01_valu_counters.json):
                 # FP64 VALU instructions per launch and the fraction of lanes doing useful work in them
+                # issue estimate: a wave64 FP64 instruction occupies a SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
                 valu = {"valu_insts_per_launch": k.get("SQ_INSTS_VALU"),
                         "lane_utilisation": (k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"])
-                                             if k.get("SQ_ACTIVE_INST_VALU") else None)}
+                                             if k.get("SQ_ACTIVE_INST_VALU") else None),
+                        "valu_issue_frac_est": (k["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * main_s)
+                                                if k.get("SQ_INSTS_VALU") and main_s > 0 else None)}
         out = {
             "metric": "Mvoxels/s SDF extract on 512^3 grid over 100k HEX8; max|err| vs ref",
             "value": value, "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -204,6 +204,15 @@ int r2s_rbf_smooth_dev(const double *d_sdf, const r2s_grid *grid, int32_t is_int
                        double kernel_threshold, double target_volume, float *d_fine_out, float *level_shift_out,
                        int32_t *cg_iters_out, void *stream);
 
+/* ---- on-disk output ------------------------------------------------------------------ */
+
+/* exportSdfToVTI(filename, grid, values, value_label, smooth)       src/DataExport/ExportToVTI.jl:22-67
+ * VTK ImageData: dimensions N*smooth+1 (smooth = 0: N+1, i.e. `nothing`), Origin = AABB_min, Spacing =
+ * cell_size(/smooth), one point-data array `value_label` (Float32 or Float64, x fastest).  ".vti" is appended
+ * when missing.  Host pointers; no device needed. */
+int r2s_export_vti(const char *filename, const r2s_grid *grid, const void *values, int32_t is_float32,
+                   int64_t n_values, const char *value_label, int32_t smooth);
+
 /* frees the process-wide work buffers the library keeps between calls (the materialised RBF matrix of the CG:
  * up to a quarter of the device memory, see r2s_post.hip) */
 void r2s_release_cache(void);

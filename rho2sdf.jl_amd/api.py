@@ -314,6 +314,30 @@ def RBFs_smoothing(sdf, grid, Is_interpolation, smooth, target_volume, threshold
     return fine.reshape(dims[2], dims[1], dims[0])
 
 
+def exportSdfToVTI(filename, grid, values, value_label, smooth=None):
+    """exportSdfToVTI(filename, grid, values, value_label, smooth) - VTK ImageData (.vti)
+    src/DataExport/ExportToVTI.jl:22-67: dimensions N(*smooth)+1, origin AABB_min, spacing cell_size(/smooth).
+    `values` is float32 or float64, x fastest (any shape).  Returns the path written."""
+    a = np.ascontiguousarray(values)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    L.check(L.lib().r2s_export_vti(str(filename).encode(), ctypes.byref(grid.c), a.ctypes.data_as(ctypes.c_void_p),
+                                   int(a.dtype == np.float32), int(a.size), str(value_label).encode(),
+                                   0 if smooth is None else int(smooth)))
+    filename = str(filename)
+    return filename if filename.endswith(".vti") else filename + ".vti"
+
+
+def export_sdf_results(fine_sdf, sdf_grid, taskName, smooth, is_interpolation, element_type):
+    """export_sdf_results_with_element_type (src/RhoToSDF.jl:249-283), the .vti part: same file name
+    `<task>_<HEX8|TET4>_B-<round(cell,4)>_smooth-<s>_<Interpolation|Approximation>.vti`, point array "distance".
+    (The two .jld2 dumps are Julia serialisation and stay in the Julia package.)"""
+    name = "Interpolation" if is_interpolation else "Approximation"
+    ename = "HEX8" if element_type == L.HEX8 else "TET4"
+    B = round(float(sdf_grid.cell_size), 4)
+    return exportSdfToVTI(f"{taskName}_{ename}_B-{B}_smooth-{smooth}_{name}.vti", sdf_grid, fine_sdf, "distance", smooth)
+
+
 class Rho2sdfOptions:
     """Rho2sdfOptions (src/RhoToSDF.jl:9-77): same fields, defaults and validation rules; file-export
     switches are accepted and ignored here (file I/O stays in the Julia package)."""
@@ -342,11 +366,12 @@ class Rho2sdfOptions:
         self.element_type = element_type
 
 
-def rho2sdf(taskName, X, IEN, rho, *, options=None, sdf_grid=None, device=-1):
+def rho2sdf(taskName, X, IEN, rho, *, options=None, sdf_grid=None, device=-1, export_results=False):
     """rho2sdf(taskName, X, IEN, rho; options) -> (fine_sdf, fine_grid, sdf_grid, sdf_dists)
-    src/RhoToSDF.jl:116-242, computing stages only (no file export).  `sdf_grid` replaces the
-    interactive prompt of sdf_grid_setup = :manual (Grid_setup.jl:111-154 is out of scope).
-    fine_grid is returned as (origin, spacing, dims) instead of one heap vector per voxel."""
+    src/RhoToSDF.jl:116-242.  `sdf_grid` replaces the interactive prompt of sdf_grid_setup = :manual
+    (Grid_setup.jl:111-154 is out of scope).  fine_grid is returned as (origin, spacing, dims) instead of one
+    heap vector per voxel.  export_results=True writes the final `.vti` like RhoToSDF.jl:230-238 (the .jld2
+    dumps and the optional intermediate exports stay in the Julia package)."""
     options = options or Rho2sdfOptions()
     mesh = Mesh(X, IEN, options.element_type)
     V_domain, V_frac = calculate_mesh_volume(mesh, rho, device=device)                      # :128
@@ -386,4 +411,6 @@ def rho2sdf(taskName, X, IEN, rho, *, options=None, sdf_grid=None, device=-1):
     xmin, xmax = np.float32(sdf_grid.AABB_min[0]), np.float32(sdf_grid.AABB_max[0])
     spacing = (xmax - xmin) / np.float32(fine_sdf.shape[2] - 1)
     fine_grid = (sdf_grid.AABB_min.astype(np.float32), float(spacing), fine_sdf.shape[::-1])
+    if export_results:
+        export_sdf_results(fine_sdf, sdf_grid, taskName, smooth, options.rbf_interp, mesh.element_type)
     return fine_sdf, fine_grid, sdf_grid, sdf_dists
