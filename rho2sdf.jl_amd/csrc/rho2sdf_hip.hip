@@ -680,7 +680,7 @@ __device__ __forceinline__ uint32_t tile_count(const int lo[3], const int hi[3])
 template <bool FILL>
 __global__ void band_bin_kernel(const BandItem* __restrict__ items, uint32_t nitems, GridDev g, SlabInfo s,
                                 uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
-                                uint32_t* __restrict__ entries)
+                                uint32_t* __restrict__ entries, uint8_t* __restrict__ tri)
 {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t it = gid / BIN_LANES, sub = gid % BIN_LANES;
@@ -692,6 +692,7 @@ __global__ void band_bin_kernel(const BandItem* __restrict__ items, uint32_t nit
         const uint32_t t = tile_of(lo, hi, q, s);
         const uint32_t pos = atomicAdd(&cnt[t], 1u);
         if (FILL) entries[off[t] + pos] = it;
+        else if (items[it].kind != 0) tri[t] = 1;   // the tile's gather needs the triangle code
     }
 }
 
@@ -1042,14 +1043,17 @@ __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __res
                                                            uint32_t* __restrict__ active_sign,
                                                            uint32_t* __restrict__ active_any,
                                                            uint32_t* __restrict__ active_sonly,
+                                                           const uint8_t* __restrict__ tri,
+                                                           uint32_t* __restrict__ active_lean,
+                                                           uint32_t* __restrict__ active_tri,
                                                            uint32_t* __restrict__ counters)
 {
     // block-aggregated append: the three lists are collected in LDS (wave-aggregated LDS atomics), then ONE
     // global atomic per block and list reserves the output range (2.1 M tiles used to mean ~100 k same-address
     // atomics = 0.49 ms)
-    __shared__ uint32_t s_cnt[4], s_base[4], s_max[2];
-    __shared__ uint32_t s_list[4][256 * AT_ITEMS];
-    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __shared__ uint32_t s_cnt[6], s_base[6], s_max[2];
+    __shared__ uint32_t s_list[6][256 * AT_ITEMS];
+    if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_max[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -1063,9 +1067,11 @@ __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __res
         const bool f[3] = {bc != 0, sc != 0 && hot[t] != 0, false};
         // [2]: union = what a sparse all-gather has to move; [3]: sign-only tiles (gathered as soon as the
         // inverse maps are there, beside the iso-surface projection)
-        const bool fl[4] = {f[0], f[1], f[0] || f[1], f[1] && !f[0]};
+        // [4] / [5]: band tiles without / with boundary triangles (lean / full gather kernel)
+        const bool ft = f[0] && tri[t] != 0;
+        const bool fl[6] = {f[0], f[1], f[0] || f[1], f[1] && !f[0], f[0] && !ft, ft};
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
+        for (int l = 0; l < 6; ++l) {
             const unsigned long long m = __ballot(fl[l]);
             if (m) {
                 uint32_t base = 0;
@@ -1081,18 +1087,18 @@ __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __res
     if (mxb > 64u) atomicMax(&s_max[0], mxb);
     if (mxs > 64u) atomicMax(&s_max[1], mxs);
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const int idx[4] = {1, 2, 5, 6};
+    if (threadIdx.x < 6) {
+        const int idx[6] = {1, 2, 5, 6, 10, 11};
         const uint32_t n = s_cnt[threadIdx.x];
         s_base[threadIdx.x] = n ? atomicAdd(&counters[idx[threadIdx.x]], n) : 0u;
-    } else if (threadIdx.x < 6) {
-        const uint32_t v = s_max[threadIdx.x - 4];
-        if (v > 64u) atomicMax(&counters[threadIdx.x - 1], v);
+    } else if (threadIdx.x < 8) {
+        const uint32_t v = s_max[threadIdx.x - 6];
+        if (v > 64u) atomicMax(&counters[threadIdx.x - 3], v);
     }
     __syncthreads();
-    uint32_t* const out[4] = {active_band, active_sign, active_any, active_sonly};
+    uint32_t* const out[6] = {active_band, active_sign, active_any, active_sonly, active_lean, active_tri};
 #pragma unroll
-    for (int l = 0; l < 4; ++l)
+    for (int l = 0; l < 6; ++l)
         for (uint32_t j = threadIdx.x; j < s_cnt[l]; j += 256u) out[l][s_base[l] + j] = s_list[l][j];
 }
 
@@ -1180,7 +1186,10 @@ struct MainArgs {
                    // 4: dist pass after the sign pass (keeps the sign already stored)
 };
 
-template <class Rec, bool DO_DIST, bool DO_SIGN>
+// TRI = false: instantiation for tiles whose band lists hold no boundary triangles (tile classification in
+// band_bin / active_tiles): without the triangle code the kernel needs half the registers and twice as many
+// wavefronts hide the dependent-load latency it is bound by
+template <class Rec, bool DO_DIST, bool DO_SIGN, bool TRI = true>
 __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
 {
     const Rec* __restrict__ erec = static_cast<const Rec*>(A.erec);
@@ -1260,11 +1269,9 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                                     st.xp[2] = A.iso_res_xp[3 * slot[u] + 2];
                                 }
                             }
-                        } else {
-#ifndef R2S_NO_TRI
+                        } else if constexpr (TRI) {
                             const BandItem& T = A.items[__builtin_amdgcn_readlane(my_it, (int)(q0 + u))];
                             process_triangle(st, T, erec[T.el], A.rho_t, x);
-#endif
                         }
                     }
                 }
@@ -1461,7 +1468,7 @@ struct r2s_plan {
     int n_cu = 256;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
-    DevBuf active, active_sign, active_any, active_sonly, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
+    DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
     DevBuf sbox, s_nchunks, s_chunk_off, sres;   // item-major inverse maps of the sign pass (HEX8)
     DevBuf nstore, store_off, s_nstore, s_store_off;   // storage (tile) chunk counts / offsets
     // state of the last run, for r2s_plan_pack_tiles_dev
@@ -1616,7 +1623,7 @@ void r2s_plan_destroy(r2s_plan* P)
     (void)hipSetDevice(P->device);
     DevBuf* all[] = {&P->deg, &P->ine_ptr, &P->ine, &P->cursor, &P->erec, &P->cls, &P->fmask, &P->nitems,
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
-                     &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any, &P->active_sonly,
+                     &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any, &P->active_sonly, &P->active_lean, &P->active_tri, &P->tri,
                      &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp,
                      &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres, &P->nstore, &P->store_off, &P->s_nstore, &P->s_store_off,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
@@ -1706,6 +1713,9 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->active_sign, sizeof(uint32_t) * (size_t)ntiles);
     ENSURE(P->active_any, sizeof(uint32_t) * (size_t)ntiles);
     ENSURE(P->active_sonly, sizeof(uint32_t) * (size_t)ntiles);
+    ENSURE(P->active_lean, sizeof(uint32_t) * (size_t)ntiles);
+    ENSURE(P->active_tri, sizeof(uint32_t) * (size_t)ntiles);
+    ENSURE(P->tri, (size_t)ntiles + 1);
     ENSURE(P->hot, (size_t)ntiles + 1);
     ENSURE(P->counters, 64);
     uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] band tiles, [2] sign tiles
@@ -1761,8 +1771,9 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipMemsetAsync(P->band_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
     HIP_TRY(hipMemsetAsync(P->sign_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
     HIP_TRY(hipMemsetAsync(P->hot.p, 0, (size_t)ntiles + 1, st));
+    HIP_TRY(hipMemsetAsync(P->tri.p, 0, (size_t)ntiles + 1, st));
     if (n_items)
-        band_bin_kernel<false><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr);
+        band_bin_kernel<false><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr, P->tri.as<uint8_t>());
     if (want_sign)
     {
         sign_hot_kernel<typename ET::Rec><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
@@ -1795,10 +1806,11 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             HIP_TRY(hipMemcpyAsync(&P->h_pinned[13], P->s_store_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
         }
     }
-    active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), P->active_sonly.as<uint32_t>(), counters);
+    active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), P->active_sonly.as<uint32_t>(), P->tri.as<uint8_t>(), P->active_lean.as<uint32_t>(), P->active_tri.as<uint32_t>(), counters);
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[2], P->band_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[3], P->sign_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&P->h_pinned[14], counters + 10, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4],
                    n_active_sign = P->h_pinned[5];
@@ -1817,7 +1829,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipMemsetAsync(P->band_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
     HIP_TRY(hipMemsetAsync(P->sign_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
     if (n_items)
-        band_bin_kernel<true><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>());
+        band_bin_kernel<true><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), nullptr);
     if (want_sign)
         sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->hot.as<uint8_t>());
     // lists longer than 64 entries only occur when the grid is coarse relative to the mesh (few tiles)
@@ -1911,8 +1923,16 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[4], 0));   // (the sweep precedes it on that stream)
             // ordered per-voxel gather: band items (distance) and candidate elements (sign) of every tile
             if (want_dist && want_sign && early_sign_tiles) {
-                A.active = P->active.as<uint32_t>(); A.n_active = n_active;    // band tiles; the others are done
-                if (n_active) sdf_tiles_kernel<ElemRec, true, true><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+                // band tiles (the others are done): lean kernel where the lists hold no boundary triangles
+                const uint32_t n_lean = P->h_pinned[14], n_tri = P->h_pinned[15];
+                if (n_lean) {
+                    A.active = P->active_lean.as<uint32_t>(); A.n_active = n_lean;
+                    sdf_tiles_kernel<ElemRec, true, true, false><<<(n_lean + 3) / 4, 256, 0, st>>>(A);
+                }
+                if (n_tri) {
+                    A.active = P->active_tri.as<uint32_t>(); A.n_active = n_tri;
+                    sdf_tiles_kernel<ElemRec, true, true, true><<<(n_tri + 3) / 4, 256, 0, st>>>(A);
+                }
             } else if (want_dist && want_sign) {
                 const uint32_t n_any = P->h_pinned[8];
                 A.active = P->active_any.as<uint32_t>(); A.n_active = n_any;
