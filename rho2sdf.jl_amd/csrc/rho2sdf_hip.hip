@@ -1858,7 +1858,9 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     // alternatives (north-star workload, ms/step): sweep at the start of the call beside prep + binning 5.9
     // (its waves delay the short kernels, even with a quarter-size grid); sign_project before the sweep 6.5
     // and sign_project starting together with the projection kernel 6.7 (the projection kernel is the long
-    // pole and should get its persistent waves placed first); this order 5.55.
+    // pole and should get its persistent waves placed first); sweep + sign_project already after the second
+    // read-back, beside the list fill / sort kernels 6.4 (those short kernels then wait for wave slots and the
+    // projection kernel starts 1.2 ms later); this order 5.3.
     {
         const bool two_streams = overlap || fork;
         hipStream_t fs = two_streams ? P->st2 : st;
