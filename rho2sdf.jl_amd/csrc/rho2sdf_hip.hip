@@ -235,7 +235,7 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
                                  const double* __restrict__ rho_n, int64_t nel, double rho_t,
                                  const uint32_t* __restrict__ ine_ptr, const uint32_t* __restrict__ ine,
                                  GridDev g, typename ET::Rec* __restrict__ erec, uint8_t* __restrict__ cls,
-                                 uint8_t* __restrict__ fmask, uint32_t* __restrict__ nitems)
+                                 uint32_t* __restrict__ fmask, uint32_t* __restrict__ nitems)
 {
     int64_t el = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nel) return;
@@ -269,30 +269,41 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
     int c = CLS_SKIP;
     if (rmin >= rho_t) c = CLS_SOLID;
     else if (rmax > rho_t) c = CLS_ISO;
-    uint32_t fm = 0, cnt = 0;
-    if (c != CLS_SKIP) {
-        for (int sg = 0; sg < ET::NES; ++sg) {
-            const int64_t n0 = nd[ET::face(sg, 0)];
-            int common = 0;
-            for (uint32_t p = ine_ptr[n0]; p < ine_ptr[n0 + 1]; ++p) {
-                const uint32_t e = ine[p];
-                bool all = true;
-                for (int a = 1; a < ET::NSN && all; ++a) {
-                    const int64_t na = nd[ET::face(sg, a)];
-                    bool found = false;
-                    for (uint32_t q = ine_ptr[na]; q < ine_ptr[na + 1]; ++q)
-                        if (ine[q] == e) { found = true; break; }
-                    all = found;
-                }
-                common += all ? 1 : 0;
-            }
-            if (common == 1) { fm |= (1u << sg); cnt += ET::NSN; }
-        }
-        if (c == CLS_ISO) cnt += 1;
-    }
     cls[el] = (uint8_t)c;
-    fmask[el] = (uint8_t)fm;
-    nitems[el] = cnt;
+    fmask[el] = 0u;
+    nitems[el] = (c == CLS_ISO) ? 1u : 0u;   // + the boundary-face triangles, added by face_mask_kernel
+}
+
+// boundary faces (sdfOnDensityField.jl:511-519): a face is on the boundary when exactly one element (this one)
+// holds all its nodes.  One thread per (element, face) - the search is a chain of dependent look-ups in the
+// node -> element lists, so it wants many threads, and elements that are neither solid nor iso leave at once.
+template <class ET>
+__global__ void face_mask_kernel(const int64_t* __restrict__ IEN, int64_t nel, const uint32_t* __restrict__ ine_ptr,
+                                 const uint32_t* __restrict__ ine, const uint8_t* __restrict__ cls,
+                                 uint32_t* __restrict__ fmask, uint32_t* __restrict__ nitems)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t el = gid / ET::NES;
+    const int sg = (int)(gid % ET::NES);
+    if (el >= nel || cls[el] == CLS_SKIP) return;
+    const int64_t n0 = IEN[el * ET::NEN + ET::face(sg, 0)] - 1;
+    int common = 0;
+    for (uint32_t p = ine_ptr[n0]; p < ine_ptr[n0 + 1]; ++p) {
+        const uint32_t e = ine[p];
+        bool all = true;
+        for (int a = 1; a < ET::NSN && all; ++a) {
+            const int64_t na = IEN[el * ET::NEN + ET::face(sg, a)] - 1;
+            bool found = false;
+            for (uint32_t q = ine_ptr[na]; q < ine_ptr[na + 1]; ++q)
+                if (ine[q] == e) { found = true; break; }
+            all = found;
+        }
+        common += all ? 1 : 0;
+    }
+    if (common == 1) {
+        atomicOr(&fmask[el], 1u << sg);
+        atomicAdd(&nitems[el], (uint32_t)ET::NSN);
+    }
 }
 
 // mini-AABB cell range of a coordinate interval (Grid.jl:130-145)
@@ -343,7 +354,7 @@ __device__ __forceinline__ uint32_t tile_chunk(uint32_t store_off, const TileBox
 
 template <class ET>
 __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, const uint8_t* __restrict__ cls,
-                                  const uint8_t* __restrict__ fmask, const uint32_t* __restrict__ item_off,
+                                  const uint32_t* __restrict__ fmask, const uint32_t* __restrict__ item_off,
                                   int64_t nel, GridDev g, SlabInfo sl, double delta,
                                   BandItem* __restrict__ items, uint32_t* __restrict__ nchunks,
                                   uint32_t* __restrict__ nstore)
@@ -1702,7 +1713,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->ine, sizeof(uint32_t) * (size_t)(nel * ET::NEN));
     ENSURE(P->erec, sizeof(typename ET::Rec) * (size_t)nel);
     ENSURE(P->cls, (size_t)nel);
-    ENSURE(P->fmask, (size_t)nel);
+    ENSURE(P->fmask, sizeof(uint32_t) * (size_t)nel);
     ENSURE(P->nitems, sizeof(uint32_t) * (size_t)(nel + 1));
     ENSURE(P->item_off, sizeof(uint32_t) * (size_t)(nel + 1));
     ENSURE(P->band_cnt, sizeof(uint32_t) * (size_t)(ntiles + 1));
@@ -1736,7 +1747,10 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipMemsetAsync(P->nitems.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
     elem_prep_kernel<ET><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
         dX, dIEN, d_rho_n, nel, rho_t, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), g, P->erec.as<typename ET::Rec>(),
-        P->cls.as<uint8_t>(), P->fmask.as<uint8_t>(), P->nitems.as<uint32_t>());
+        P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->nitems.as<uint32_t>());
+    face_mask_kernel<ET><<<(unsigned)((nel * ET::NES + 255) / 256), 256, 0, st>>>(
+        dIEN, nel, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(),
+        P->nitems.as<uint32_t>());
     {
         int rc = scan_exclusive(P, P->nitems.as<uint32_t>(), P->item_off.as<uint32_t>(), nel + 1, st);
         if (rc) return rc;
@@ -1755,7 +1769,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         HIP_TRY(hipMemsetAsync(P->nchunks.p, 0, sizeof(uint32_t) * (size_t)(n_items + 1), st));
         HIP_TRY(hipMemsetAsync(P->nstore.p, 0, sizeof(uint32_t) * (size_t)(n_items + 1), st));
         item_build_kernel<ET><<<(unsigned)((nel + 63) / 64), 64, 0, st>>>(
-            P->erec.as<typename ET::Rec>(), P->cls.as<uint8_t>(), P->fmask.as<uint8_t>(), P->item_off.as<uint32_t>(), nel,
+            P->erec.as<typename ET::Rec>(), P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->item_off.as<uint32_t>(), nel,
             g, s, delta, P->items.as<BandItem>(), P->nchunks.as<uint32_t>(), P->nstore.as<uint32_t>());
         int rc = scan_exclusive(P, P->nchunks.as<uint32_t>(), P->chunk_off.as<uint32_t>(), (int64_t)n_items + 1, st);
         if (rc) return rc;
