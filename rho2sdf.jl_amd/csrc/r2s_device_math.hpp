@@ -108,22 +108,6 @@ R2S_DEV void hex8_shape_d(const double xi[3], double N[8], double dN[8][3])
     dN[4][2] = c * t1;     dN[5][2] = -c * t2;    dN[6][2] = c * t3;     dN[7][2] = -c * t4;
 }
 
-// mixed second derivatives d2N/dxi1dxi2, d2N/dxi1dxi3, d2N/dxi2dxi3
-R2S_DEV void hex8_shape_mixed(const double xi[3], double m[8][3])
-{
-    const double x1m = xi[0] - 1, x1p = xi[0] + 1, x2m = xi[1] - 1, x2p = xi[1] + 1;
-    const double x3m = xi[2] - 1, x3p = xi[2] + 1;
-    const double c = 0.125;
-    m[0][0] = -c * x3m; m[0][1] = -c * x2m; m[0][2] = -c * x1m;
-    m[1][0] = c * x3m;  m[1][1] = c * x2m;  m[1][2] = c * x1p;
-    m[2][0] = -c * x3m; m[2][1] = -c * x2p; m[2][2] = -c * x1p;
-    m[3][0] = c * x3m;  m[3][1] = c * x2p;  m[3][2] = c * x1m;
-    m[4][0] = c * x3p;  m[4][1] = c * x2m;  m[4][2] = c * x1m;
-    m[5][0] = -c * x3p; m[5][1] = -c * x2m; m[5][2] = -c * x1p;
-    m[6][0] = c * x3p;  m[6][1] = c * x2p;  m[6][2] = c * x1p;
-    m[7][0] = -c * x3p; m[7][1] = -c * x2p; m[7][2] = -c * x1m;
-}
-
 R2S_DEV double norm3(double a, double b, double c) { return sqrt(a * a + b * b + c * c); }
 
 // grid point (Grid.jl:87) and its cell index (Grid.jl:58)

@@ -1,15 +1,18 @@
 // MI355X (gfx950) signed-distance extraction engine: kernels + C ABI.
 //
-// Pipeline of one r2s_plan_run_dev() call (all on one HIP stream):
-//   node_degree / ine_fill      node -> element CSR            (MeshInformations.jl:69-77)
-//   elem_prep                   gather element records, classify solid/iso, boundary faces
-//   item_build                  band work items (boundary triangles + iso projections)
-//   bin_count / scan / bin_fill / bin_sort
-//                               4x4x4-voxel tile -> item list and tile -> element list
-//   fill                        sentinel sweep (HBM-bound)
-//   sdf_tiles                   one wavefront per active tile: ordered gather over the
-//                               tile's lists, FP64 VALU (projection + inverse map)
-// See DESIGN.md for the data layout and the roofline of each kernel.
+// Pipeline of one r2s_plan_run_dev() call (stream 1 = the caller's stream, stream 2 = the plan's own):
+//   node_degree / ine_fill        node -> element CSR                       (MeshInformations.jl:69-77)
+//   elem_prep / face_mask         element records (+ solver constants), solid/iso class, boundary faces
+//   item_build                    band work items (boundary triangles + iso projections) and their boxes
+//   band_bin / sign_hot / sign_bin / sign_box / scan / active_tiles / bin_sort
+//                                 4x4x4-voxel tile -> item list and (hot tiles) -> candidate element list,
+//                                 boxes of the candidate elements, compact lists of the tiles to gather
+//   fill                          sentinel sweep (HBM-bound)                                  [stream 2]
+//   sign_project                  item-major Newton inverse maps of the sign pass (HEX8)      [stream 2]
+//   iso_project_hex_pl            persistent lane-refill SQP projection onto the iso-surface  [stream 1]
+//   sdf_tiles                     one wavefront per active tile: ordered gather over the tile's lists
+//                                 (look-ups of the item-major results, triangles inline), writes dist*sign
+// See DESIGN.md for the data layout, the flow and the measured numbers of each kernel.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -36,7 +39,7 @@ __constant__ int c_hex_isn[6][4] = {{0, 3, 2, 1}, {0, 1, 5, 4}, {1, 2, 6, 5},
                                     {2, 3, 7, 6}, {3, 0, 4, 7}, {4, 5, 6, 7}};
 
 // ------------------------------------------------------------------------------------
-// exclusive scan of uint32 (block = 256 threads x 4 items)
+// exclusive scan of uint32 (block = 1024 threads x 4 items)
 // ------------------------------------------------------------------------------------
 #define SCAN_BLOCK 1024
 #define SCAN_ITEMS 4
@@ -160,8 +163,6 @@ __host__ __device__ __forceinline__ bool slab_local_range(const SlabInfo& s, int
     lb = 4 * tb + ((tb * s.G + s.r == layer_b) ? (b & 3) : 3);
     return la <= lb;
 }
-
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // n x n LU with partial pivoting, same operation order as the oracle's lu_solve (stands in for
 // LAPACK getrf behind Julia's `\`); piv[c] = row swapped with row c.  Prep kernels only.
