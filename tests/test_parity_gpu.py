@@ -285,3 +285,18 @@ def test_distorted_hex_random_density(pkg, oracle, seed, jitter, bf):
     pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
     og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
     _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, bf, f"distorted hex, seed {seed}")
+
+
+@pytest.mark.parametrize("fillv", [0.0, 1.0])
+def test_uniform_density(pkg, oracle, fillv):
+    """degenerate work lists: an all-void mesh (no items, no hot tiles: the output is the sentinel everywhere) and an
+    all-solid one (boundary triangles only, no iso items; every tile of the mesh is hot)"""
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, _ = synthetic.hex_mesh(5, jitter=0.1)
+    rn = np.full(len(X), fillv)
+    nmax = synthetic.grid_n_max_for_points(36)
+    pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
+    _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, 1.1, f"uniform density {fillv}")
+    if fillv == 0.0:
+        assert np.all(pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5) == -1.0e10)
