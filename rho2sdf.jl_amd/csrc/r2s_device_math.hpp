@@ -822,6 +822,15 @@ struct alignas(16) TetRec {
     int32_t sing3, sing4;
     int32_t blo[3], bhi[3];  // 1-based bin range of create_grid_tetrahedra_mapping_TET4 (:191-192)
     int32_t pad;
+    // per-element constants of the iso-surface projection (tet4_iso_constants): inverse of the edge matrix,
+    // density gradient and its square, and per face the segment {rho = rho_t} n face (start, direction, length^2)
+    double Ai[3][3];
+    double gr[3];
+    double g2;
+    double sa[4][3];
+    double sab[4][3];
+    double sab2[4];
+    int32_t segok[4];
 };
 
 __device__ const int c_tet_isn[4][3] = {{0, 2, 1}, {0, 1, 3}, {1, 2, 3}, {0, 3, 2}};
@@ -876,10 +885,11 @@ R2S_DEV bool projected_on_full_segment(VoxState& s, const TetRec& E, double rt, 
 
 // compute_coords_on_iso, TET4 (ComputeCoordsOnIso.jl:90-181): closest point of the planar polygon
 // {p in tet : rho(p) = rho_t}, closed form (see the oracle / DESIGN.md); natural coordinates out.
-R2S_DEV void iso_project_tet4(const TetRec& E, const double x[3], double rt, double lam[3])
+// Everything that does not depend on the voxel is evaluated once per element (tet4_iso_constants) with the
+// same expressions, in the same order, as the oracle evaluates them per voxel.
+R2S_DEV void tet4_iso_constants(TetRec& E, double rt)
 {
-    double A[3][3], Ai[3][3];
-#pragma unroll
+    double A[3][3];
     for (int i = 0; i < 3; ++i) {
         A[i][0] = E.X[1][i] - E.X[0][i];
         A[i][1] = E.X[2][i] - E.X[0][i];
@@ -888,28 +898,69 @@ R2S_DEV void iso_project_tet4(const TetRec& E, const double x[3], double rt, dou
     const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
     const double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
     const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
-    Ai[0][0] = c00 / det; Ai[1][0] = c01 / det; Ai[2][0] = c02 / det;
-    Ai[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
-    Ai[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
-    Ai[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
-    Ai[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
-    Ai[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
-    Ai[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+    E.Ai[0][0] = c00 / det; E.Ai[1][0] = c01 / det; E.Ai[2][0] = c02 / det;
+    E.Ai[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+    E.Ai[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
+    E.Ai[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+    E.Ai[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
+    E.Ai[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+    E.Ai[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
     const double dr[3] = {E.r[1] - E.r[0], E.r[2] - E.r[0], E.r[3] - E.r[0]};
-    double gr[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) gr[i] = Ai[0][i] * dr[0] + Ai[1][i] * dr[1] + Ai[2][i] * dr[2];
-    const double g2 = gr[0] * gr[0] + gr[1] * gr[1] + gr[2] * gr[2];
+    for (int i = 0; i < 3; ++i) E.gr[i] = E.Ai[0][i] * dr[0] + E.Ai[1][i] * dr[1] + E.Ai[2][i] * dr[2];
+    E.g2 = E.gr[0] * E.gr[0] + E.gr[1] * E.gr[1] + E.gr[2] * E.gr[2];
+    for (int f = 0; f < 4; ++f) {
+        double P[3][3];
+        int np = 0;
+        for (int e = 0; e < 3; ++e) {
+            const int a = c_tet_isn[f][e], b = c_tet_isn[f][(e + 1) % 3];
+            const double ra = E.r[a] - rt, rb = E.r[b] - rt;
+            if (ra * rb <= 0.0 && E.r[a] != E.r[b]) {
+                const double t = (rt - E.r[a]) / (E.r[b] - E.r[a]);
+                P[np][0] = E.X[a][0] + t * (E.X[b][0] - E.X[a][0]);
+                P[np][1] = E.X[a][1] + t * (E.X[b][1] - E.X[a][1]);
+                P[np][2] = E.X[a][2] + t * (E.X[b][2] - E.X[a][2]);
+                np++;
+            }
+        }
+        E.segok[f] = np >= 2;
+        double a3[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
+        if (np >= 2) {
+            for (int i = 0; i < 3; ++i) { a3[i] = P[0][i]; b3[i] = P[1][i]; }
+            if (np == 3) {
+                double d01 = 0, d02 = 0, d12 = 0;
+                for (int i = 0; i < 3; ++i) {
+                    d01 += (P[0][i] - P[1][i]) * (P[0][i] - P[1][i]);
+                    d02 += (P[0][i] - P[2][i]) * (P[0][i] - P[2][i]);
+                    d12 += (P[1][i] - P[2][i]) * (P[1][i] - P[2][i]);
+                }
+                if (d02 >= d01 && d02 >= d12) { for (int i = 0; i < 3; ++i) b3[i] = P[2][i]; }
+                else if (d12 >= d01 && d12 >= d02) {
+                    for (int i = 0; i < 3; ++i) { a3[i] = P[1][i]; b3[i] = P[2][i]; }
+                }
+            }
+        }
+        double ab2 = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            E.sa[f][i] = a3[i];
+            E.sab[f][i] = b3[i] - a3[i];
+            ab2 += E.sab[f][i] * E.sab[f][i];
+        }
+        E.sab2[f] = ab2;
+    }
+}
+
+R2S_DEV void iso_project_tet4(const TetRec& E, const double x[3], double rt, double lam[3])
+{
     const double d0[3] = {x[0] - E.X[0][0], x[1] - E.X[0][1], x[2] - E.X[0][2]};
-    const double rho_x = E.r[0] + (gr[0] * d0[0] + gr[1] * d0[1] + gr[2] * d0[2]);
-    const double tq = (rho_x - rt) / g2;
+    const double rho_x = E.r[0] + (E.gr[0] * d0[0] + E.gr[1] * d0[1] + E.gr[2] * d0[2]);
+    const double tq = (rho_x - rt) / E.g2;
     double best[3] = {0, 0, 0}, bestd = INFINITY;
     {
-        const double q[3] = {x[0] - tq * gr[0], x[1] - tq * gr[1], x[2] - tq * gr[2]};
+        const double q[3] = {x[0] - tq * E.gr[0], x[1] - tq * E.gr[1], x[2] - tq * E.gr[2]};
         const double dq[3] = {q[0] - E.X[0][0], q[1] - E.X[0][1], q[2] - E.X[0][2]};
         double l[4];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) l[i + 1] = Ai[i][0] * dq[0] + Ai[i][1] * dq[1] + Ai[i][2] * dq[2];
+        for (int i = 0; i < 3; ++i) l[i + 1] = E.Ai[i][0] * dq[0] + E.Ai[i][1] * dq[1] + E.Ai[i][2] * dq[2];
         l[0] = 1.0 - ((l[1] + l[2]) + l[3]);
         if (l[0] >= 0.0 && l[1] >= 0.0 && l[2] >= 0.0 && l[3] >= 0.0) {
             best[0] = q[0]; best[1] = q[1]; best[2] = q[2];
@@ -919,53 +970,19 @@ R2S_DEV void iso_project_tet4(const TetRec& E, const double x[3], double rt, dou
     if (bestd != 0.0) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            double P[3][3];
-            int np = 0;
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const int a = c_tet_isn[f][e], b = c_tet_isn[f][(e + 1) % 3];
-                const double ra = E.r[a] - rt, rb = E.r[b] - rt;
-                if (ra * rb <= 0.0 && E.r[a] != E.r[b]) {
-                    const double t = (rt - E.r[a]) / (E.r[b] - E.r[a]);
-                    const double px = E.X[a][0] + t * (E.X[b][0] - E.X[a][0]);
-                    const double py = E.X[a][1] + t * (E.X[b][1] - E.X[a][1]);
-                    const double pz = E.X[a][2] + t * (E.X[b][2] - E.X[a][2]);
-                    if (np == 0) { P[0][0] = px; P[0][1] = py; P[0][2] = pz; }
-                    else if (np == 1) { P[1][0] = px; P[1][1] = py; P[1][2] = pz; }
-                    else { P[2][0] = px; P[2][1] = py; P[2][2] = pz; }
-                    np++;
-                }
-            }
-            if (np >= 2) {
-                double a3[3] = {P[0][0], P[0][1], P[0][2]}, b3[3] = {P[1][0], P[1][1], P[1][2]};
-                if (np == 3) {
-                    double d01 = 0, d02 = 0, d12 = 0;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        d01 += (P[0][i] - P[1][i]) * (P[0][i] - P[1][i]);
-                        d02 += (P[0][i] - P[2][i]) * (P[0][i] - P[2][i]);
-                        d12 += (P[1][i] - P[2][i]) * (P[1][i] - P[2][i]);
-                    }
-                    if (d02 >= d01 && d02 >= d12) { b3[0] = P[2][0]; b3[1] = P[2][1]; b3[2] = P[2][2]; }
-                    else if (d12 >= d01 && d12 >= d02) {
-                        a3[0] = P[1][0]; a3[1] = P[1][1]; a3[2] = P[1][2];
-                        b3[0] = P[2][0]; b3[1] = P[2][1]; b3[2] = P[2][2];
-                    }
-                }
-                double ab[3], ab2 = 0.0, dot = 0.0;
+            if (E.segok[f]) {
+                double dot = 0.0;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    ab[i] = b3[i] - a3[i];
-                    const double ax = x[i] - a3[i];
-                    ab2 += ab[i] * ab[i];
-                    dot += ax * ab[i];
+                    const double ax = x[i] - E.sa[f][i];
+                    dot += ax * E.sab[f][i];
                 }
-                double s = ab2 > 0.0 ? dot / ab2 : 0.0;
+                double s = E.sab2[f] > 0.0 ? dot / E.sab2[f] : 0.0;
                 s = fmin(fmax(s, 0.0), 1.0);
                 double p[3], dd = 0.0;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    p[i] = a3[i] + s * ab[i];
+                    p[i] = E.sa[f][i] + s * E.sab[f][i];
                     dd += (x[i] - p[i]) * (x[i] - p[i]);
                 }
                 if (dd < bestd) { bestd = dd; best[0] = p[0]; best[1] = p[1]; best[2] = p[2]; }
@@ -976,7 +993,7 @@ R2S_DEV void iso_project_tet4(const TetRec& E, const double x[3], double rt, dou
     const double db[3] = {best[0] - E.X[0][0], best[1] - E.X[0][1], best[2] - E.X[0][2]};
     double l234[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) l234[i] = Ai[i][0] * db[0] + Ai[i][1] * db[1] + Ai[i][2] * db[2];
+    for (int i = 0; i < 3; ++i) l234[i] = E.Ai[i][0] * db[0] + E.Ai[i][1] * db[1] + E.Ai[i][2] * db[2];
     lam[0] = 1.0 - ((l234[0] + l234[1]) + l234[2]);
     lam[1] = l234[0];
     lam[2] = l234[1];

@@ -193,13 +193,13 @@ struct HexT {
     using Rec = ElemRec;
     static constexpr int NEN = 8, NES = 6, NSN = 4;
     static __device__ __forceinline__ int face(int sg, int a) { return c_hex_isn[sg][a]; }
-    static __device__ void finish(Rec& R, const GridDev&) { hex8_monomials(R); hex8_planes(R); hex8_newton0(R); }
+    static __device__ void finish(Rec& R, const GridDev&, double) { hex8_monomials(R); hex8_planes(R); hex8_newton0(R); }
 };
 struct TetT {
     using Rec = TetRec;
     static constexpr int NEN = 4, NES = 4, NSN = 3;
     static __device__ __forceinline__ int face(int sg, int a) { return c_tet_isn[sg][a]; }
-    static __device__ void finish(Rec& R, const GridDev& g)
+    static __device__ void finish(Rec& R, const GridDev& g, double rho_t)
     {
         double A[3][3], T[4][4];
         for (int i = 0; i < 3; ++i) {   // FindLocalCoordinates.jl:124: hcat(x2-x1, x3-x1, x4-x1)
@@ -226,6 +226,7 @@ struct TetT {
             R.bhi[ax] = (int32_t)fmax(b, -2.0e9);
         }
         R.pad = 0;
+        tet4_iso_constants(R, rho_t);
     }
 };
 
@@ -265,7 +266,7 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
     }
     R.rmax = rmax;
     R.rmin = rmin;
-    ET::finish(R, g);
+    ET::finish(R, g, rho_t);
     erec[el] = R;
     int c = CLS_SKIP;
     if (rmin >= rho_t) c = CLS_SOLID;
