@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "r2s_common.hpp"
@@ -491,6 +492,7 @@ __global__ void __launch_bounds__(256) rbf_matvec_kernel(RbfGeom G, const float*
 // The buffer is kept for the life of the process (r2s_release_cache frees it): giving tens of GB back to the
 // driver and asking for them again costs seconds per call (freed VRAM is scrubbed), far more than it saves.
 static DevBuf g_rbf_kv;
+static std::mutex g_rbf_kv_mutex;   // one smoothing call at a time may use (or regrow) the shared buffer
 #define RBF_MAX_TAPS 160
 struct RbfTaps {
     int n;
@@ -789,7 +791,8 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
                     taps.n++;
                 }
         bool use_k = false;
-        if (taps_ok) {
+        std::unique_lock<std::mutex> kv_lock(g_rbf_kv_mutex, std::try_to_lock);   // busy: fall back to on-the-fly
+        if (taps_ok && kv_lock.owns_lock()) {
             size_t free_b = 0, total_b = 0;
             const size_t need = sizeof(float) * (size_t)n * (size_t)taps.n;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= total_b / 4 &&
@@ -937,6 +940,7 @@ int r2s_rbf_smooth_dev(const double* d_sdf, const r2s_grid* grid, int32_t is_int
 /* frees the process-wide work buffers kept between calls (the materialised RBF matrix) */
 void r2s_release_cache(void)
 {
+    std::lock_guard<std::mutex> lock(g_rbf_kv_mutex);
     g_rbf_kv.release();
 }
 
