@@ -1923,7 +1923,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 // beside the iso-surface projection
                 MainArgs B = A;
                 B.active = P->active_sonly.as<uint32_t>(); B.n_active = n_sonly;
-                sdf_tiles_kernel<ElemRec, false, true><<<(n_sonly + 3) / 4, 256, 0, ss>>>(B);
+                sdf_tiles_kernel<ElemRec, false, true><<<n_sonly, 64, 0, ss>>>(B);
             }
             HIP_TRY(hipEventRecord(P->ev2[2], ss));
             A.iso_res = P->iso_res.as<double>();
@@ -1945,7 +1945,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 const uint32_t n_lean = P->h_pinned[14], n_tri = P->h_pinned[15];
                 if (n_lean) {
                     A.active = P->active_lean.as<uint32_t>(); A.n_active = n_lean;
-                    sdf_tiles_kernel<ElemRec, true, true, false><<<(n_lean + 3) / 4, 256, 0, st>>>(A);
+                    sdf_tiles_kernel<ElemRec, true, true, false><<<n_lean, 64, 0, st>>>(A);   // one-wave workgroups: ~10 % faster
                 }
                 if (n_tri) {
                     A.active = P->active_tri.as<uint32_t>(); A.n_active = n_tri;
