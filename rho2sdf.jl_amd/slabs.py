@@ -121,8 +121,11 @@ class SlabGather:
         if nf_mine or nm_mine:
             got = self.ops.pack2(self.my_slab, payload, ids, masks, mids)
             assert tuple(got) == (nf_mine, nm_mine), (got, nf_mine, nm_mine)
+        # the collective runs on the communicator's stream: the sentinel pre-fill of the whole volume
+        # (1 GB of HBM writes at 512^3) overlaps with it instead of preceding it
+        work = dist.all_gather_into_tensor(buf, seg, async_op=True)
         self.ops.fill(self.full, SENTINEL)
-        dist.all_gather_into_tensor(buf, seg)
+        work.wait()
         self.last_bytes = buf.numel() * buf.element_size()
         for r, (cf, cm) in enumerate(allc):
             payload, ids, masks, mids = self._segment_views(buf[r * seglen:(r + 1) * seglen], mf, mm)
