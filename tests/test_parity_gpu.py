@@ -300,3 +300,37 @@ def test_uniform_density(pkg, oracle, fillv):
     _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, 1.1, f"uniform density {fillv}")
     if fillv == 0.0:
         assert np.all(pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5) == -1.0e10)
+
+
+def test_chapadlo_config4_grid(pkg, oracle):
+    """BASELINE config 4 (robot gripper, "256^3"): N_max = 249 gives the reference's 87 x 166 x 257 grid
+    (SURVEY 8(d)); the four contiguous Z-slabs of the 4-GPU partition (257 planes -> 65 per rank) are computed one
+    by one and must equal the oracle's full volume bit for bit"""
+    import torch
+    X, IEN, rho = load_fixture("chapadlo")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    pg = pkg.Grid(X.min(0), X.max(0), 249, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), 249, 3)
+    assert pg.dims == (87, 166, 257)
+    d, _, _ = oracle.eval_distances(X, IEN, rn, 0.5, og, 1.1, want_xp=False)
+    ref = d * oracle.sign_detection(X, IEN, rn, 0.5, og)
+    from rho2sdf_jl_amd import slabs
+    dev = torch.device("cuda:0")
+    dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rn))
+    plan = pkg.DevicePlan(0)
+    nx, ny, nz = pg.dims
+    per, bounds = slabs.slab_bounds(nz, 4)
+    assert per == 65
+    pieces = []
+    for k0, k1 in bounds:
+        out = torch.empty((k1 - k0) * ny * nx, dtype=torch.float64, device=dev)
+        plan.run(dX, dI, dR, 0.5, pg, k_begin=k0, k_end=k1, sdf=out)
+        pieces.append(out)
+    got = torch.cat(pieces).cpu().numpy()
+    plan.close()
+    assert np.array_equal(np.abs(got) > 1e9, np.abs(ref) > 1e9)
+    assert np.array_equal(np.sign(got), np.sign(ref))
+    real = np.abs(ref) < 1e9
+    rel = np.abs(got[real] - ref[real]) / np.maximum(np.abs(ref[real]), 1e-300)
+    assert not ((rel > RTOL) & (np.abs(got[real] - ref[real]) > 1e-12 * og.cell)).any()
+    print(f"chapadlo 87x166x257: bit-equal {int((got == ref).sum())}/{got.size}")
