@@ -165,13 +165,14 @@ def test_tet4_solid_boundary(pkg, oracle):
     _compare(pkg, oracle, X, IT, rn, 0.05, pg, og, 1.1, "tet4 solid boundary")
 
 
-@pytest.mark.parametrize("dims_n", [40, 37])
-def test_interleaved_layers_equal_full_volume(pkg, oracle, dims_n):
+@pytest.mark.parametrize("dims_n,tets", [(40, False), (37, False), (37, True)])
+def test_interleaved_layers_equal_full_volume(pkg, oracle, dims_n, tets):
     """the balanced multi-GPU partition (4-plane tile layers dealt round-robin, r2s_params.zstride/zphase):
-    all ranks' parts, gathered and reordered exactly as bench.py does, == one full-volume run"""
+    all ranks' parts, gathered and reordered exactly as bench.py does, == one full-volume run (HEX8 and the
+    TET4 family of BASELINE config 5)"""
     import torch
     from rho2sdf_jl_amd import slabs, synthetic
-    X, IEN, rn = synthetic.hex_mesh(8)
+    X, IEN, rn = synthetic.tet_mesh(6) if tets else synthetic.hex_mesh(8)
     pg = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(dims_n), 3)
     dev = torch.device("cuda:0")
     dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rn))
