@@ -230,12 +230,13 @@ def test_sparse_tile_stitching_equals_full_volume(pkg, oracle):
     plan.close()
 
 
-def test_compressed_tile_stitching_equals_full_volume(pkg, oracle):
+@pytest.mark.parametrize("tets", [False, True])
+def test_compressed_tile_stitching_equals_full_volume(pkg, oracle, tets):
     """compressed stitching (r2s_plan_pack_tiles2_dev / r2s_unpack_masks_dev): band tiles travel as 64 doubles,
     sign-only tiles as one 64-bit mask; scattering every rank's share must reproduce the full-volume run bit for bit"""
     import torch
     from rho2sdf_jl_amd import slabs, synthetic
-    X, IEN, rn = synthetic.hex_mesh(8)
+    X, IEN, rn = synthetic.tet_mesh(8) if tets else synthetic.hex_mesh(8)
     dev = torch.device("cuda:0")
     dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rn))
     plan = pkg.DevicePlan(0)
