@@ -21,6 +21,8 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -45,12 +47,19 @@ __constant__ int c_hex_isn[6][4] = {{0, 3, 2, 1}, {0, 1, 5, 4}, {1, 2, 6, 5},
 #define SCAN_ITEMS 4
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
 
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_block_kernel(const uint32_t* __restrict__ in,
-                                                               uint32_t* __restrict__ out,
-                                                               uint32_t* __restrict__ block_sums,
-                                                               int64_t n)
+// up to two arrays of the same length per launch (blockIdx.y picks the array): the pipeline's count arrays
+// come in pairs (band / sign lists, work / storage chunks) and every launch saved is ~5 us of a 0.5 ms prologue
+struct ScanPair {
+    const uint32_t* in[2];
+    uint32_t* out[2];
+    uint32_t* sums[2];   // per-block totals (nullptr: not wanted)
+};
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_block_kernel(ScanPair sp, int64_t n)
 {
     __shared__ uint32_t wave_sums[SCAN_BLOCK / 64];
+    const uint32_t* __restrict__ in = sp.in[blockIdx.y];
+    uint32_t* __restrict__ out = sp.out[blockIdx.y];
+    uint32_t* __restrict__ block_sums = sp.sums[blockIdx.y];
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS], sum = 0;
 #pragma unroll
@@ -83,16 +92,44 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_block_kernel(const uint32_t* 
     if (threadIdx.x == 0 && block_sums) block_sums[blockIdx.x] = total;
 }
 
-__global__ void scan_add_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ block_offs,
-                                int64_t n)
+__global__ void scan_add_kernel(ScanPair sp, int64_t n)
 {
+    uint32_t* __restrict__ out = sp.out[blockIdx.y];
     const int64_t i = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x;
-    const uint32_t add = block_offs[blockIdx.x];
+    const uint32_t add = sp.sums[blockIdx.y][blockIdx.x];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         int64_t j = i + (int64_t)k * SCAN_BLOCK;
         if (j < n) out[j] += add;
     }
+}
+
+// zero up to four buffers with one launch (blockIdx.y picks the buffer); sizes are in 32-bit words and may
+// be rounded up - every buffer comes from DevBuf::ensure, which over-allocates by >= 256 bytes
+struct ZeroSet {
+    uint32_t* p[4];
+    int64_t nwords[4];
+};
+__global__ void zero_many_kernel(ZeroSet z)
+{
+    uint32_t* __restrict__ p = z.p[blockIdx.y];
+    const int64_t n = z.nwords[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static void zero_many(hipStream_t st, std::initializer_list<std::pair<void*, size_t>> bufs)
+{
+    ZeroSet z;
+    unsigned nb = 0;
+    int64_t mx = 0;
+    for (const auto& b : bufs) {
+        z.p[nb] = static_cast<uint32_t*>(b.first);
+        z.nwords[nb] = (int64_t)((b.second + 3) / 4);
+        mx = std::max(mx, z.nwords[nb]);
+        nb++;
+    }
+    for (unsigned i = nb; i < 4; ++i) { z.p[i] = nullptr; z.nwords[i] = 0; }
+    const unsigned gx = (unsigned)std::min<int64_t>((mx + 1023) / 1024, 2048);
+    if (nb && gx) zero_many_kernel<<<dim3(gx, nb), 256, 0, st>>>(z);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1496,22 +1533,34 @@ struct r2s_plan {
     hipEvent_t ev2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
-static int scan_exclusive(r2s_plan* P, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st, int level = 0)
+// exclusive scans of one or two (in1 != nullptr) arrays of n entries each
+static int scan_exclusive2(r2s_plan* P, const uint32_t* in0, uint32_t* out0, const uint32_t* in1, uint32_t* out1,
+                           int64_t n, hipStream_t st, int level = 0)
 {
     if (n <= 0) return 0;
+    const unsigned ny = in1 ? 2u : 1u;
     const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    ScanPair sp;
+    sp.in[0] = in0; sp.out[0] = out0; sp.in[1] = in1; sp.out[1] = out1;
+    sp.sums[0] = sp.sums[1] = nullptr;
     if (nb == 1) {
-        scan_block_kernel<<<1, SCAN_BLOCK, 0, st>>>(in, out, nullptr, n);
+        scan_block_kernel<<<dim3(1, ny), SCAN_BLOCK, 0, st>>>(sp, n);
         return 0;
     }
     if (level >= 3) return fail(R2S_ERR_ARG, "scan too large");
-    if (P->scan_tmp[level].ensure(sizeof(uint32_t) * (size_t)nb)) return fail(R2S_ERR_NOMEM, "scan workspace");
-    uint32_t* sums = P->scan_tmp[level].as<uint32_t>();
-    scan_block_kernel<<<(unsigned)nb, SCAN_BLOCK, 0, st>>>(in, out, sums, n);
-    int rc = scan_exclusive(P, sums, sums, nb, st, level + 1);
+    if (P->scan_tmp[level].ensure(sizeof(uint32_t) * 2 * (size_t)nb)) return fail(R2S_ERR_NOMEM, "scan workspace");
+    sp.sums[0] = P->scan_tmp[level].as<uint32_t>();
+    sp.sums[1] = sp.sums[0] + nb;
+    scan_block_kernel<<<dim3((unsigned)nb, ny), SCAN_BLOCK, 0, st>>>(sp, n);
+    int rc = scan_exclusive2(P, sp.sums[0], sp.sums[0], in1 ? sp.sums[1] : nullptr, in1 ? sp.sums[1] : nullptr, nb, st,
+                             level + 1);
     if (rc) return rc;
-    scan_add_kernel<<<(unsigned)nb, SCAN_BLOCK, 0, st>>>(out, sums, n);
+    scan_add_kernel<<<dim3((unsigned)nb, ny), SCAN_BLOCK, 0, st>>>(sp, n);
     return 0;
+}
+static int scan_exclusive(r2s_plan* P, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st)
+{
+    return scan_exclusive2(P, in, out, nullptr, nullptr, n, st);
 }
 
 extern "C" {
@@ -1735,9 +1784,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
 
     HIP_TRY(hipEventRecord(P->ev[0], st));
     // ---- node -> element CSR ----
-    HIP_TRY(hipMemsetAsync(P->deg.p, 0, sizeof(uint32_t) * (size_t)(nnp + 1), st));
-    HIP_TRY(hipMemsetAsync(P->cursor.p, 0, sizeof(uint32_t) * (size_t)(nnp + 1), st));
-    HIP_TRY(hipMemsetAsync(counters, 0, 64, st));
+    zero_many(st, {{P->deg.p, sizeof(uint32_t) * (size_t)(nnp + 1)}, {P->cursor.p, sizeof(uint32_t) * (size_t)(nnp + 1)},
+                   {counters, 64}, {P->nitems.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
     {
         const int64_t n = nel * ET::NEN;
         node_degree_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, ET::NEN, nnp, P->deg.as<uint32_t>(), (int*)counters);
@@ -1746,7 +1794,6 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         ine_fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, ET::NEN, nnp, P->ine_ptr.as<uint32_t>(), P->cursor.as<uint32_t>(), P->ine.as<uint32_t>());
     }
     // ---- element records, classes, item counts ----
-    HIP_TRY(hipMemsetAsync(P->nitems.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
     elem_prep_kernel<ET><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
         dX, dIEN, d_rho_n, nel, rho_t, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), g, P->erec.as<typename ET::Rec>(),
         P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->nitems.as<uint32_t>());
@@ -1768,14 +1815,12 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->nstore, sizeof(uint32_t) * (size_t)(n_items + 1));
     ENSURE(P->store_off, sizeof(uint32_t) * (size_t)(n_items + 1));
     if (n_items) {
-        HIP_TRY(hipMemsetAsync(P->nchunks.p, 0, sizeof(uint32_t) * (size_t)(n_items + 1), st));
-        HIP_TRY(hipMemsetAsync(P->nstore.p, 0, sizeof(uint32_t) * (size_t)(n_items + 1), st));
+        zero_many(st, {{P->nchunks.p, sizeof(uint32_t) * (size_t)(n_items + 1)}, {P->nstore.p, sizeof(uint32_t) * (size_t)(n_items + 1)}});
         item_build_kernel<ET><<<(unsigned)((nel + 63) / 64), 64, 0, st>>>(
             P->erec.as<typename ET::Rec>(), P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->item_off.as<uint32_t>(), nel,
             g, s, delta, P->items.as<BandItem>(), P->nchunks.as<uint32_t>(), P->nstore.as<uint32_t>());
-        int rc = scan_exclusive(P, P->nchunks.as<uint32_t>(), P->chunk_off.as<uint32_t>(), (int64_t)n_items + 1, st);
-        if (rc) return rc;
-        rc = scan_exclusive(P, P->nstore.as<uint32_t>(), P->store_off.as<uint32_t>(), (int64_t)n_items + 1, st);
+        int rc = scan_exclusive2(P, P->nchunks.as<uint32_t>(), P->chunk_off.as<uint32_t>(), P->nstore.as<uint32_t>(),
+                                 P->store_off.as<uint32_t>(), (int64_t)n_items + 1, st);
         if (rc) return rc;
         item_chunks_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(P->items.as<BandItem>(), P->chunk_off.as<uint32_t>(), P->store_off.as<uint32_t>(), n_items);
         HIP_TRY(hipMemcpyAsync(&P->h_pinned[10], P->chunk_off.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
@@ -1784,10 +1829,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipEventRecord(P->ev[1], st));
 
     // ---- tile bins ----
-    HIP_TRY(hipMemsetAsync(P->band_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
-    HIP_TRY(hipMemsetAsync(P->sign_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
-    HIP_TRY(hipMemsetAsync(P->hot.p, 0, (size_t)ntiles + 1, st));
-    HIP_TRY(hipMemsetAsync(P->tri.p, 0, (size_t)ntiles + 1, st));
+    zero_many(st, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)},
+                   {P->hot.p, (size_t)ntiles + 1}, {P->tri.p, (size_t)ntiles + 1}});
     if (n_items)
         band_bin_kernel<false><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr, P->tri.as<uint8_t>());
     if (want_sign)
@@ -1796,9 +1839,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>());
     }
     {
-        int rc = scan_exclusive(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
-        if (rc) return rc;
-        rc = scan_exclusive(P, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
+        int rc = scan_exclusive2(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->sign_cnt.as<uint32_t>(),
+                                 P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
         if (rc) return rc;
     }
     constexpr bool HEX = std::is_same<typename ET::Rec, ElemRec>::value;
@@ -1811,12 +1853,10 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             ENSURE(P->s_chunk_off, sizeof(uint32_t) * (size_t)(nel + 1));
             ENSURE(P->s_nstore, sizeof(uint32_t) * (size_t)(nel + 1));
             ENSURE(P->s_store_off, sizeof(uint32_t) * (size_t)(nel + 1));
-            HIP_TRY(hipMemsetAsync(P->s_nchunks.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
-            HIP_TRY(hipMemsetAsync(P->s_nstore.p, 0, sizeof(uint32_t) * (size_t)(nel + 1), st));
+            zero_many(st, {{P->s_nchunks.p, sizeof(uint32_t) * (size_t)(nel + 1)}, {P->s_nstore.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
             sign_box_kernel<<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>(), P->s_nstore.as<uint32_t>());
-            int rc = scan_exclusive(P, P->s_nchunks.as<uint32_t>(), P->s_chunk_off.as<uint32_t>(), nel + 1, st);
-            if (rc) return rc;
-            rc = scan_exclusive(P, P->s_nstore.as<uint32_t>(), P->s_store_off.as<uint32_t>(), nel + 1, st);
+            int rc = scan_exclusive2(P, P->s_nchunks.as<uint32_t>(), P->s_chunk_off.as<uint32_t>(), P->s_nstore.as<uint32_t>(),
+                                     P->s_store_off.as<uint32_t>(), nel + 1, st);
             if (rc) return rc;
             HIP_TRY(hipMemcpyAsync(&P->h_pinned[11], P->s_chunk_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(&P->h_pinned[13], P->s_store_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
@@ -1842,8 +1882,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->band_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
     ENSURE(P->sign_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_sign, 1));
     ENSURE(P->sign_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_sign, 1));
-    HIP_TRY(hipMemsetAsync(P->band_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
-    HIP_TRY(hipMemsetAsync(P->sign_cnt.p, 0, sizeof(uint32_t) * (size_t)(ntiles + 1), st));
+    zero_many(st, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}});
     if (n_items)
         band_bin_kernel<true><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), nullptr);
     if (want_sign)
