@@ -1370,7 +1370,7 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                             in[u] = valid && ok && di < (uint32_t)dim3[0] && dj < (uint32_t)dim3[1] && dk < (uint32_t)dim3[2];
                             rmax[u] = __hiloint2double(hh[7], hh[6]);
                             v[u] = INFINITY;
-                            if (in[u])
+                            if (in[u] && !done)   // a lane that is done (as of the previous batch) needs no more look-ups
                                 v[u] = A.sres[(size_t)tile_chunk((uint32_t)hh[8], tile_box(lo3, dim3), tx, ty, tz) * 64u + (uint32_t)lane];
                         }
 #pragma unroll
