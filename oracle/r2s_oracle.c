@@ -351,7 +351,7 @@ typedef struct {
     double f, c;
 } iso_fc;
 
-static inline iso_fc iso_eval_fc(const double x[3], const double Xe[8][3], const double re[8],
+static inline iso_fc iso_eval_fc(const double x[3], const double Xe[16][3], const double re[16],
                                  double rt, const double xi[3])
 {
     iso_fc o;
@@ -769,7 +769,7 @@ static inline int write_value(dist_ctx *c, int64_t v, double d, const double xp[
 }
 
 /* IsProjectedOnFullSegment, HEX8 branch (sdfOnDensityField.jl:78-119) */
-static int projected_on_full_segment_hex8(dist_ctx *c, const double Xe[8][3], const double re[8],
+static int projected_on_full_segment_hex8(dist_ctx *c, const double Xe[16][3], const double re[16],
                                           double rt, const double xp[3], const double x[3], int64_t v)
 {
     double xi[3], N[8];
@@ -791,7 +791,7 @@ static int projected_on_full_segment_hex8(dist_ctx *c, const double Xe[8][3], co
 
 static int projected_on_full_segment_tet4(dist_ctx *c, const double Xe[8][3], const double re[8],
                                           double rt, const double xp[3], const double x[3], int64_t v);
-static inline int projected_on_full_segment(dist_ctx *c, const double Xe[8][3], const double re[8],
+static inline int projected_on_full_segment(dist_ctx *c, const double Xe[16][3], const double re[16],
                                             double rt, const double xp[3], const double x[3], int64_t v)
 {
     return c->elem_type == 0 ? projected_on_full_segment_hex8(c, Xe, re, rt, xp, x, v)
@@ -819,7 +819,7 @@ static void barycentric(const double x1[3], const double x2[3], const double x3[
 
 /* process_triangle_projection! (sdfOnDensityField.jl:628-815), HEX8 validation */
 static void process_triangle(dist_ctx *c, const double Xt[3][3], int is_solid,
-                             const double Xe[8][3], const double re[8], double rt)
+                             const double Xe[16][3], const double re[16], double rt)
 {
     const orc_grid *g = c->g;
     double Et[3][3], n[3];
@@ -894,7 +894,7 @@ static void process_triangle(dist_ctx *c, const double Xt[3][3], int is_solid,
 
 /* process_boundary_faces! (sdfOnDensityField.jl:489-558) */
 static void process_boundary_faces(dist_ctx *c, const orc_mesh *m, int64_t el, int is_solid,
-                                   const double Xe[8][3], const double re[8], double rt)
+                                   const double Xe[16][3], const double re[16], double rt)
 {
     for (int sg = 0; sg < m->nes; ++sg) {
         if (!face_is_boundary(m, el, sg)) continue;
@@ -1043,7 +1043,7 @@ static void elem_gather_hex8(const double *X, const int64_t *IEN, const double *
 }
 
 /* per-voxel state machine of SignDetection.jl:41-70 for one candidate element */
-static inline void sign_visit(const double Xe[8][3], const double re[8], double rt, const double x[3],
+static inline void sign_visit(const double Xe[16][3], const double re[16], double rt, const double x[3],
                               double *max_local, double *sign, int *done)
 {
     double xi[3], N[8];
