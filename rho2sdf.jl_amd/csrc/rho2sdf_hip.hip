@@ -1915,7 +1915,9 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     // and sign_project starting together with the projection kernel 6.7 (the projection kernel is the long
     // pole and should get its persistent waves placed first); sweep + sign_project already after the second
     // read-back, beside the list fill / sort kernels 6.4 (those short kernels then wait for wave slots and the
-    // projection kernel starts 1.2 ms later); this order 5.3.
+    // projection kernel starts 1.2 ms later); inverse maps split into elements near the band (which the band
+    // gather waits for) and the rest: no change - what is left after the projection kernel is work-bound; this
+    // order 5.15.
     {
         const bool two_streams = overlap || fork;
         hipStream_t fs = two_streams ? P->st2 : st;
