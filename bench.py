@@ -176,6 +176,10 @@ def main():
                                              if k.get("SQ_ACTIVE_INST_VALU") else None),
                         "valu_issue_frac_est": (k["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * main_s)
                                                 if k.get("SQ_INSTS_VALU") and main_s > 0 else None)}
+                if valu["lane_utilisation"] and valu["valu_issue_frac_est"]:
+                    # useful FP64-rate lane-instructions against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+                    # (78.6 TFLOP/s FP64 vector peak when every instruction is an FMA)
+                    valu["fp64_valu_frac_est"] = valu["lane_utilisation"] * valu["valu_issue_frac_est"]
         out = {
             "metric": "Mvoxels/s SDF extract on 512^3 grid over 100k HEX8; max|err| vs ref",
             "value": value, "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
