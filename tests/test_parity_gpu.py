@@ -336,3 +336,17 @@ def test_chapadlo_config4_grid(pkg, oracle):
     rel = np.abs(got[real] - ref[real]) / np.maximum(np.abs(ref[real]), 1e-300)
     assert not ((rel > RTOL) & (np.abs(got[real] - ref[real]) > 1e-12 * og.cell)).any()
     print(f"chapadlo 87x166x257: bit-equal {int((got == ref).sum())}/{got.size}")
+
+
+def test_mesh_finer_than_grid(pkg, oracle):
+    """a grid much coarser than the mesh: tile lists hold hundreds of items / candidates (the > 64-entry paths of
+    the list sort and of the lane-parallel list walk in the gather)"""
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, rn = synthetic.hex_mesh(20)
+    nmax = synthetic.grid_n_max_for_points(24)
+    pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
+    st = {}
+    pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5, stats=st)
+    assert st["n_sign_entries"] / max(st["n_active_sign_tiles"], 1) > 64
+    _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, 1.1, "mesh 20^3 on a 24^3 grid")
