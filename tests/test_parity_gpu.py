@@ -350,3 +350,31 @@ def test_mesh_finer_than_grid(pkg, oracle):
     pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5, stats=st)
     assert st["n_sign_entries"] / max(st["n_active_sign_tiles"], 1) > 64
     _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, 1.1, "mesh 20^3 on a 24^3 grid")
+
+
+def test_elements_much_larger_than_cells(pkg, oracle):
+    """8 elements on a 340^3 grid: every item box holds > 2^22 lattice points (the integer-division path of the
+    box enumeration, thousands of 64-voxel chunks per item).  Checked on every 48th Z plane (the oracle's plane
+    sampling, as in bench.py)."""
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, _ = synthetic.hex_mesh(2, jitter=0.1)
+    rn = np.clip(1.2 - np.linalg.norm(X, axis=1), 0.0, 1.0)
+    nmax = synthetic.grid_n_max_for_points(340)
+    pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
+    nx, ny, nz = pg.dims
+    sdf = pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5).reshape(nz, ny, nx)
+    stride = 48
+    oracle.set_k_sampling(stride, 0)
+    try:
+        d, _, _ = oracle.eval_distances(X, IEN, rn, 0.5, og, 1.1, want_xp=False)
+        ref = (d * oracle.sign_detection(X, IEN, rn, 0.5, og)).reshape(nz, ny, nx)[::stride]
+    finally:
+        oracle.set_k_sampling(1, 0)
+    got = sdf[::stride]
+    assert np.array_equal(np.abs(got) > 1e9, np.abs(ref) > 1e9) and np.array_equal(np.sign(got), np.sign(ref))
+    real = np.abs(ref) < 1e9
+    assert real.sum() > 1000
+    rel = np.abs(got[real] - ref[real]) / np.maximum(np.abs(ref[real]), 1e-300)
+    assert not ((rel > RTOL) & (np.abs(got[real] - ref[real]) > 1e-12 * og.cell)).any()
+    print(f"large elements: {int(real.sum())} band voxels on the sampled planes, bit-equal {int((got == ref).sum())}/{got.size}")
