@@ -213,6 +213,11 @@ int r2s_rbf_smooth_dev(const double *d_sdf, const r2s_grid *grid, int32_t is_int
 int r2s_export_vti(const char *filename, const r2s_grid *grid, const void *values, int32_t is_float32,
                    int64_t n_values, const char *value_label, int32_t smooth);
 
+/* exportToVTU(fileName, X, IEN, VTK_CODE, rho)                       src/DataExport/ExportToVTU.jl:2-99
+ * ASCII UnstructuredGrid of the mesh (VTK_CODE 12 = hexahedron, 10 = tetra), optional nodal "density". */
+int r2s_export_vtu(const char *filename, const double *X, int64_t nnp, const int64_t *IEN, int64_t nel,
+                   int32_t nen, int32_t vtk_code, const double *rho_n);
+
 /* frees the process-wide work buffers the library keeps between calls (the materialised RBF matrix of the CG:
  * up to a quarter of the device memory, see r2s_post.hip) */
 void r2s_release_cache(void);

@@ -82,6 +82,7 @@ SYMBOLS = [
                                       ctypes.c_double, ctypes.c_double, ctypes.c_int32, c_float_p, c_float_p,
                                       ctypes.POINTER(ctypes.c_int32), c_float_p]),
     ("r2s_release_cache", None, []),
+    ("r2s_export_vtu", ctypes.c_int, [ctypes.c_char_p] + _MESH + [ctypes.c_int32, ctypes.c_int32, c_double_p]),
     ("r2s_export_vti", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(R2SGrid), _P, ctypes.c_int32, ctypes.c_int64,
                                       ctypes.c_char_p, ctypes.c_int32]),
     ("r2s_rbf_smooth_dev", ctypes.c_int, [_P, ctypes.POINTER(R2SGrid), ctypes.c_int32, ctypes.c_int32, ctypes.c_double,

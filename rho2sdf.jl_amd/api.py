@@ -328,6 +328,22 @@ def exportSdfToVTI(filename, grid, values, value_label, smooth=None):
     return filename if filename.endswith(".vti") else filename + ".vti"
 
 
+def exportToVTU(fileName, X, IEN, VTK_CODE=None, rho=None):
+    """exportToVTU(fileName, X, IEN, VTK_CODE, rho) - ASCII UnstructuredGrid of the mesh with optional nodal
+    densities (src/DataExport/ExportToVTU.jl:2-99).  X (nnp, 3), IEN (nel, nen) 1-based; VTK_CODE defaults to
+    12 (hexahedron) / 10 (tetra) by the number of element nodes, like the reference's callers."""
+    mesh = Mesh(X, IEN)
+    code = (12 if mesh.nen == 8 else 10) if VTK_CODE is None else int(VTK_CODE)
+    r = None
+    if rho is not None:
+        r = np.ascontiguousarray(rho, dtype=np.float64)
+        if r.shape != (mesh.nnp,):
+            raise L.R2SError("length of nodal densities does not match number of nodes")
+    L.check(L.lib().r2s_export_vtu(str(fileName).encode(), _d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, mesh.nen, code,
+                                   _d(r) if r is not None else None))
+    return str(fileName)
+
+
 def export_sdf_results(fine_sdf, sdf_grid, taskName, smooth, is_interpolation, element_type):
     """export_sdf_results_with_element_type (src/RhoToSDF.jl:249-283), the .vti part: same file name
     `<task>_<HEX8|TET4>_B-<round(cell,4)>_smooth-<s>_<Interpolation|Approximation>.vti`, point array "distance".

@@ -55,4 +55,48 @@ int r2s_export_vti(const char* filename, const r2s_grid* grid, const void* value
     return 0;
 }
 
+// exportToVTU(fileName, X, IEN, VTK_CODE, rho)                        src/DataExport/ExportToVTU.jl:2-99
+// ASCII UnstructuredGrid with the reference's arrays: Points (Float64; |x| < 1e-20 written as 0), connectivity
+// (0-based), offsets, types (VTK_CODE: 12 = hexahedron, 10 = tetra), optional point data "density".
+// Numbers are written with 17 significant digits (Julia prints the shortest round-trip form; same values).
+int r2s_export_vtu(const char* filename, const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, int32_t nen,
+                   int32_t vtk_code, const double* rho_n)
+{
+    if (!filename || !X || !IEN || nnp <= 0 || nel <= 0 || nen <= 0) return fail(R2S_ERR_ARG, "bad argument");
+    FILE* f = fopen(filename, "w");
+    if (!f) return fail(R2S_ERR_ARG, "cannot open %s for writing", filename);
+    fprintf(f, "<VTKFile type=\"UnstructuredGrid\" version=\"0.1\" byte_order=\"LittleEndian\">\n  <UnstructuredGrid>\n");
+    fprintf(f, "    <Piece NumberOfPoints=\"%lld\" NumberOfCells=\"%lld\">\n", (long long)nnp, (long long)nel);
+    fprintf(f, "\t  <Points>\n        <DataArray type=\"Float64\" NumberOfComponents=\"3\" format=\"ascii\">\n");
+    for (int64_t a = 0; a < nnp; ++a) {
+        fprintf(f, "          ");
+        for (int i = 0; i < 3; ++i) {
+            const double v = X[3 * a + i];
+            fprintf(f, " %.17g", (v < 1.0e-20 && v > -1.0e-20) ? 0.0 : v);
+        }
+        fprintf(f, "\n");
+    }
+    fprintf(f, "        </DataArray>\n\t  </Points>\n      <Cells>\n");
+    fprintf(f, "\t\t  <DataArray type=\"Int32\" Name=\"connectivity\" format=\"ascii\">\n");
+    for (int64_t el = 0; el < nel; ++el) {
+        fprintf(f, "         ");
+        for (int a = 0; a < nen; ++a) fprintf(f, " %lld", (long long)(IEN[el * nen + a] - 1));
+        fprintf(f, "\n");
+    }
+    fprintf(f, "        </DataArray>\n        <DataArray type=\"Int32\" Name=\"offsets\" format=\"ascii\">\n");
+    for (int64_t el = 1; el <= nel; ++el) fprintf(f, "          %lld\n", (long long)(el * nen));
+    fprintf(f, "        </DataArray>\n        <DataArray type=\"UInt8\" Name=\"types\" format=\"ascii\">\n");
+    for (int64_t el = 0; el < nel; ++el) fprintf(f, "          %d\n", (int)vtk_code);
+    fprintf(f, "        </DataArray>\n      </Cells>\n");
+    if (rho_n) {
+        fprintf(f, "      <PointData Scalars=\"scalars\">\n           <DataArray type=\"Float32\" Name=\"density\" Format=\"ascii\">\n");
+        for (int64_t a = 0; a < nnp; ++a) fprintf(f, "             %.17g\n", rho_n[a]);
+        fprintf(f, "           </DataArray>\n      </PointData>\n");
+    }
+    fprintf(f, "    </Piece>\n  </UnstructuredGrid>\n</VTKFile>\n");
+    const int bad = ferror(f);
+    if (fclose(f) != 0 || bad) return fail(R2S_ERR_ARG, "write to %s failed", filename);
+    return 0;
+}
+
 }  // extern "C"

@@ -51,3 +51,27 @@ def test_result_file_name(pkg, tmp_path, monkeypatch):
     dims = tuple(int(n) * 2 + 1 for n in g.c.N)
     p = pkg.export_sdf_results(np.zeros(dims[::-1], dtype=np.float32), g, "beam", 2, True, pkg._lib.HEX8)
     assert p == f"beam_HEX8_B-{round(g.cell_size, 4)}_smooth-2_Interpolation.vti"     # RhoToSDF.jl:268
+
+
+def test_vtu_round_trip(pkg, tmp_path):
+    """exportToVTU (reference src/DataExport/ExportToVTU.jl:2-99): points, 0-based connectivity, offsets, cell types
+    and the nodal density array read back from the ASCII file"""
+    from conftest import load_fixture
+    X, IEN, rho = load_fixture("sphere")
+    rn = np.linspace(0.0, 1.0, len(X))
+    X = X.copy()
+    X[3, 1] = 1e-25                                   # |x| < 1e-20 is written as 0 (ExportToVTU.jl:39-41)
+    path = pkg.exportToVTU(str(tmp_path / "mesh.vtu"), X, IEN, 12, rn)
+    txt = open(path).read()
+    assert f'NumberOfPoints="{len(X)}" NumberOfCells="{len(IEN)}"' in txt
+    blocks = re.findall(r"<DataArray[^>]*>\n(.*?)</DataArray>", txt, flags=re.S)
+    pts = np.array(blocks[0].split(), dtype=np.float64).reshape(-1, 3)
+    conn = np.array(blocks[1].split(), dtype=np.int64).reshape(-1, 8)
+    offs = np.array(blocks[2].split(), dtype=np.int64)
+    types = np.array(blocks[3].split(), dtype=np.int64)
+    dens = np.array(blocks[4].split(), dtype=np.float64)
+    Xz = X.copy()
+    Xz[np.abs(Xz) < 1e-20] = 0.0
+    assert np.array_equal(pts, Xz) and np.array_equal(conn, IEN - 1)
+    assert np.array_equal(offs, 8 * np.arange(1, len(IEN) + 1)) and np.all(types == 12)
+    assert np.array_equal(dens, rn) and 'Name="density"' in txt
