@@ -271,8 +271,7 @@ struct TetT {
 // faces (:511-519), work-item count, lattice range of the element AABB for the sign bins.
 template <class ET>
 __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __restrict__ IEN,
-                                 const double* __restrict__ rho_n, int64_t nel, double rho_t,
-                                 const uint32_t* __restrict__ ine_ptr, const uint32_t* __restrict__ ine,
+                                 const double* __restrict__ rho_n, int64_t nel, int64_t nnp, double rho_t,
                                  GridDev g, typename ET::Rec* __restrict__ erec, uint8_t* __restrict__ cls,
                                  uint32_t* __restrict__ fmask, uint32_t* __restrict__ nitems)
 {
@@ -284,6 +283,7 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
 #pragma unroll
     for (int a = 0; a < ET::NEN; ++a) {
         nd[a] = IEN[el * ET::NEN + a] - 1;
+        if ((uint64_t)nd[a] >= (uint64_t)nnp) nd[a] = 0;   // reported by node_degree_kernel; keep the loads in range
 #pragma unroll
         for (int i = 0; i < 3; ++i) R.X[a][i] = X[3 * nd[a] + i];
         R.r[a] = rho_n[nd[a]];
@@ -319,12 +319,13 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
 template <class ET>
 __global__ void face_mask_kernel(const int64_t* __restrict__ IEN, int64_t nel, const uint32_t* __restrict__ ine_ptr,
                                  const uint32_t* __restrict__ ine, const uint8_t* __restrict__ cls,
-                                 uint32_t* __restrict__ fmask, uint32_t* __restrict__ nitems)
+                                 uint32_t* __restrict__ fmask, uint32_t* __restrict__ nitems,
+                                 const int* __restrict__ bad)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t el = gid / ET::NES;
     const int sg = (int)(gid % ET::NES);
-    if (el >= nel || cls[el] == CLS_SKIP) return;
+    if (el >= nel || cls[el] == CLS_SKIP || *bad) return;   // bad: IEN holds ids outside 1..nnp, the call fails after this kernel
     const int64_t n0 = IEN[el * ET::NEN + ET::face(sg, 0)] - 1;
     int common = 0;
     for (uint32_t p = ine_ptr[n0]; p < ine_ptr[n0 + 1]; ++p) {
@@ -1783,23 +1784,26 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] band tiles, [2] sign tiles
 
     HIP_TRY(hipEventRecord(P->ev[0], st));
-    // ---- node -> element CSR ----
+    // ---- node -> element CSR (second stream) beside the element records, classes, item counts ----
     zero_many(st, {{P->deg.p, sizeof(uint32_t) * (size_t)(nnp + 1)}, {P->cursor.p, sizeof(uint32_t) * (size_t)(nnp + 1)},
                    {counters, 64}, {P->nitems.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
+    HIP_TRY(hipEventRecord(P->ev2[0], st));
+    HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[0], 0));
     {
         const int64_t n = nel * ET::NEN;
-        node_degree_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, ET::NEN, nnp, P->deg.as<uint32_t>(), (int*)counters);
-        int rc = scan_exclusive(P, P->deg.as<uint32_t>(), P->ine_ptr.as<uint32_t>(), nnp + 1, st);
+        node_degree_kernel<<<(unsigned)((n + 255) / 256), 256, 0, P->st2>>>(dIEN, nel, ET::NEN, nnp, P->deg.as<uint32_t>(), (int*)counters);
+        int rc = scan_exclusive(P, P->deg.as<uint32_t>(), P->ine_ptr.as<uint32_t>(), nnp + 1, P->st2);
         if (rc) return rc;
-        ine_fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dIEN, nel, ET::NEN, nnp, P->ine_ptr.as<uint32_t>(), P->cursor.as<uint32_t>(), P->ine.as<uint32_t>());
+        ine_fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, P->st2>>>(dIEN, nel, ET::NEN, nnp, P->ine_ptr.as<uint32_t>(), P->cursor.as<uint32_t>(), P->ine.as<uint32_t>());
     }
-    // ---- element records, classes, item counts ----
+    HIP_TRY(hipEventRecord(P->ev2[1], P->st2));
     elem_prep_kernel<ET><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
-        dX, dIEN, d_rho_n, nel, rho_t, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), g, P->erec.as<typename ET::Rec>(),
+        dX, dIEN, d_rho_n, nel, nnp, rho_t, g, P->erec.as<typename ET::Rec>(),
         P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->nitems.as<uint32_t>());
+    HIP_TRY(hipStreamWaitEvent(st, P->ev2[1], 0));
     face_mask_kernel<ET><<<(unsigned)((nel * ET::NES + 255) / 256), 256, 0, st>>>(
         dIEN, nel, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(),
-        P->nitems.as<uint32_t>());
+        P->nitems.as<uint32_t>(), (const int*)counters);
     {
         int rc = scan_exclusive(P, P->nitems.as<uint32_t>(), P->item_off.as<uint32_t>(), nel + 1, st);
         if (rc) return rc;

@@ -149,3 +149,18 @@ def test_mesh_volume_tet4(pkg, oracle):
     assert vd == pytest.approx(0.75 * 8.0, rel=1e-12)      # [-1,1]^3, see the note in r2s_pre.hip
     rn_gpu = pkg.DenseInNodes(pkg.Mesh(X, IT), rho)
     assert np.abs(rn_gpu - oracle.dense_in_nodes(X, IT, rho)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("badval", [0, -3, 10**9])
+def test_connectivity_outside_node_range_is_an_error(pkg, oracle, badval):
+    """IEN ids outside 1..nnp: the call fails with a message (the reference would throw a BoundsError)
+    and the device survives to run the next call."""
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    pg = pkg.Grid(X.min(0), X.max(0), 10, 3)
+    bad = IEN.copy()
+    bad[len(bad) // 2, 3] = badval
+    with pytest.raises(pkg._lib.R2SError, match="outside 1..nnp"):
+        pkg.sdf_fused(pkg.Mesh(X, bad), pg, rn, 0.5)
+    sdf = pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5, band_factor=2.5)
+    assert (np.abs(sdf) == 1e10).sum() == 1836
