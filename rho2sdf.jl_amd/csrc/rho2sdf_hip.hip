@@ -135,6 +135,21 @@ static void zero_many(hipStream_t st, std::initializer_list<std::pair<void*, siz
 // ------------------------------------------------------------------------------------
 // mesh preparation kernels
 // ------------------------------------------------------------------------------------
+// The scalars the host needs between stages (array sizes) travel to pinned host memory in ONE small kernel
+// per read-back point instead of one blit kernel per value.
+struct ReadBack {
+    const uint32_t* src[8];
+    uint32_t n[8];     // words per entry (<= 8)
+    uint32_t dst[8];   // first word in the pinned block
+    int cnt = 0;
+    void add(const uint32_t* p, uint32_t words, uint32_t at) { src[cnt] = p; n[cnt] = words; dst[cnt] = at; ++cnt; }
+};
+__global__ void read_back_kernel(ReadBack rb, uint32_t* __restrict__ host)
+{
+    const int q = threadIdx.x >> 3, w = threadIdx.x & 7;
+    if (q < rb.cnt && (uint32_t)w < rb.n[q]) host[rb.dst[q] + w] = rb.src[q][w];
+}
+
 __global__ void node_degree_kernel(const int64_t* __restrict__ IEN, int64_t nel, int nen, int64_t nnp,
                                    uint32_t* __restrict__ deg, int* __restrict__ bad)
 {
@@ -793,6 +808,28 @@ struct IsoElemLds {
     double X[8][3];
 };
 #define R2S_ISO_SLOTS 4
+#ifdef R2S_ISO_STATS   // diagnostic build only (tools/iso_phase_stats.py): visits and active lanes per phase
+__device__ unsigned long long g_iso_stats[32];   // [16..31]: histogram of SQP iterations / 4
+#define ISO_STAT(p, cond)                                                                  \
+    {                                                                                      \
+        const uint64_t m__ = __ballot(cond);                                               \
+        if (m__ && lane == 0) {                                                            \
+            atomicAdd(&g_iso_stats[2 * (p)], 1ull);                                        \
+            atomicAdd(&g_iso_stats[2 * (p) + 1], (unsigned long long)__popcll(m__));       \
+        }                                                                                  \
+    }
+extern "C" int r2s_debug_iso_stats(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iso_stats), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_iso_stats), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#else
+#define ISO_STAT(p, cond)
+#endif
 __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
     const BandItem* __restrict__ items, uint32_t nitems, const uint32_t* __restrict__ chunk_off, uint32_t nchunks,
     uint32_t group, const ElemRec* __restrict__ erec, GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
@@ -819,7 +856,11 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
         const uint64_t m_done = __ballot(s.phase == ISO_DONE);
         const uint64_t m_busy = __ballot(s.phase != ISO_DONE && s.phase != ISO_IDLE);
         if (m_busy == 0 || __popcll(m_done) >= R2S_ISO_REFILL_MIN) {
+            ISO_STAT(6, s.phase == ISO_DONE)
             if (s.phase == ISO_DONE) {
+#ifdef R2S_ISO_STATS
+                atomicAdd(&g_iso_stats[16 + (s.it / 4 > 15 ? 15 : s.it / 4)], 1ull);
+#endif
                 const IsoElemLds& E = slots[eslot];
                 double N[8], xp[3];
                 hex8_shape(s.xi, N);
@@ -908,11 +949,17 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
         // ---- one visit of each phase ----
         {
             const IsoElemLds& E = slots[eslot];
+            ISO_STAT(0, s.phase == ISO_EVAL)
             if (s.phase == ISO_EVAL) iso_lane_eval(E, rho_t, s);
+            ISO_STAT(1, s.phase == ISO_QP)
             if (s.phase == ISO_QP) iso_lane_qp(s);
+            ISO_STAT(2, s.phase == ISO_POST)
             if (s.phase == ISO_POST) iso_lane_post(s);
+            ISO_STAT(3, s.phase == ISO_LS)
             if (s.phase == ISO_LS) iso_lane_ls(E, rho_t, s);
+            ISO_STAT(4, s.phase == ISO_UPD)
             if (s.phase == ISO_UPD) iso_lane_update(s);
+            ISO_STAT(5, true)
         }
     }
 }
@@ -1528,6 +1575,7 @@ struct r2s_plan {
     uint32_t last_n_any = 0, last_n_band = 0, last_n_sonly = 0;
     bool has_last = false;
     uint32_t* h_pinned = nullptr;  // 16 words
+    uint32_t* d_pinned = nullptr;  // the same block as the device sees it
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // second stream: sentinel sweep + sign pass run beside the iso-surface projection (fused SDF output)
     hipStream_t st2 = nullptr;
@@ -1664,7 +1712,8 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) P->n_cu = prop.multiProcessorCount;
     }
-    HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostGetDevicePointer((void**)&P->d_pinned, P->h_pinned, 0));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
     for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
     {
@@ -1808,8 +1857,12 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         int rc = scan_exclusive(P, P->nitems.as<uint32_t>(), P->item_off.as<uint32_t>(), nel + 1, st);
         if (rc) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[0], P->item_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[1], counters, 4, hipMemcpyDeviceToHost, st));
+    {
+        ReadBack rb;
+        rb.add(P->item_off.as<uint32_t>() + nel, 1, 0);
+        rb.add(counters, 1, 1);
+        read_back_kernel<<<1, 64, 0, st>>>(rb, P->d_pinned);
+    }
     HIP_TRY(hipStreamSynchronize(st));
     if (P->h_pinned[1]) return fail(R2S_ERR_ARG, "IEN contains node ids outside 1..nnp");
     const uint32_t n_items = want_dist ? P->h_pinned[0] : 0;
@@ -1818,6 +1871,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->chunk_off, sizeof(uint32_t) * (size_t)(n_items + 1));
     ENSURE(P->nstore, sizeof(uint32_t) * (size_t)(n_items + 1));
     ENSURE(P->store_off, sizeof(uint32_t) * (size_t)(n_items + 1));
+    ReadBack rb2;   // second read-back point (after the count passes)
     if (n_items) {
         zero_many(st, {{P->nchunks.p, sizeof(uint32_t) * (size_t)(n_items + 1)}, {P->nstore.p, sizeof(uint32_t) * (size_t)(n_items + 1)}});
         item_build_kernel<ET><<<(unsigned)((nel + 63) / 64), 64, 0, st>>>(
@@ -1827,8 +1881,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                                  P->store_off.as<uint32_t>(), (int64_t)n_items + 1, st);
         if (rc) return rc;
         item_chunks_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(P->items.as<BandItem>(), P->chunk_off.as<uint32_t>(), P->store_off.as<uint32_t>(), n_items);
-        HIP_TRY(hipMemcpyAsync(&P->h_pinned[10], P->chunk_off.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&P->h_pinned[12], P->store_off.as<uint32_t>() + n_items, 4, hipMemcpyDeviceToHost, st));
+        rb2.add(P->chunk_off.as<uint32_t>() + n_items, 1, 10);
+        rb2.add(P->store_off.as<uint32_t>() + n_items, 1, 12);
     }
     HIP_TRY(hipEventRecord(P->ev[1], st));
 
@@ -1862,15 +1916,16 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             int rc = scan_exclusive2(P, P->s_nchunks.as<uint32_t>(), P->s_chunk_off.as<uint32_t>(), P->s_nstore.as<uint32_t>(),
                                      P->s_store_off.as<uint32_t>(), nel + 1, st);
             if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(&P->h_pinned[11], P->s_chunk_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(&P->h_pinned[13], P->s_store_off.as<uint32_t>() + nel, 4, hipMemcpyDeviceToHost, st));
+            rb2.add(P->s_chunk_off.as<uint32_t>() + nel, 1, 11);
+            rb2.add(P->s_store_off.as<uint32_t>() + nel, 1, 13);
         }
     }
     active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), P->active_sonly.as<uint32_t>(), P->tri.as<uint8_t>(), P->active_lean.as<uint32_t>(), P->active_tri.as<uint32_t>(), counters);
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[2], P->band_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[3], P->sign_off.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[4], counters + 1, 24, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&P->h_pinned[14], counters + 10, 8, hipMemcpyDeviceToHost, st));
+    rb2.add(P->band_off.as<uint32_t>() + ntiles, 1, 2);
+    rb2.add(P->sign_off.as<uint32_t>() + ntiles, 1, 3);
+    rb2.add(counters + 1, 6, 4);
+    rb2.add(counters + 10, 2, 14);
+    read_back_kernel<<<1, 64, 0, st>>>(rb2, P->d_pinned);
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_band = P->h_pinned[2], n_sign = P->h_pinned[3], n_active = P->h_pinned[4],
                    n_active_sign = P->h_pinned[5];
@@ -1975,8 +2030,11 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
             HIP_TRY(hipEventRecord(P->ev[7], st));
             if (want_dist && n_chunks) {
-                const uint32_t group = 4, ngroups = (n_chunks + group - 1) / group;   // chunks per fetch (1-8: +-2 %)
                 const uint32_t resident = (uint32_t)P->n_cu * 4u * 3u;   // CUs x SIMDs x waves/SIMD of this kernel
+                // chunks per fetch: 4 when every wavefront gets dozens of them (1-8: +-2 %), fewer for a small share of
+                // the grid (one rank of 4 / 8), where coarse groups leave wavefronts unevenly loaded (-15 % at 13 chunks/wave)
+                const uint32_t group = std::min(4u, std::max(1u, n_chunks / (resident * 12u)));
+                const uint32_t ngroups = (n_chunks + group - 1) / group;
                 HIP_TRY(hipMemsetAsync(counters + 8, 0, 4, st));
                 iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
                     P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
