@@ -808,6 +808,9 @@ struct IsoElemLds {
     double X[8][3];
 };
 #define R2S_ISO_SLOTS 4
+#ifndef R2S_ISO_QP2_MIN
+#define R2S_ISO_QP2_MIN 24
+#endif
 #ifdef R2S_ISO_STATS   // diagnostic build only (tools/iso_phase_stats.py): visits and active lanes per phase
 __device__ unsigned long long g_iso_stats[32];   // [16..31]: histogram of SQP iterations / 4
 #define ISO_STAT(p, cond)                                                                  \
@@ -953,6 +956,12 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
             if (s.phase == ISO_EVAL) iso_lane_eval(E, rho_t, s);
             ISO_STAT(1, s.phase == ISO_QP)
             if (s.phase == ISO_QP) iso_lane_qp(s);
+            // lanes whose active set changed need another pattern: worth a second visit in this trip only when
+            // many of them do (23 % on average; an unconditional second visit costs what it saves)
+            if (__popcll(__ballot(s.phase == ISO_QP)) >= R2S_ISO_QP2_MIN) {
+                ISO_STAT(7, s.phase == ISO_QP)
+                if (s.phase == ISO_QP) iso_lane_qp(s);
+            }
             ISO_STAT(2, s.phase == ISO_POST)
             if (s.phase == ISO_POST) iso_lane_post(s);
             ISO_STAT(3, s.phase == ISO_LS)

@@ -20,6 +20,12 @@ dX, dI, dR = (torch.from_numpy(t).to(dev) for t in (X, IEN, rn))
 out = torch.empty(g.ngp, dtype=torch.float64, device=dev)
 plan = pkg.DevicePlan(0)
 for mode in a.modes.split(","):
+    import time
+    st = plan.run(dX, dI, dR, 0.5, g, **{mode: out})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for r in range(a.reps):
         st = plan.run(dX, dI, dR, 0.5, g, **{mode: out})
+    torch.cuda.synchronize()
+    st["ms_wall_avg"] = (time.perf_counter() - t0) / a.reps * 1e3
     print(mode, json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}))
