@@ -33,25 +33,66 @@ ALG_BYTES_PER_VOXEL = 8.0      # one Float64 store per voxel; +
 DOMINANT_KERNEL = "iso_project_hex_pl_kernel"
 
 
-def cpu_baseline(X, IEN, rho_n, rho_t, n_max, stride):
-    """The oracle (CPU restatement, kind "port") on a bounded sample of the SAME workload:
-    every `stride`-th Z plane of the same grid over the same mesh, one thread."""
+def _oracle_planes(X, IEN, rho_n, rho_t, n_max, stride, phase):
+    """the oracle on the Z planes k % stride == phase of the grid (one thread); returns (seconds, sdf of those planes)"""
     O = graft.load_oracle()
     og = O.grid_make(X.min(0), X.max(0), n_max, 3)
-    O.set_k_sampling(stride, 0)
+    O.set_k_sampling(stride, phase)
     t0 = time.perf_counter()
     dist, _, st = O.eval_distances(X, IEN, rho_n, rho_t, og, 1.1, want_xp=False)
     sign = O.sign_detection(X, IEN, rho_n, rho_t, og)
-    sdf = dist * sign
+    nx, ny, nz = og.dims
+    sdf = dist.reshape(nz, ny, nx)[phase::stride] * sign.reshape(nz, ny, nx)[phase::stride]   # RhoToSDF.jl:171
     dt = time.perf_counter() - t0
     O.set_k_sampling(1, 0)
-    nx, ny, nz = og.dims
-    planes = len(range(0, nz, stride))
+    return dt, sdf, og.dims
+
+
+def cpu_worker(args):
+    """child process of cpu_baseline (never touches torch or the GPU): one phase of the plane sample"""
+    graft.load_package()
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, rho_n = synthetic.hex_mesh(args.mesh)
+    n_max = synthetic.grid_n_max_for_points(args.grid)
+    dt, sdf, dims = _oracle_planes(X, IEN, rho_n, 0.5, n_max, args.cpu_stride, args.cpu_worker)
+    nx, ny, nz = dims
+    if args.cpu_save:
+        np.save(args.cpu_save, sdf)
+    print(json.dumps({"seconds": dt, "planes": len(range(args.cpu_worker, nz, args.cpu_stride)), "dims": [nx, ny, nz]}))
+
+
+def cpu_baseline(args, threads):
+    """The oracle (CPU restatement, kind "port") on a bounded sample of the SAME workload, on `threads` host
+    cores: worker w (its own process, one thread) computes the Z planes k % stride == w of the same grid over
+    the same mesh - the reference's threading is also a static split of independent work with a merge at the
+    end (sdfOnDensityField.jl:183-184, 457-461).  Throughput = sampled voxels / slowest worker's oracle time.
+    Returns (record, sdf planes of worker 0 = planes [::stride])."""
+    import subprocess
+    import tempfile
+    threads = max(1, min(threads, args.cpu_stride))
+    with tempfile.TemporaryDirectory() as tmp:
+        save = os.path.join(tmp, "planes0.npy")
+        base = [sys.executable, os.path.abspath(__file__), "--grid", str(args.grid), "--mesh", str(args.mesh),
+                "--cpu-stride", str(args.cpu_stride)]
+        procs = [subprocess.Popen(base + ["--cpu-worker", str(w)] + (["--cpu-save", save] if w == 0 else []),
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for w in range(threads)]
+        outs = []
+        for p in procs:
+            o, e = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError("cpu baseline worker failed: " + e[-400:])
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+        ref = np.load(save)
+    nx, ny, nz = outs[0]["dims"]
+    planes = sum(o["planes"] for o in outs)
     nvox = planes * nx * ny
-    return {"value": nvox / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-            "sample": f"every {stride}th Z plane ({planes} of {nz} planes, {nvox} voxels) of the same "
-                      f"{nx}x{ny}x{nz} grid over the same mesh; {dt:.1f} s single thread",
-            "seconds": dt}, sdf
+    dt = max(o["seconds"] for o in outs)
+    cpu_s = sum(o["seconds"] for o in outs)
+    return {"value": nvox / dt / 1e6, "unit": "Mvoxels/s", "cores": threads, "kind": "port",
+            "sample": f"{planes} of {nz} Z planes ({nvox} voxels; plane k belongs to worker k % {args.cpu_stride}, "
+                      f"workers 0..{threads - 1}) of the same {nx}x{ny}x{nz} grid over the same mesh; {threads} "
+                      f"single-thread processes, slowest {dt:.1f} s, {cpu_s:.0f} s of CPU work in all",
+            "seconds": dt}, ref
 
 
 def main():
@@ -61,7 +102,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=512, help="grid points per axis (512 = north star)")
     ap.add_argument("--mesh", type=int, default=46, help="HEX8 cells per axis (46 -> 97 336 elements)")
-    ap.add_argument("--cpu-stride", type=int, default=16, help="CPU baseline samples every n-th Z plane")
+    ap.add_argument("--cpu-stride", type=int, default=32, help="CPU baseline: worker w takes the Z planes k %% stride == w")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline processes (0: host cores available, at most 16)")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-save", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare the sampled planes with the oracle")
     ap.add_argument("--partition", choices=["interleaved", "contiguous"], default="interleaved",
@@ -70,6 +114,8 @@ def main():
                     help="N > 1: all-gather only the non-sentinel 4x4x4 tiles (sparse, interleaved partition) "
                          "or the whole Float64 volume (dense)")
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        return cpu_worker(args)
 
     import torch
     import torch.distributed as dist
@@ -205,12 +251,13 @@ def main():
             "work": {k: int(st0[k]) for k in ("n_items", "n_band_entries", "n_sign_entries", "n_tiles", "n_active_tiles", "n_active_sign_tiles")},
         }
         if (world == 1 and not args.no_cpu_baseline) or args.check:
-            cb, ref = cpu_baseline(X, IEN, rho_n, rho_t, n_max, args.cpu_stride)
+            threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+            cb, ref = cpu_baseline(args, threads)
             if world == 1:
                 out["cpu_baseline"] = cb      # timed on rank 0 at N = 1 only
             if args.check:
                 got = sg.volume()[::args.cpu_stride].cpu().numpy().ravel()
-                want = ref.reshape(nz, ny, nx)[::args.cpu_stride].ravel()
+                want = ref.ravel()
                 sent = np.abs(want) > 1e9
                 real = ~sent
                 rel = np.abs(got[real] - want[real]) / np.maximum(np.abs(want[real]), 1e-300)

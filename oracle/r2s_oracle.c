@@ -951,16 +951,17 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
     c.next = (int64_t *)malloc(sizeof(int64_t) * (size_t)ngp);
     c.dist = dist_out;
     c.xp = xp_out; /* may be NULL: projection points not requested */
-    for (int64_t i = 0; i < ngp; ++i) { c.head[i] = -1; c.next[i] = -1; c.dist[i] = BIG; }
+    /* next[v] is written below for every listed point and only ever reached through head[] */
+    for (int64_t i = 0; i < ngp; ++i) { c.head[i] = -1; c.dist[i] = BIG; }
     if (xp_out) memset(xp_out, 0, sizeof(double) * 3 * (size_t)ngp);
     /* LinkedList (Grid.jl:47-68) */
     {
         int64_t v = 0;
-        for (int64_t k = 0; k <= g->N[2]; ++k)
+        for (int64_t k = 0; k <= g->N[2]; ++k) {
+          if (k % g_kstride != g_kphase) { v += (g->N[0] + 1) * (g->N[1] + 1); continue; } /* plane not sampled */
           for (int64_t j = 0; j <= g->N[1]; ++j)
             for (int64_t i = 0; i <= g->N[0]; ++i, ++v) {
                 double p[3];
-                if (k % g_kstride != g_kphase) continue;
                 grid_point(g, i, j, k, p);
                 double I1 = cell_of(g, 0, p[0]), I2 = cell_of(g, 1, p[1]), I3 = cell_of(g, 2, p[2]);
                 int64_t Ia = (int64_t)(I3 * (double)(g->N[0] + 1) * (double)(g->N[1] + 1) +
@@ -968,6 +969,7 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
                 c.next[v] = c.head[Ia];
                 c.head[Ia] = v;
             }
+        }
     }
     int64_t n_solid = 0, n_iso = 0;
     for (int64_t el = 0; el < nel; ++el) {
@@ -1115,7 +1117,11 @@ int orc_sign_detection(const double *X, int64_t nnp, const int64_t *IEN, int64_t
     double *cmax = (double *)malloc(sizeof(double) * (size_t)ngp);
     double *mloc = (double *)malloc(sizeof(double) * (size_t)ngp);
     unsigned char *flag = (unsigned char *)calloc((size_t)ngp, 1); /* bit0 any, bit1 done */
-    for (int64_t v = 0; v < ngp; ++v) { signs[v] = -1.0; cmax[v] = -INFINITY; mloc[v] = 10.0; }
+    for (int64_t v = 0; v < ngp; ++v) signs[v] = -1.0;
+    for (int64_t k = 0; k <= g->N[2]; ++k) { /* work arrays: only the sampled planes are ever touched */
+        if (k % g_kstride != g_kphase) continue;
+        for (int64_t v = k * nx * ny; v < (k + 1) * nx * ny; ++v) { cmax[v] = -INFINITY; mloc[v] = 10.0; }
+    }
     for (int pass = 0; pass < 2; ++pass)
         for (int64_t el = 0; el < nel; ++el) {
             double Xe[16][3], re[16], mn[3], mx[3], rmax;
