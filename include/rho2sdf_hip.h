@@ -218,6 +218,25 @@ int r2s_export_vti(const char *filename, const r2s_grid *grid, const void *value
 int r2s_export_vtu(const char *filename, const double *X, int64_t nnp, const int64_t *IEN, int64_t nel,
                    int32_t nen, int32_t vtk_code, const double *rho_n);
 
+/* import_vtu_mesh(vtu_file) -> (X, IEN, rho)                         src/DataImport/VTUImport.jl:22-112
+ * Mesh of an ASCII UnstructuredGrid file: hexahedra (VTK type 12, 8 nodes) or tetrahedra (10, 4 nodes), other
+ * cells are skipped and counted; IEN comes back 1-based.  Element densities (:117-226): the first cell-data
+ * field named density / rho / volfrac / ... (the reference's list), else the first cell-data field, else 1.0;
+ * taken by position, padded with 1.0.  The arrays are malloc'ed by the library: release them with
+ * r2s_free_vtu_mesh.  Binary / appended files (which the reference reads through ReadVTK) are refused. */
+typedef struct r2s_vtu_mesh {
+    int64_t nnp, nel;
+    int32_t nen;         /* 8 or 4 */
+    int32_t elem_type;   /* R2S_HEX8 / R2S_TET4 */
+    int64_t n_skipped;   /* cells of other types */
+    double *X;           /* [nnp][3] */
+    int64_t *IEN;        /* [nel][nen], 1-based */
+    double *rho;         /* [nel] */
+    char density_field[64]; /* cell-data field the densities came from ("" = default 1.0) */
+} r2s_vtu_mesh;
+int r2s_import_vtu(const char *filename, r2s_vtu_mesh *out);
+void r2s_free_vtu_mesh(r2s_vtu_mesh *mesh);
+
 /* frees the process-wide work buffers the library keeps between calls (the materialised RBF matrix of the CG:
  * up to a quarter of the device memory, see r2s_post.hip) */
 void r2s_release_cache(void);

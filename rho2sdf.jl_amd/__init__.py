@@ -7,10 +7,10 @@ itself as module `rho2sdf_jl_amd`.
 from . import _lib
 from .api import (DenseInNodes, DevicePlan, Grid, Mesh, RBFs_smoothing, Rho2sdfOptions, Sign_Detection,
                   calculate_mesh_volume, calculate_volume_from_sdf, evalDistances, find_threshold_for_volume,
-                  exportSdfToVTI, exportToVTU, export_sdf_results, getMesh_AABB, noninteractive_sdf_grid_setup,
+                  exportSdfToVTI, exportToVTU, export_sdf_results, getMesh_AABB, import_vtu_mesh, noninteractive_sdf_grid_setup,
                   remove_sdf_artifacts, rho2sdf, sdf_fused)
 
 __all__ = ["DenseInNodes", "DevicePlan", "Grid", "Mesh", "RBFs_smoothing", "Rho2sdfOptions", "Sign_Detection",
            "calculate_mesh_volume", "calculate_volume_from_sdf", "evalDistances", "find_threshold_for_volume",
-           "exportSdfToVTI", "exportToVTU", "export_sdf_results", "getMesh_AABB", "noninteractive_sdf_grid_setup", "remove_sdf_artifacts",
+           "exportSdfToVTI", "exportToVTU", "export_sdf_results", "getMesh_AABB", "import_vtu_mesh", "noninteractive_sdf_grid_setup", "remove_sdf_artifacts",
            "rho2sdf", "sdf_fused", "_lib"]

@@ -41,6 +41,12 @@ class R2SStats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class R2SVtuMesh(ctypes.Structure):
+    _fields_ = [("nnp", ctypes.c_int64), ("nel", ctypes.c_int64), ("nen", ctypes.c_int32),
+                ("elem_type", ctypes.c_int32), ("n_skipped", ctypes.c_int64), ("X", c_double_p),
+                ("IEN", c_int64_p), ("rho", c_double_p), ("density_field", ctypes.c_char * 64)]
+
+
 # every symbol include/rho2sdf_hip.h declares: (name, restype, argtypes)
 _P = ctypes.c_void_p
 _MESH = [c_double_p, ctypes.c_int64, c_int64_p, ctypes.c_int64]
@@ -83,6 +89,8 @@ SYMBOLS = [
                                       ctypes.POINTER(ctypes.c_int32), c_float_p]),
     ("r2s_release_cache", None, []),
     ("r2s_export_vtu", ctypes.c_int, [ctypes.c_char_p] + _MESH + [ctypes.c_int32, ctypes.c_int32, c_double_p]),
+    ("r2s_import_vtu", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(R2SVtuMesh)]),
+    ("r2s_free_vtu_mesh", None, [ctypes.POINTER(R2SVtuMesh)]),
     ("r2s_export_vti", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(R2SGrid), _P, ctypes.c_int32, ctypes.c_int64,
                                       ctypes.c_char_p, ctypes.c_int32]),
     ("r2s_rbf_smooth_dev", ctypes.c_int, [_P, ctypes.POINTER(R2SGrid), ctypes.c_int32, ctypes.c_int32, ctypes.c_double,

@@ -344,6 +344,24 @@ def exportToVTU(fileName, X, IEN, VTK_CODE=None, rho=None):
     return str(fileName)
 
 
+def import_vtu_mesh(vtu_file, info=None):
+    """import_vtu_mesh(vtu_file) -> (X, IEN, rho)   (src/DataImport/VTUImport.jl:22-112)
+    X (nnp, 3) Float64, IEN (nel, nen) Int64 1-based, rho (nel,) element densities.  ASCII .vtu only.
+    `info` (a dict) receives element_type, n_skipped and the cell-data field the densities came from."""
+    m = L.R2SVtuMesh()
+    L.check(L.lib().r2s_import_vtu(str(vtu_file).encode(), ctypes.byref(m)))
+    try:
+        X = np.ctypeslib.as_array(m.X, shape=(m.nnp, 3)).copy()
+        IEN = np.ctypeslib.as_array(m.IEN, shape=(m.nel, m.nen)).copy()
+        rho = np.ctypeslib.as_array(m.rho, shape=(m.nel,)).copy()
+        if info is not None:
+            info.update(element_type=int(m.elem_type), n_skipped=int(m.n_skipped),
+                        density_field=m.density_field.decode())
+    finally:
+        L.lib().r2s_free_vtu_mesh(ctypes.byref(m))
+    return X, IEN, rho
+
+
 def export_sdf_results(fine_sdf, sdf_grid, taskName, smooth, is_interpolation, element_type):
     """export_sdf_results_with_element_type (src/RhoToSDF.jl:249-283), the .vti part: same file name
     `<task>_<HEX8|TET4>_B-<round(cell,4)>_smooth-<s>_<Interpolation|Approximation>.vti`, point array "distance".

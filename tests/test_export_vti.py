@@ -6,6 +6,8 @@ import re
 import numpy as np
 import pytest
 
+from conftest import load_fixture
+
 
 def _read_vti(path):
     raw = open(path, "rb").read()
@@ -75,3 +77,71 @@ def test_vtu_round_trip(pkg, tmp_path):
     assert np.array_equal(pts, Xz) and np.array_equal(conn, IEN - 1)
     assert np.array_equal(offs, 8 * np.arange(1, len(IEN) + 1)) and np.all(types == 12)
     assert np.array_equal(dens, rn) and 'Name="density"' in txt
+
+
+def _vtu(points, conn, offsets, types, cell_data="", fmt="ascii"):
+    pts = "\n".join(" ".join(repr(float(v)) for v in p) for p in points)
+    return f"""<?xml version="1.0"?>
+<VTKFile type="UnstructuredGrid" version="0.1" byte_order="LittleEndian">
+  <UnstructuredGrid>
+    <Piece NumberOfPoints="{len(points)}" NumberOfCells="{len(types)}">
+      <Points>
+        <DataArray type="Float64" NumberOfComponents="3" format="{fmt}">
+{pts}
+        </DataArray>
+      </Points>
+      <Cells>
+        <DataArray type="Int64" Name="connectivity" format="ascii">{" ".join(map(str, conn))}</DataArray>
+        <DataArray type="Int64" Name="offsets" format="ascii">{" ".join(map(str, offsets))}</DataArray>
+        <DataArray type="UInt8" Name="types" format="ascii">{" ".join(map(str, types))}</DataArray>
+      </Cells>
+      {cell_data}
+    </Piece>
+  </UnstructuredGrid>
+</VTKFile>
+"""
+
+
+def test_vtu_import_round_trip(pkg, tmp_path):
+    """import_vtu_mesh (VTUImport.jl:22-112) reads back what exportToVTU wrote: same X, 1-based IEN; the file
+    holds no cell data, so the element densities default to 1.0 (:127-136)"""
+    X, IEN, rho = load_fixture("sphere")
+    path = pkg.exportToVTU(str(tmp_path / "sphere.vtu"), X, IEN, 12, np.linspace(0, 1, len(X)))
+    info = {}
+    X2, IEN2, rho2 = pkg.import_vtu_mesh(path, info)
+    assert np.array_equal(X2, X) and np.array_equal(IEN2, IEN) and IEN2.dtype == np.int64
+    assert np.array_equal(rho2, np.ones(len(IEN))) and info == {"element_type": 0, "n_skipped": 0, "density_field": ""}
+
+
+def test_vtu_import_cells_and_density_fields(pkg, tmp_path):
+    pts = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)]
+    # two tetrahedra, one triangle (type 5: skipped, VTUImport.jl:89-92); densities by position (:183-196)
+    conn, offs, types = [0, 1, 2, 3, 1, 2, 3, 4, 0, 1, 2], [4, 8, 11], [10, 10, 5]
+    cd = ('<CellData><DataArray type="Float64" Name="stress" format="ascii">9 9 9</DataArray>'
+          '<DataArray type="Float64" Name="volfrac" format="ascii">0.25 0.75 0.5</DataArray></CellData>')
+    p = tmp_path / "tets.vtu"
+    p.write_text(_vtu(pts, conn, offs, types, cd))
+    info = {}
+    X, IEN, rho = pkg.import_vtu_mesh(str(p), info)
+    assert X.shape == (5, 3) and np.array_equal(IEN, [[1, 2, 3, 4], [2, 3, 4, 5]])
+    assert np.array_equal(rho, [0.25, 0.75]) and info == {"element_type": 1, "n_skipped": 1, "density_field": "volfrac"}
+    # no usual name: the first field is used; too short: padded with 1.0
+    p.write_text(_vtu(pts, conn, offs, types, '<CellData><DataArray type="Float32" Name="stress" format="ascii">0.5</DataArray></CellData>'))
+    X, IEN, rho = pkg.import_vtu_mesh(str(p), info)
+    assert np.array_equal(rho, [0.5, 1.0]) and info["density_field"] == "stress"
+
+
+def test_vtu_import_errors(pkg, tmp_path):
+    with pytest.raises(pkg._lib.R2SError, match="VTU file not found"):             # VTUImport.jl:23-25
+        pkg.import_vtu_mesh(str(tmp_path / "missing.vtu"))
+    pts = [(0, 0, 0), (1, 0, 0), (0, 1, 0)]
+    p = tmp_path / "tri.vtu"
+    p.write_text(_vtu(pts, [0, 1, 2], [3], [5]))
+    with pytest.raises(pkg._lib.R2SError, match="No supported elements found"):   # :96-98
+        pkg.import_vtu_mesh(str(p))
+    p.write_text(_vtu(pts + [(0, 0, 1)], [0, 1, 2, 7], [4], [10]))
+    with pytest.raises(pkg._lib.R2SError, match="refers to point"):
+        pkg.import_vtu_mesh(str(p))
+    p.write_text(_vtu(pts + [(0, 0, 1)], [0, 1, 2, 3], [4], [10], fmt="binary"))
+    with pytest.raises(pkg._lib.R2SError, match="ASCII .vtu only"):
+        pkg.import_vtu_mesh(str(p))
