@@ -540,12 +540,18 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
         double sigma = 100.0 * trG / aa2;
         int use_exact = 1, corner = 0, stop = 0; (void)use_exact;
         double lam_new = lam, alpha = 1.0;
+        double dGd = 0.0; /* curvature of f along a corner step (penalty parameter below) */
         if (e >= mplus) {
             for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
             corner = 1;
         } else if (e <= mminus) {
             for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
             corner = 1;
+        }
+        if (corner) {
+            double Gd[3];
+            for (int i = 0; i < 3; ++i) Gd[i] = dot3(G[i][0], G[i][1], G[i][2], d[0], d[1], d[2]);
+            dGd = dot3(d[0], d[1], d[2], Gd[0], Gd[1], Gd[2]);
         } else {
             /* convexified QP data: H' = H + sigma a a^T, g' = g - sigma e a (identical to (H,g) on
              * the plane a.d = e).  Exact Lagrangian Hessian when H' is positive definite, else
@@ -562,7 +568,17 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
             H[0][1] += S[0]; H[1][0] = H[0][1];
             H[0][2] += S[1]; H[2][0] = H[0][2];
             H[1][2] += S[2]; H[2][1] = H[1][2];
-            if (!spd3(H, 0.0)) {
+            /* positive definite where the QP is going to be solved first: on the face of the box the last QP ended
+             * on (warm-start pattern).  Testing the whole 3x3 matrix sent iterates that sit on a face to the
+             * Gauss-Newton matrix although the exact one is definite along the face, and Gauss-Newton only converges
+             * linearly there (ratio ~ -0.9: 60 iterations and still 1e-5 away). */
+            double Hm[3][3];
+            {
+                const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) Hm[i][j] = (sp[i] || sp[j]) ? ((i == j) ? 1.0 : 0.0) : H[i][j];
+            }
+            if (!spd3(Hm, 0.0)) {
                 use_exact = 0;
                 for (int i = 0; i < 3; ++i)
                     for (int j = 0; j < 3; ++j) H[i][j] = Hgn[i][j];
@@ -575,6 +591,16 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
                 int p = pat;
                 for (int step = 0; step < 8 && p >= 0; ++step) {
                     int rc = qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt);
+                    if (rc == 0 && use_exact) {
+                        /* the walk left the warm-start face for one on which the exact matrix is not positive
+                         * definite: this iteration continues with Gauss-Newton, from the warm-start pattern */
+                        use_exact = 0;
+                        for (int i = 0; i < 3; ++i)
+                            for (int j = 0; j < 3; ++j) H[i][j] = Hgn[i][j];
+                        p = pat;
+                        step = -1;
+                        continue;
+                    }
                     if (rc == 0) break;
                     if (rc == 1 && kkt) {
                         found = 1;
@@ -624,6 +650,15 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
                 double pred_c = fabs(c) - fabs(c + ad);
                 double gd = dot3(g[0], g[1], g[2], d[0], d[1], d[2]);
                 double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
+                if (corner && pred_c > 0.0) {
+                    /* The linearised constraint cannot be met inside the trust region: the step only buys
+                     * feasibility, and the merit function has to pay for the growth of f it causes including its
+                     * curvature (mu >= (g.d + d.G.d / 2) / ((1 - 1/2) pred_c), Nocedal & Wright (18.36)).  With the
+                     * first-order part alone the line search cut such steps down to ~1e-3 and elements that the
+                     * iso-surface only clips near a corner ended the 60 iterations far from the surface. */
+                    const double need = 2.0 * fma(0.5, dGd, gd) / pred_c;
+                    if (need > mu_t) mu_t = need;
+                }
                 if (!(fma(-mu_t, pred_c, gd) < 0.0)) {
                     if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
                     else stop = 2; /* no descent on the merit function */

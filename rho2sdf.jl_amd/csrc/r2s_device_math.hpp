@@ -478,11 +478,23 @@ enum { ISO_IDLE = 0, ISO_EVAL, ISO_QP, ISO_POST, ISO_LS, ISO_UPD, ISO_DONE };
 struct IsoLane {
     double x[3];
     double xi[3], mu, Delta;
-    double H[3][3], gp[3], a[3], g[3], lo[3], hi[3], d[3];
+    double H[3][3], a[3], g[3], d[3];
+    double se;   // sigma * e: the QP gradient g - se * a and the step bounds are rebuilt where they are needed
+                 // (a handful of operations) instead of occupying 16 registers between the phases
     double e, f, c, lam_new, alpha, D, phi0, bestq;
     int pat, it, p, step, ip, ls, stop, phase;
     bool corner, found, fb;
 };
+
+// step bounds of the current iterate: the box |xi| <= 1 cut with the trust region
+R2S_DEV void iso_lane_bounds(const IsoLane& s, double lo[3], double hi[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        lo[i] = fmax(-1.0 - s.xi[i], -s.Delta);
+        hi[i] = fmin(1.0 - s.xi[i], s.Delta);
+    }
+}
 
 R2S_DEV void iso_lane_start(IsoLane& s, const double x[3])
 {
@@ -531,16 +543,13 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
         for (int q = 0; q < 3; ++q)
             S[q] = fma(lam, mr[q], -2.0 * dot3(r[0], r[1], r[2], M2[0][q], M2[1][q], M2[2][q]));
     }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        s.lo[i] = fmax(-1.0 - s.xi[i], -s.Delta);
-        s.hi[i] = fmin(1.0 - s.xi[i], s.Delta);
-    }
+    double lo[3], hi[3];
+    iso_lane_bounds(s, lo, hi);
     const double e = -c;
     double mplus = 0.0, mminus = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        double p = s.a[i] * s.lo[i], q = s.a[i] * s.hi[i];
+        double p = s.a[i] * lo[i], q = s.a[i] * hi[i];
         mplus += fmax(p, q);
         mminus += fmin(p, q);
     }
@@ -554,23 +563,30 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
     s.e = e; s.f = f; s.c = c;
     if (e >= mplus) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? s.hi[i] : ((s.a[i] < 0.0) ? s.lo[i] : 0.0);
+        for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0);
         s.corner = true;
-        s.phase = ISO_POST;
     } else if (e <= mminus) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? s.lo[i] : ((s.a[i] < 0.0) ? s.hi[i] : 0.0);
+        for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? lo[i] : ((s.a[i] < 0.0) ? hi[i] : 0.0);
         s.corner = true;
+    }
+    if (s.corner) {
+        // curvature of f along the corner step, for the penalty parameter (iso_lane_post); bestq is free here
+        double Gd[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Gd[i] = dot3(G[i][0], G[i][1], G[i][2], s.d[0], s.d[1], s.d[2]);
+        s.bestq = dot3(s.d[0], s.d[1], s.d[2], Gd[0], Gd[1], Gd[2]);
         s.phase = ISO_POST;
     } else {
         double Hgn[3][3];   // Gauss-Newton + sigma a a^T (symmetric by construction, like H)
         const double se = sigma * e;
+        s.se = se;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double sa = sigma * s.a[i];
 #pragma unroll
             for (int j = i; j < 3; ++j) Hgn[i][j] = Hgn[j][i] = fma(sa, s.a[j], G[i][j]);
-            s.gp[i] = fma(-se, s.a[i], s.g[i]);
+
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -579,7 +595,21 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
         s.H[0][1] += S[0]; s.H[1][0] = s.H[0][1];
         s.H[0][2] += S[1]; s.H[2][0] = s.H[0][2];
         s.H[1][2] += S[2]; s.H[2][1] = s.H[1][2];
-        if (!spd3(s.H)) {
+        // positive definite on the face of the box the last QP ended on (warm-start pattern) - see the oracle
+        double Hm[3][3];
+        {
+            const int sp[3] = {s.pat % 3, (s.pat / 3) % 3, s.pat / 9};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Hm[i][j] = (sp[i] || sp[j]) ? ((i == j) ? 1.0 : 0.0) : s.H[i][j];
+        }
+        // While the active-set walk runs with the exact matrix (ip = 1), the off-diagonals of the Gauss-Newton
+        // matrix wait in D, phi0 and lam_new: those three are dead between EVAL and the end of the walk (POST
+        // writes D and phi0, the QP writes lam_new when it is done) and the state has no registers to spare.
+        s.ip = spd3(Hm) ? 1 : 0;
+        s.D = Hgn[0][1]; s.phi0 = Hgn[0][2]; s.lam_new = Hgn[1][2];
+        if (!s.ip) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -597,7 +627,11 @@ R2S_DEV void iso_lane_qp(IsoLane& s)
 {
     QpOut o;
     const int p = s.fb ? c_pat_order[s.ip] : s.p;
-    const int rc = qp_pattern(p, s.H, s.gp, s.a, s.e, s.lo, s.hi, o);
+    double lo[3], hi[3], gp[3];
+    iso_lane_bounds(s, lo, hi);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gp[i] = fma(-s.se, s.a[i], s.g[i]);
+    const int rc = qp_pattern(p, s.H, gp, s.a, s.e, lo, hi, o);
     bool done = false;
     if (!s.fb) {
         // active-set walk: the first primal feasible KKT pattern is the minimiser
@@ -607,6 +641,15 @@ R2S_DEV void iso_lane_qp(IsoLane& s)
             s.d[0] = o.d[0]; s.d[1] = o.d[1]; s.d[2] = o.d[2];
             s.lam_new = o.lam;
             done = true;
+        } else if (rc == 0 && s.ip) {
+            // the walk left the warm-start face for one on which the exact matrix is not positive definite: this
+            // iteration continues with Gauss-Newton (same diagonal), from the warm-start pattern
+            s.ip = 0;
+            s.H[0][1] = s.H[1][0] = s.D;
+            s.H[0][2] = s.H[2][0] = s.phi0;
+            s.H[1][2] = s.H[2][1] = s.lam_new;
+            s.p = s.pat;
+            s.step = 0;
         } else {
             bool to_fb = (rc == 0);
             if (!to_fb) {
@@ -635,12 +678,13 @@ R2S_DEV void iso_lane_qp(IsoLane& s)
         if (!s.found) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                s.d[i] = (s.e > 0.0) ? ((s.a[i] > 0.0) ? s.hi[i] : ((s.a[i] < 0.0) ? s.lo[i] : 0.0))
-                                     : ((s.a[i] > 0.0) ? s.lo[i] : ((s.a[i] < 0.0) ? s.hi[i] : 0.0));
+                s.d[i] = (s.e > 0.0) ? ((s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0))
+                                     : ((s.a[i] > 0.0) ? lo[i] : ((s.a[i] < 0.0) ? hi[i] : 0.0));
             s.corner = true;
+            s.bestq = 0.0;   // (numerically degenerate QP: the penalty rule of corner steps without its curvature term)
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) s.d[i] = fmin(fmax(s.d[i], s.lo[i]), s.hi[i]);
+        for (int i = 0; i < 3; ++i) s.d[i] = fmin(fmax(s.d[i], lo[i]), hi[i]);
         s.phase = ISO_POST;
     }
 }
@@ -655,6 +699,11 @@ R2S_DEV void iso_lane_post(IsoLane& s)
         const double pred_c = fabs(s.c) - fabs(s.c + ad);
         const double gd = dot3(s.g[0], s.g[1], s.g[2], s.d[0], s.d[1], s.d[2]);
         double mu_t = s.corner ? s.mu : fmax(0.5 * s.mu, 2.0 * fabs(s.lam_new));
+        if (s.corner && pred_c > 0.0) {
+            // a step that only buys feasibility: the merit function pays for the growth of f including its curvature
+            const double need = 2.0 * fma(0.5, s.bestq, gd) / pred_c;
+            if (need > mu_t) mu_t = need;
+        }
         if (!(fma(-mu_t, pred_c, gd) < 0.0)) {
             if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
             else s.stop = 2;

@@ -412,7 +412,7 @@ __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, con
                                   const uint32_t* __restrict__ fmask, const uint32_t* __restrict__ item_off,
                                   int64_t nel, GridDev g, SlabInfo sl, double delta,
                                   BandItem* __restrict__ items, uint32_t* __restrict__ nchunks,
-                                  uint32_t* __restrict__ nstore)
+                                  uint32_t* __restrict__ nstore, uint8_t* __restrict__ hard, double rho_t)
 {
     int64_t el = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nel) return;
@@ -543,8 +543,42 @@ __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, con
             const TileBox tb = tile_box(T.lo, T.dim);
             nstore[w] = vol ? (uint32_t)(tb.td[0] * tb.td[1] * tb.td[2]) : 0u;
         }
+        if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
+            // iso-surface close to a node: the elements it only clips near a corner or follows along a face, where the
+            // SQP needs tens of iterations - they go first in the work order (work_order_kernel)
+            double dmin = INFINITY;
+            for (int k = 0; k < 8; ++k) dmin = fmin(dmin, fabs(E.r[k] - rho_t));
+            hard[w] = dmin < 0.1 * (E.rmax - E.rmin) ? 1 : 0;
+        }
         items[w++] = T;
     }
+}
+
+// Work order of the persistent projection kernel (HEX8): items whose iso-surface passes close to a node come
+// first.  Those are the elements the surface only clips near a corner or follows along a face, and that is where
+// the SQP needs tens of iterations (degenerate or nearly infeasible sub-problems) instead of four.  A lane works
+// through such a voxel alone, so when one of them is handed out near the end of the kernel everything waits for
+// it (the drain phase used to be a quarter of the kernel's run time); handed out first, it finishes in the
+// shadow of the bulk.  One block; the order inside the two classes is whatever the atomics give - it has no
+// influence on the results (every pair writes its own slot).
+__global__ void __launch_bounds__(1024) work_order_kernel(const uint8_t* __restrict__ hard, const uint32_t* __restrict__ nchunks,
+                                                          uint32_t nitems, uint32_t* __restrict__ perm,
+                                                          uint32_t* __restrict__ wchunks)
+{
+    __shared__ uint32_t n_hard, c_hard, c_easy;
+    if (threadIdx.x == 0) { n_hard = 0; c_hard = 0; c_easy = 0; }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t it = threadIdx.x; it < nitems; it += blockDim.x) mine += hard[it] ? 1u : 0u;
+    if (mine) atomicAdd(&n_hard, mine);
+    __syncthreads();
+    const uint32_t nh = n_hard;
+    for (uint32_t it = threadIdx.x; it < nitems; it += blockDim.x) {
+        const uint32_t pos = hard[it] ? atomicAdd(&c_hard, 1u) : nh + atomicAdd(&c_easy, 1u);
+        perm[pos] = it;
+        wchunks[pos] = nchunks[it];
+    }
+    if (threadIdx.x == 0) wchunks[nitems] = 0;
 }
 
 // writes the scanned chunk offsets back into the items
@@ -811,8 +845,16 @@ struct IsoElemLds {
 #ifndef R2S_ISO_QP2_MIN
 #define R2S_ISO_QP2_MIN 24
 #endif
+#ifdef R2S_ISO_WAVE_END   // diagnostic build only (tools/iso_phase_stats.py): when the wavefronts of the kernel leave
+__device__ unsigned long long g_iso_wave_end[4096];   // wall_clock64 at the exit of every wavefront; [4094]: a start
+extern "C" int r2s_debug_iso_wave_end(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iso_wave_end), sizeof(unsigned long long) * 4096) != hipSuccess;
+}
+#endif
 #ifdef R2S_ISO_STATS   // diagnostic build only (tools/iso_phase_stats.py): visits and active lanes per phase
-__device__ unsigned long long g_iso_stats[32];   // [16..31]: histogram of SQP iterations / 4
+__device__ unsigned long long g_iso_stats[56];   // [0..15] ISO_STAT pairs, [16..31] histogram of SQP iterations / 4,
+                                                 // [32..47] of log2(trips of a pair), [48..51] sums over pairs with >= 128 trips
 #define ISO_STAT(p, cond)                                                                  \
     {                                                                                      \
         const uint64_t m__ = __ballot(cond);                                               \
@@ -821,11 +863,18 @@ __device__ unsigned long long g_iso_stats[32];   // [16..31]: histogram of SQP i
             atomicAdd(&g_iso_stats[2 * (p) + 1], (unsigned long long)__popcll(m__));       \
         }                                                                                  \
     }
+__device__ unsigned long long g_iso_long[8 * 64];   // [0] count; 8 words per long-running pair
+extern "C" int r2s_debug_iso_long(unsigned long long* out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iso_long), sizeof(unsigned long long) * 8 * 64) != hipSuccess) return 1;
+    unsigned long long z[8 * 64] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_iso_long), z, sizeof z) != hipSuccess;
+}
 extern "C" int r2s_debug_iso_stats(unsigned long long* out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iso_stats), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iso_stats), sizeof(unsigned long long) * 56) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[32] = {0};
+        unsigned long long z[56] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_iso_stats), z, sizeof z) != hipSuccess) return 1;
     }
     return 0;
@@ -836,10 +885,13 @@ extern "C" int r2s_debug_iso_stats(unsigned long long* out, int reset)
 __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
     const BandItem* __restrict__ items, uint32_t nitems, const uint32_t* __restrict__ chunk_off, uint32_t nchunks,
     uint32_t group, const ElemRec* __restrict__ erec, GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
-    double* __restrict__ res_xp, uint32_t* __restrict__ counter)
+    double* __restrict__ res_xp, uint32_t* __restrict__ counter, const uint32_t* __restrict__ perm)
 {
     __shared__ IsoElemLds slots[R2S_ISO_SLOTS];
     const uint32_t lane = threadIdx.x;
+#ifdef R2S_ISO_WAVE_END
+    if (lane == 0 && blockIdx.x == 1) g_iso_wave_end[4094] = wall_clock64();   // (about) the start of the kernel
+#endif
     // wave-uniform bookkeeping
     uint32_t c = 0, c_end = 0;        // rest of the fetched chunk group
     uint32_t it = 0, co = 0, cn = 0;  // newest item and its chunk range
@@ -852,6 +904,9 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
     // per lane
     IsoLane s;
     s.phase = ISO_IDLE;
+#ifdef R2S_ISO_STATS
+    int dbg_trips = 0, dbg_qp = 0, dbg_ls = 0, dbg_el = 0;
+#endif
     size_t my = 0;
     int eslot = 0;
 
@@ -863,6 +918,26 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
             if (s.phase == ISO_DONE) {
 #ifdef R2S_ISO_STATS
                 atomicAdd(&g_iso_stats[16 + (s.it / 4 > 15 ? 15 : s.it / 4)], 1ull);
+                atomicAdd(&g_iso_stats[32 + (31 - __clz(dbg_trips | 1))], 1ull);
+                if (dbg_trips >= 128) {   // who are they: element, voxel coordinates, iterations, trips of up to 63 of them
+                    const unsigned long long k = atomicAdd(&g_iso_long[0], 1ull);
+                    if (k < 63) {
+                        g_iso_long[8 * (k + 1) + 0] = (unsigned long long)dbg_el;
+                        g_iso_long[8 * (k + 1) + 1] = (unsigned long long)__double_as_longlong(s.x[0]);
+                        g_iso_long[8 * (k + 1) + 2] = (unsigned long long)__double_as_longlong(s.x[1]);
+                        g_iso_long[8 * (k + 1) + 3] = (unsigned long long)__double_as_longlong(s.x[2]);
+                        g_iso_long[8 * (k + 1) + 4] = (unsigned long long)s.it;
+                        g_iso_long[8 * (k + 1) + 5] = (unsigned long long)dbg_trips;
+                        g_iso_long[8 * (k + 1) + 6] = (unsigned long long)dbg_qp;
+                        g_iso_long[8 * (k + 1) + 7] = (unsigned long long)dbg_ls;
+                    }
+                }
+                if (dbg_trips >= 128) {   // the pairs behind the kernel's tail: where do their trips go?
+                    atomicAdd(&g_iso_stats[48], (unsigned long long)dbg_trips);
+                    atomicAdd(&g_iso_stats[49], (unsigned long long)dbg_qp);
+                    atomicAdd(&g_iso_stats[50], (unsigned long long)dbg_ls);
+                    atomicAdd(&g_iso_stats[51], (unsigned long long)s.it);
+                }
 #endif
                 const IsoElemLds& E = slots[eslot];
                 double N[8], xp[3];
@@ -907,7 +982,7 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
                             const uint32_t mid = (lo + hi) >> 1;
                             if (chunk_off[mid] <= c) lo = mid; else hi = mid;
                         }
-                        it = lo; co = chunk_off[lo]; cn = chunk_off[lo + 1];
+                        it = perm[lo]; co = chunk_off[lo]; cn = chunk_off[lo + 1];   // chunk_off is in work order
                         have_item = true;
                         const BandItem& T = items[it];
                         const double* src = reinterpret_cast<const double*>(&erec[T.el]);
@@ -941,19 +1016,31 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
                         x[1] = grid_coord(g, 1, j);
                         x[2] = grid_coord(g, 2, slab_global_k(sl, kl));
                         iso_lane_start(s, x);
+#ifdef R2S_ISO_STATS
+                        dbg_trips = 0; dbg_qp = 0; dbg_ls = 0; dbg_el = items[it].el;
+#endif
                         my = tile_slot(st_off, tb, i, j, kl);
                         eslot = cur_slot;
                     }
                 }
                 next += (uint32_t)__popcll(m_idle);
             }
-            if (exhausted && __ballot(s.phase != ISO_IDLE) == 0) break;
+            if (exhausted && __ballot(s.phase != ISO_IDLE) == 0) {
+#ifdef R2S_ISO_WAVE_END
+                if (lane == 0 && blockIdx.x < 4094) g_iso_wave_end[blockIdx.x] = wall_clock64();
+#endif
+                break;
+            }
         }
         // ---- one visit of each phase ----
         {
             const IsoElemLds& E = slots[eslot];
             ISO_STAT(0, s.phase == ISO_EVAL)
             if (s.phase == ISO_EVAL) iso_lane_eval(E, rho_t, s);
+#ifdef R2S_ISO_STATS
+            if (s.phase == ISO_QP) dbg_qp += 1;
+            if (s.phase == ISO_LS) dbg_ls += 1;
+#endif
             ISO_STAT(1, s.phase == ISO_QP)
             if (s.phase == ISO_QP) iso_lane_qp(s);
             // lanes whose active set changed need another pattern: worth a second visit in this trip only when
@@ -969,6 +1056,9 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
             ISO_STAT(4, s.phase == ISO_UPD)
             if (s.phase == ISO_UPD) iso_lane_update(s);
             ISO_STAT(5, true)
+#ifdef R2S_ISO_STATS
+            if (s.phase != ISO_IDLE) dbg_trips += 1;
+#endif
         }
     }
 }
@@ -1576,6 +1666,7 @@ struct r2s_plan {
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
     DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
+    DevBuf perm, wchunks, hardflag;   // work order of the persistent projection kernel (HEX8)
     DevBuf sbox, s_nchunks, s_chunk_off, sres;   // item-major inverse maps of the sign pass (HEX8)
     DevBuf nstore, store_off, s_nstore, s_store_off;   // storage (tile) chunk counts / offsets
     // state of the last run, for r2s_plan_pack_tiles_dev
@@ -1746,7 +1837,7 @@ void r2s_plan_destroy(r2s_plan* P)
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
                      &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any, &P->active_sonly, &P->active_lean, &P->active_tri, &P->tri,
                      &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp,
-                     &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres, &P->nstore, &P->store_off, &P->s_nstore, &P->s_store_off,
+                     &P->perm, &P->wchunks, &P->hardflag, &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres, &P->nstore, &P->store_off, &P->s_nstore, &P->s_store_off,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
     for (DevBuf* b : all) b->release();
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
@@ -1882,11 +1973,21 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->store_off, sizeof(uint32_t) * (size_t)(n_items + 1));
     ReadBack rb2;   // second read-back point (after the count passes)
     if (n_items) {
-        zero_many(st, {{P->nchunks.p, sizeof(uint32_t) * (size_t)(n_items + 1)}, {P->nstore.p, sizeof(uint32_t) * (size_t)(n_items + 1)}});
+        ENSURE(P->hardflag, (size_t)n_items + 1);
+        zero_many(st, {{P->nchunks.p, sizeof(uint32_t) * (size_t)(n_items + 1)}, {P->nstore.p, sizeof(uint32_t) * (size_t)(n_items + 1)},
+                       {P->hardflag.p, (size_t)n_items + 1}});
         item_build_kernel<ET><<<(unsigned)((nel + 63) / 64), 64, 0, st>>>(
             P->erec.as<typename ET::Rec>(), P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->item_off.as<uint32_t>(), nel,
-            g, s, delta, P->items.as<BandItem>(), P->nchunks.as<uint32_t>(), P->nstore.as<uint32_t>());
-        int rc = scan_exclusive2(P, P->nchunks.as<uint32_t>(), P->chunk_off.as<uint32_t>(), P->nstore.as<uint32_t>(),
+            g, s, delta, P->items.as<BandItem>(), P->nchunks.as<uint32_t>(), P->nstore.as<uint32_t>(), P->hardflag.as<uint8_t>(), rho_t);
+        const uint32_t* work_counts = P->nchunks.as<uint32_t>();
+        if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
+            ENSURE(P->perm, sizeof(uint32_t) * (size_t)n_items);
+            ENSURE(P->wchunks, sizeof(uint32_t) * (size_t)(n_items + 1));
+            work_order_kernel<<<1, 1024, 0, st>>>(P->hardflag.as<uint8_t>(), P->nchunks.as<uint32_t>(), n_items,
+                                                  P->perm.as<uint32_t>(), P->wchunks.as<uint32_t>());
+            work_counts = P->wchunks.as<uint32_t>();   // chunk_off then runs in work order (HEX8)
+        }
+        int rc = scan_exclusive2(P, work_counts, P->chunk_off.as<uint32_t>(), P->nstore.as<uint32_t>(),
                                  P->store_off.as<uint32_t>(), (int64_t)n_items + 1, st);
         if (rc) return rc;
         item_chunks_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(P->items.as<BandItem>(), P->chunk_off.as<uint32_t>(), P->store_off.as<uint32_t>(), n_items);
@@ -2047,7 +2148,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 HIP_TRY(hipMemsetAsync(counters + 8, 0, 4, st));
                 iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
                     P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
-                    s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, counters + 8);
+                    s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, counters + 8,
+                    P->perm.as<uint32_t>());
             }
             HIP_TRY(hipEventRecord(P->ev[6], st));
             if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[4], 0));   // (the sweep precedes it on that stream)

@@ -15,10 +15,14 @@ dX, dI, dR = (torch.from_numpy(t).to(dev) for t in (X, IEN, rn))
 out = torch.empty(g.ngp, dtype=torch.float64, device=dev)
 plan = pkg.DevicePlan(0)
 L = pkg._lib.lib()
-buf = (ctypes.c_ulonglong * 32)()
+buf = (ctypes.c_ulonglong * 56)()
 L.r2s_debug_iso_stats(buf, 1)
-st = plan.run(dX, dI, dR, 0.5, g, sdf=out)
-torch.cuda.synchronize()
+lng = (ctypes.c_ulonglong * 512)()
+for _ in range(3):   # the last run is the one reported (allocations and first touches are behind it)
+    L.r2s_debug_iso_stats(buf, 1)
+    L.r2s_debug_iso_long(lng)
+    st = plan.run(dX, dI, dR, 0.5, g, sdf=out)
+    torch.cuda.synchronize()
 L.r2s_debug_iso_stats(buf, 1)
 names = ["EVAL", "QP", "POST", "LS", "UPD", "trip", "finish"]
 for i, n in enumerate(names):
@@ -26,3 +30,12 @@ for i, n in enumerate(names):
     print(f"{n:7s} visits {v:10d} lanes {l:12d} util {l / max(1, 64 * v):.3f}")
 print("pairs (finished lanes)", buf[13], "chunks", st["n_iso_chunks"])
 print("iterations/4 histogram", [buf[16 + i] for i in range(16)])
+print("log2(trips per pair) histogram", [buf[32 + i] for i in range(16)])
+print("pairs with >= 128 trips: trips %d, QP visits %d (second visits of a trip not counted), LS visits %d, SQP iterations %d" % (buf[48], buf[49], buf[50], buf[51]))
+import struct
+L.r2s_debug_iso_long(lng)
+print("pairs with >= 256 trips:", lng[0])
+for k in range(min(int(lng[0]), 63)):
+    w = lng[8 * (k + 1): 8 * (k + 2)]
+    xyz = [struct.unpack("d", struct.pack("Q", v))[0] for v in w[1:4]]
+    print("LONG el %d x %.17g %.17g %.17g its %d trips %d qp %d ls %d" % (w[0], xyz[0], xyz[1], xyz[2], w[4], w[5], w[6], w[7]))
