@@ -481,7 +481,7 @@ struct IsoLane {
     double H[3][3], a[3], g[3], d[3];
     double se;   // sigma * e: the QP gradient g - se * a and the step bounds are rebuilt where they are needed
                  // (a handful of operations) instead of occupying 16 registers between the phases
-    double e, f, c, lam_new, alpha, D, phi0, bestq;
+    double f, c, lam_new, alpha, D, phi0, bestq;
     int pat, it, p, step, ip, ls, stop, phase;
     bool corner, found, fb;
 };
@@ -560,7 +560,7 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
     s.stop = 0;
     s.lam_new = lam;
     s.alpha = 1.0;
-    s.e = e; s.f = f; s.c = c;
+    s.f = f; s.c = c;   // (e = -c is rebuilt where the QP needs it)
     if (e >= mplus) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0);
@@ -631,7 +631,8 @@ R2S_DEV void iso_lane_qp(IsoLane& s)
     iso_lane_bounds(s, lo, hi);
 #pragma unroll
     for (int i = 0; i < 3; ++i) gp[i] = fma(-s.se, s.a[i], s.g[i]);
-    const int rc = qp_pattern(p, s.H, gp, s.a, s.e, lo, hi, o);
+    const double e = -s.c;
+    const int rc = qp_pattern(p, s.H, gp, s.a, e, lo, hi, o);
     bool done = false;
     if (!s.fb) {
         // active-set walk: the first primal feasible KKT pattern is the minimiser
@@ -678,7 +679,7 @@ R2S_DEV void iso_lane_qp(IsoLane& s)
         if (!s.found) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                s.d[i] = (s.e > 0.0) ? ((s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0))
+                s.d[i] = (e > 0.0) ? ((s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0))
                                      : ((s.a[i] > 0.0) ? lo[i] : ((s.a[i] < 0.0) ? hi[i] : 0.0));
             s.corner = true;
             s.bestq = 0.0;   // (numerically degenerate QP: the penalty rule of corner steps without its curvature term)

@@ -102,3 +102,25 @@ def test_iso_projection_vs_independent_slsqp(oracle):
         mine = np.linalg.norm(x - Xe.T @ N)
         worst = max(worst, abs(mine - dist) / max(dist, 1e-300))
     assert worst <= 1e-6, worst
+
+
+def test_iso_projection_on_hard_elements_vs_independent_slsqp(oracle):
+    """Elements of the north-star mesh whose iso-surface passes close to a node (corner clips, surfaces along a
+    face: nearly infeasible linearisations, degenerate reduced Hessians) - where the first version of the SQP left
+    pairs unconverged after 60 iterations.  600 pairs, none filtered by outcome, against scipy's Kraft SLSQP
+    (vectors + generator: tests/golden/make_slsqp_hard_vectors.py)."""
+    import os
+    from conftest import ROOT
+    d = np.load(os.path.join(ROOT, "tests", "golden", "slsqp_iso_projection_hard.npz"))
+    S = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float)
+    worst, n = 0.0, 0
+    for x, Xe, re, rt, dist, ok, c in zip(d["x"], d["Xe"], d["re"], d["rt"], d["dist"], d["success"], d["c"]):
+        if not ok or abs(c) > 1e-9:
+            continue          # SLSQP itself failed: nothing to compare with
+        xi, it = oracle.iso_project_hex8(x, Xe, re, float(rt))
+        assert it <= 60
+        N = 0.125 * np.prod(1 + S * xi, axis=1)
+        assert abs(re @ N - rt) < 1e-10
+        worst = max(worst, abs(np.linalg.norm(x - Xe.T @ N) - dist) / max(dist, 1e-300))
+        n += 1
+    assert n >= 590 and worst <= 1e-6, (n, worst)
