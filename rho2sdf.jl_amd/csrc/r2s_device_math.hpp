@@ -143,46 +143,41 @@ R2S_DEV void hex8_monomials(ElemRec& R)
 // product of the two in-face tangents at the face centre, oriented along s * dX/dxi_a; offset = max of
 // n.X over the 8 corners of the cube |xi| = 1.011 (a trilinear map takes the cube into the convex hull of
 // the corner images) plus a rounding margin.  Degenerate faces give n = 0 and never reject.
-R2S_DEV void hex8_planes(ElemRec& R)
+R2S_DEV void hex8_plane(const ElemRec& R, int a, int sg, double n[3], double& po)
 {
     const double lamb = 1.011;
     double ext = 0.0;
     for (int i = 0; i < 3; ++i) ext += R.mx[i] - R.mn[i];
-    for (int a = 0; a < 3; ++a) {
-        for (int sg = 0; sg < 2; ++sg) {
-            const double s = sg ? 1.0 : -1.0;
-            double xi[3] = {0.0, 0.0, 0.0};
-            xi[a] = s;
-            double J[3][3];   // J[i][q] = dX_i / dxi_q
-            for (int i = 0; i < 3; ++i) {
-                J[i][0] = R.C[1][i] + xi[1] * R.C[4][i] + xi[2] * R.C[5][i] + xi[1] * xi[2] * R.C[7][i];
-                J[i][1] = R.C[2][i] + xi[0] * R.C[4][i] + xi[2] * R.C[6][i] + xi[0] * xi[2] * R.C[7][i];
-                J[i][2] = R.C[3][i] + xi[0] * R.C[5][i] + xi[1] * R.C[6][i] + xi[0] * xi[1] * R.C[7][i];
-            }
-            const int b = (a + 1) % 3, c = (a + 2) % 3;
-            double n[3] = {J[1][b] * J[2][c] - J[2][b] * J[1][c], J[2][b] * J[0][c] - J[0][b] * J[2][c],
-                           J[0][b] * J[1][c] - J[1][b] * J[0][c]};
-            const double along = s * (n[0] * J[0][a] + n[1] * J[1][a] + n[2] * J[2][a]);
-            if (along < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-            if (!(along != 0.0)) { n[0] = n[1] = n[2] = 0.0; }   // degenerate or NaN: never rejects
-            double off = -INFINITY;
-            for (int k = 0; k < 8; ++k) {
-                const double s1 = (k & 1) ? lamb : -lamb, s2 = (k & 2) ? lamb : -lamb, s3 = (k & 4) ? lamb : -lamb;
-                double v = 0.0;
-                for (int i = 0; i < 3; ++i) {
-                    const double Xi = R.C[0][i] + s1 * R.C[1][i] + s2 * R.C[2][i] + s3 * R.C[3][i] +
-                                      s1 * s2 * R.C[4][i] + s1 * s3 * R.C[5][i] + s2 * s3 * R.C[6][i] +
-                                      s1 * s2 * s3 * R.C[7][i];
-                    v += n[i] * Xi;
-                }
-                off = fmax(off, v);
-            }
-            const double nn = fabs(n[0]) + fabs(n[1]) + fabs(n[2]);
-            const int f = 2 * a + sg;
-            R.pn[f][0] = n[0]; R.pn[f][1] = n[1]; R.pn[f][2] = n[2];
-            R.po[f] = off + 1e-9 * nn * ext;
-        }
+    const double s = sg ? 1.0 : -1.0;
+    double xi[3] = {0.0, 0.0, 0.0};
+    xi[a] = s;
+    double J[3][3];   // J[i][q] = dX_i / dxi_q
+    for (int i = 0; i < 3; ++i) {
+        J[i][0] = R.C[1][i] + xi[1] * R.C[4][i] + xi[2] * R.C[5][i] + xi[1] * xi[2] * R.C[7][i];
+        J[i][1] = R.C[2][i] + xi[0] * R.C[4][i] + xi[2] * R.C[6][i] + xi[0] * xi[2] * R.C[7][i];
+        J[i][2] = R.C[3][i] + xi[0] * R.C[5][i] + xi[1] * R.C[6][i] + xi[0] * xi[1] * R.C[7][i];
     }
+    const int b = (a + 1) % 3, c = (a + 2) % 3;
+    n[0] = J[1][b] * J[2][c] - J[2][b] * J[1][c];
+    n[1] = J[2][b] * J[0][c] - J[0][b] * J[2][c];
+    n[2] = J[0][b] * J[1][c] - J[1][b] * J[0][c];
+    const double along = s * (n[0] * J[0][a] + n[1] * J[1][a] + n[2] * J[2][a]);
+    if (along < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    if (!(along != 0.0)) { n[0] = n[1] = n[2] = 0.0; }   // degenerate or NaN: never rejects
+    double off = -INFINITY;
+    for (int k = 0; k < 8; ++k) {
+        const double s1 = (k & 1) ? lamb : -lamb, s2 = (k & 2) ? lamb : -lamb, s3 = (k & 4) ? lamb : -lamb;
+        double v = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const double Xi = R.C[0][i] + s1 * R.C[1][i] + s2 * R.C[2][i] + s3 * R.C[3][i] +
+                              s1 * s2 * R.C[4][i] + s1 * s3 * R.C[5][i] + s2 * s3 * R.C[6][i] +
+                              s1 * s2 * s3 * R.C[7][i];
+            v += n[i] * Xi;
+        }
+        off = fmax(off, v);
+    }
+    const double nn = fabs(n[0]) + fabs(n[1]) + fabs(n[2]);
+    po = off + 1e-9 * nn * ext;
 }
 
 // constants of the inverse map's first Newton step (see inv_map_hex8): the cofactor / det / reciprocal

@@ -245,7 +245,7 @@ struct HexT {
     using Rec = ElemRec;
     static constexpr int NEN = 8, NES = 6, NSN = 4;
     static __device__ __forceinline__ int face(int sg, int a) { return c_hex_isn[sg][a]; }
-    static __device__ void finish(Rec& R, const GridDev&, double) { hex8_monomials(R); hex8_planes(R); hex8_newton0(R); }
+    static __device__ void finish(Rec& R, const GridDev&, double) { hex8_monomials(R); hex8_newton0(R); }   // + hex_planes_kernel
 };
 struct TetT {
     using Rec = TetRec;
@@ -326,6 +326,20 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
     cls[el] = (uint8_t)c;
     fmask[el] = 0u;
     nitems[el] = (c == CLS_ISO) ? 1u : 0u;   // + the boundary-face triangles, added by face_mask_kernel
+}
+
+// bounding half-spaces of the inflated elements (ElemRec::pn / po, used by sign_project_kernel only): one thread
+// per (element, face), on the second stream - off the critical path of the mesh preparation
+__global__ void hex_planes_kernel(ElemRec* __restrict__ erec, int64_t nel)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t el = gid / 6;
+    const int f = (int)(gid % 6);
+    if (el >= nel) return;
+    double n[3], po;
+    hex8_plane(erec[el], f >> 1, f & 1, n, po);
+    erec[el].pn[f][0] = n[0]; erec[el].pn[f][1] = n[1]; erec[el].pn[f][2] = n[2];
+    erec[el].po[f] = po;
 }
 
 // boundary faces (sdfOnDensityField.jl:511-519): a face is on the boundary when exactly one element (this one)
@@ -1679,7 +1693,7 @@ struct r2s_plan {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // second stream: sentinel sweep + sign pass run beside the iso-surface projection (fused SDF output)
     hipStream_t st2 = nullptr;
-    hipEvent_t ev2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 // exclusive scans of one or two (in1 != nullptr) arrays of n entries each
@@ -1815,7 +1829,7 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 64, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostGetDevicePointer((void**)&P->d_pinned, P->h_pinned, 0));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
-    for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
+    for (int i = 0; i < 6; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
     {
         // high priority: the short stages of the second stream (sentinel sweep, inverse maps of the sign pass,
         // sign-only gather) get wave slots ahead of the long persistent projection kernel.  Measured on the
@@ -1843,7 +1857,7 @@ void r2s_plan_destroy(r2s_plan* P)
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
     for (int i = 0; i < 8; ++i)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 6; ++i)
         if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
     if (P->st2) (void)hipStreamDestroy(P->st2);
     delete P;
@@ -1932,11 +1946,17 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->counters, 64);
     uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] band tiles, [2] sign tiles
 
+    HIP_TRY(hipStreamWaitEvent(st, P->ev2[5], 0));   // (a previous call that failed early may have left hex_planes_kernel behind)
     HIP_TRY(hipEventRecord(P->ev[0], st));
     // ---- node -> element CSR (second stream) beside the element records, classes, item counts ----
     zero_many(st, {{P->deg.p, sizeof(uint32_t) * (size_t)(nnp + 1)}, {P->cursor.p, sizeof(uint32_t) * (size_t)(nnp + 1)},
                    {counters, 64}, {P->nitems.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
     HIP_TRY(hipEventRecord(P->ev2[0], st));
+    // (host order: the long kernel of this stream first, then the chain of short ones for the other stream)
+    elem_prep_kernel<ET><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
+        dX, dIEN, d_rho_n, nel, nnp, rho_t, g, P->erec.as<typename ET::Rec>(),
+        P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->nitems.as<uint32_t>());
+    HIP_TRY(hipEventRecord(P->ev2[5], st));
     HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[0], 0));
     {
         const int64_t n = nel * ET::NEN;
@@ -1946,9 +1966,12 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         ine_fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, P->st2>>>(dIEN, nel, ET::NEN, nnp, P->ine_ptr.as<uint32_t>(), P->cursor.as<uint32_t>(), P->ine.as<uint32_t>());
     }
     HIP_TRY(hipEventRecord(P->ev2[1], P->st2));
-    elem_prep_kernel<ET><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
-        dX, dIEN, d_rho_n, nel, nnp, rho_t, g, P->erec.as<typename ET::Rec>(),
-        P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->nitems.as<uint32_t>());
+    if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
+        // bounding half-spaces for the sign pass: behind the element records, on the second stream
+        HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[5], 0));
+        hex_planes_kernel<<<(unsigned)((nel * 6 + 255) / 256), 256, 0, P->st2>>>(P->erec.as<ElemRec>(), nel);
+        HIP_TRY(hipEventRecord(P->ev2[5], P->st2));   // from here on: "planes done"
+    }
     HIP_TRY(hipStreamWaitEvent(st, P->ev2[1], 0));
     face_mask_kernel<ET><<<(unsigned)((nel * ET::NES + 255) / 256), 256, 0, st>>>(
         dIEN, nel, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(),
@@ -2120,6 +2143,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             if (!fork) HIP_TRY(hipEventRecord(P->ev2[1], ss));
             if (want_sign && n_schunks) {
                 const uint32_t cpw = 8, nwaves = (n_schunks + cpw - 1) / cpw;   // chunks per wavefront
+                HIP_TRY(hipStreamWaitEvent(ss, P->ev2[5], 0));   // bounding half-spaces (hex_planes_kernel, second stream)
                 sign_project_kernel<<<nwaves, 64, 0, ss>>>(P->sbox.as<SignBox>(), (uint32_t)nel, P->s_chunk_off.as<uint32_t>(), n_schunks, P->s_store_off.as<uint32_t>(), cpw,
                                                           P->erec.as<ElemRec>(), g, s, rho_t, P->hot.as<uint8_t>(), P->sres.as<double>());
             }
@@ -2145,7 +2169,10 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 // the grid (one rank of 4 / 8), where coarse groups leave wavefronts unevenly loaded (-15 % at 13 chunks/wave)
                 const uint32_t group = std::min(4u, std::max(1u, n_chunks / (resident * 12u)));
                 const uint32_t ngroups = (n_chunks + group - 1) / group;
-                HIP_TRY(hipMemsetAsync(counters + 8, 0, 4, st));
+                // (counters[8], the chunk counter, is zero since the start of the call)
+                // the sweep has to get its wavefronts placed before this kernel fills every SIMD for 3 ms (it is released
+                // once the second stream has reached the sweep; high priority does the rest)
+                if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[0], 0));
                 iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
                     P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
                     s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, counters + 8,
@@ -2220,6 +2247,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             }
         }
     }
+    HIP_TRY(hipStreamWaitEvent(st, P->ev2[5], 0));   // nothing of this call is left on the second stream
     HIP_TRY(hipEventRecord(P->ev[5], st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
