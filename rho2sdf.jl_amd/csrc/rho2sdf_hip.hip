@@ -2164,7 +2164,11 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
             HIP_TRY(hipEventRecord(P->ev[7], st));
             if (want_dist && n_chunks) {
-                const uint32_t resident = (uint32_t)P->n_cu * 4u * 3u;   // CUs x SIMDs x waves/SIMD of this kernel
+                static const int wps_env = getenv("R2S_ISO_WPS") ? atoi(getenv("R2S_ISO_WPS")) : 0;   // tuning knob
+                const uint32_t wps = (wps_env >= 1 && wps_env <= 3) ? (uint32_t)wps_env : 3u;
+                const uint32_t resident = (uint32_t)P->n_cu * 4u * wps;   // CUs x SIMDs x waves/SIMD of this kernel
+                // (2 waves/SIMD, or 3 on only part of the SIMDs so that sign_project finds room beside them from the
+                // start: measured, no gain - the two kernels together are bound by their FP64 work either way)
                 // chunks per fetch: 4 when every wavefront gets dozens of them (1-8: +-2 %), fewer for a small share of
                 // the grid (one rank of 4 / 8), where coarse groups leave wavefronts unevenly loaded (-15 % at 13 chunks/wave)
                 const uint32_t group = std::min(4u, std::max(1u, n_chunks / (resident * 12u)));
