@@ -325,8 +325,18 @@ struct QpOut {
     int next;  // pattern an active-set step would try next (-1: none)
 };
 
+// symmetric 3x3 matrix, upper triangle only (the QP matrix of the SQP: six registers instead of nine per lane)
+struct Sym3 {
+    double a00, a01, a02, a11, a12, a22;
+    R2S_DEV double operator()(int i, int j) const
+    {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        return lo == 0 ? (hi == 0 ? a00 : (hi == 1 ? a01 : a02)) : (lo == 1 ? (hi == 1 ? a11 : a12) : a22);
+    }
+};
+
 // returns 0: pattern unusable, 2: primal infeasible, 1: primal feasible (o.kkt tells optimality)
-R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const double a[3], double e,
+R2S_DEV int qp_pattern(int pat, const Sym3& H, const double g[3], const double a[3], double e,
                        const double lo[3], const double hi[3], QpOut& o)
 {
     o.next = -1;
@@ -349,11 +359,11 @@ R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const d
             double t = -g[i];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                if (s[j]) t = fma(-H[i][j], dB[j], t);
+                if (s[j]) t = fma(-H(i, j), dB[j], t);
             b[i] = t;
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) M[i][j] = (s[i] || s[j]) ? ((i == j) ? 1.0 : 0.0) : H[i][j];
+        for (int j = 0; j < 3; ++j) M[i][j] = (s[i] || s[j]) ? ((i == j) ? 1.0 : 0.0) : H(i, j);
     }
     // inverse of the masked symmetric matrix by its adjugate (one division); the leading minors double as
     // the positive-definiteness test (Sylvester)
@@ -408,7 +418,7 @@ R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const d
     double Hd[3], q = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        Hd[i] = dot3(H[i][0], H[i][1], H[i][2], o.d[0], o.d[1], o.d[2]);
+        Hd[i] = dot3(H(i, 0), H(i, 1), H(i, 2), o.d[0], o.d[1], o.d[2]);
         q = fma(o.d[i], fma(0.5, Hd[i], g[i]), q);
     }
     bool kkt = true;
@@ -431,15 +441,15 @@ R2S_DEV int qp_pattern(int pat, const double H[3][3], const double g[3], const d
 
 static __constant__ int c_pat_order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8, 10, 11, 19, 20, 12, 15, 21, 24};
 
-R2S_DEV bool spd3(const double H[3][3])
+R2S_DEV bool spd3(double h00, double h01, double h02, double h11, double h12, double h22)
 {
-    // Sylvester's criterion on the (symmetric) matrix: leading minors, no division
-    const double c00 = fma(H[1][1], H[2][2], -(H[1][2] * H[1][2]));
-    const double c01 = fma(H[0][2], H[1][2], -(H[0][1] * H[2][2]));
-    const double c02 = fma(H[0][1], H[1][2], -(H[0][2] * H[1][1]));
-    const double m2 = fma(H[0][0], H[1][1], -(H[0][1] * H[0][1]));
-    const double det = dot3(H[0][0], H[0][1], H[0][2], c00, c01, c02);
-    return (H[0][0] > 0.0) && (m2 > 0.0) && (det > 0.0);
+    // Sylvester's criterion on the symmetric matrix: leading minors, no division
+    const double c00 = fma(h11, h22, -(h12 * h12));
+    const double c01 = fma(h02, h12, -(h01 * h22));
+    const double c02 = fma(h01, h12, -(h02 * h11));
+    const double m2 = fma(h00, h11, -(h01 * h01));
+    const double det = dot3(h00, h01, h02, c00, c01, c02);
+    return (h00 > 0.0) && (m2 > 0.0) && (det > 0.0);
 }
 
 template <class ER>   // any record with C[8][3], Cr[8] (ElemRec in SGPRs, IsoElemLds per lane)
@@ -473,7 +483,8 @@ enum { ISO_IDLE = 0, ISO_EVAL, ISO_QP, ISO_POST, ISO_LS, ISO_UPD, ISO_DONE };
 struct IsoLane {
     double x[3];
     double xi[3], mu, Delta;
-    double H[3][3], a[3], g[3], d[3];
+    Sym3 H;
+    double a[3], g[3], d[3];
     double se;   // sigma * e: the QP gradient g - se * a and the step bounds are rebuilt where they are needed
                  // (a handful of operations) instead of occupying 16 registers between the phases
     double f, c, lam_new, alpha, D, phi0, bestq;
@@ -573,43 +584,27 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
         s.bestq = dot3(s.d[0], s.d[1], s.d[2], Gd[0], Gd[1], Gd[2]);
         s.phase = ISO_POST;
     } else {
-        double Hgn[3][3];   // Gauss-Newton + sigma a a^T (symmetric by construction, like H)
         const double se = sigma * e;
         s.se = se;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double sa = sigma * s.a[i];
-#pragma unroll
-            for (int j = i; j < 3; ++j) Hgn[i][j] = Hgn[j][i] = fma(sa, s.a[j], G[i][j]);
-
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) s.H[i][j] = Hgn[i][j];
-        s.H[0][1] += S[0]; s.H[1][0] = s.H[0][1];
-        s.H[0][2] += S[1]; s.H[2][0] = s.H[0][2];
-        s.H[1][2] += S[2]; s.H[2][1] = s.H[1][2];
+        const double sa0 = sigma * s.a[0], sa1 = sigma * s.a[1], sa2 = sigma * s.a[2];
+        Sym3 Hgn;   // Gauss-Newton + sigma a a^T
+        Hgn.a00 = fma(sa0, s.a[0], G[0][0]); Hgn.a01 = fma(sa0, s.a[1], G[0][1]); Hgn.a02 = fma(sa0, s.a[2], G[0][2]);
+        Hgn.a11 = fma(sa1, s.a[1], G[1][1]); Hgn.a12 = fma(sa1, s.a[2], G[1][2]);
+        Hgn.a22 = fma(sa2, s.a[2], G[2][2]);
+        s.H = Hgn;
+        s.H.a01 += S[0];
+        s.H.a02 += S[1];
+        s.H.a12 += S[2];
         // positive definite on the face of the box the last QP ended on (warm-start pattern) - see the oracle
-        double Hm[3][3];
-        {
-            const int sp[3] = {s.pat % 3, (s.pat / 3) % 3, s.pat / 9};
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) Hm[i][j] = (sp[i] || sp[j]) ? ((i == j) ? 1.0 : 0.0) : s.H[i][j];
-        }
+        const bool f0 = (s.pat % 3) != 0, f1 = ((s.pat / 3) % 3) != 0, f2 = (s.pat / 9) != 0;
+        const bool ex = spd3(f0 ? 1.0 : s.H.a00, (f0 || f1) ? 0.0 : s.H.a01, (f0 || f2) ? 0.0 : s.H.a02,
+                             f1 ? 1.0 : s.H.a11, (f1 || f2) ? 0.0 : s.H.a12, f2 ? 1.0 : s.H.a22);
         // While the active-set walk runs with the exact matrix (ip = 1), the off-diagonals of the Gauss-Newton
         // matrix wait in D, phi0 and lam_new: those three are dead between EVAL and the end of the walk (POST
         // writes D and phi0, the QP writes lam_new when it is done) and the state has no registers to spare.
-        s.ip = spd3(Hm) ? 1 : 0;
-        s.D = Hgn[0][1]; s.phi0 = Hgn[0][2]; s.lam_new = Hgn[1][2];
-        if (!s.ip) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) s.H[i][j] = Hgn[i][j];
-        }
+        s.ip = ex ? 1 : 0;
+        s.D = Hgn.a01; s.phi0 = Hgn.a02; s.lam_new = Hgn.a12;
+        if (!ex) s.H = Hgn;
         s.p = s.pat;
         s.step = 0;
         s.found = false;
@@ -641,9 +636,9 @@ R2S_DEV void iso_lane_qp(IsoLane& s)
             // the walk left the warm-start face for one on which the exact matrix is not positive definite: this
             // iteration continues with Gauss-Newton (same diagonal), from the warm-start pattern
             s.ip = 0;
-            s.H[0][1] = s.H[1][0] = s.D;
-            s.H[0][2] = s.H[2][0] = s.phi0;
-            s.H[1][2] = s.H[2][1] = s.lam_new;
+            s.H.a01 = s.D;
+            s.H.a02 = s.phi0;
+            s.H.a12 = s.lam_new;
             s.p = s.pat;
             s.step = 0;
         } else {
