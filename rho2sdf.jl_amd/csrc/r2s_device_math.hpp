@@ -489,7 +489,7 @@ struct IsoLane {
                  // (a handful of operations) instead of occupying 16 registers between the phases
     double f, c, lam_new, alpha, D, phi0, bestq;
     int pat, it, p, step, ip, ls, stop, phase;
-    bool corner, found, fb;
+    bool corner, found, fb, restarted;
 };
 
 // step bounds of the current iterate: the box |xi| <= 1 cut with the trust region
@@ -508,6 +508,7 @@ R2S_DEV void iso_lane_start(IsoLane& s, const double x[3])
     s.xi[0] = s.xi[1] = s.xi[2] = 0.0;
     s.mu = 0.0; s.Delta = 2.0;
     s.pat = 0; s.it = 0;
+    s.restarted = false;
     s.phase = ISO_EVAL;
 }
 
@@ -725,11 +726,33 @@ R2S_DEV void iso_lane_ls(const ER& E, double rt, IsoLane& s)
     }
 }
 
-R2S_DEV void iso_lane_update(IsoLane& s)
+template <class ER>
+R2S_DEV void iso_lane_update(const ER& E, IsoLane& s)
 {
     const double dm = fmax(fabs(s.d[0]), fmax(fabs(s.d[1]), fabs(s.d[2])));
     s.Delta = (s.alpha < 1.0) ? s.alpha * dm : fmin(2.0, fmax(s.Delta, 2.0 * dm));
-    if (s.stop == 2) { s.phase = ISO_DONE; return; }
+    if (s.stop == 2) {
+        if (!s.restarted && fabs(s.c) > 1e-10) {
+            // stuck at a point that does not satisfy the constraint: one more attempt from half-way to the node whose
+            // density lies farthest on the other side of the threshold (see the oracle)
+            double best = -INFINITY;
+            int kb = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double xc[3] = {(k & 1) ? 1.0 : -1.0, (k & 2) ? 1.0 : -1.0, (k & 4) ? 1.0 : -1.0};
+                const double rk = tri_eval_value(R2S_CR(E), xc);
+                const double score = (s.c < 0.0) ? rk : -rk;
+                if (score > best) { best = score; kb = k; }
+            }
+            s.xi[0] = (kb & 1) ? 0.5 : -0.5; s.xi[1] = (kb & 2) ? 0.5 : -0.5; s.xi[2] = (kb & 4) ? 0.5 : -0.5;
+            s.mu = 0.0; s.Delta = 2.0; s.pat = 0; s.restarted = true;
+            s.it += 1;
+            s.phase = (s.it == R2S_ISO_MAXIT) ? ISO_DONE : ISO_EVAL;
+            return;
+        }
+        s.phase = ISO_DONE;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) s.xi[i] = fmin(fmax(fma(s.alpha, s.d[i], s.xi[i]), -1.0), 1.0);
     if (s.stop == 1) { s.phase = ISO_DONE; return; }

@@ -1068,7 +1068,7 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
             ISO_STAT(3, s.phase == ISO_LS)
             if (s.phase == ISO_LS) iso_lane_ls(E, rho_t, s);
             ISO_STAT(4, s.phase == ISO_UPD)
-            if (s.phase == ISO_UPD) iso_lane_update(s);
+            if (s.phase == ISO_UPD) iso_lane_update(E, s);
             ISO_STAT(5, true)
 #ifdef R2S_ISO_STATS
             if (s.phase != ISO_IDLE) dbg_trips += 1;
