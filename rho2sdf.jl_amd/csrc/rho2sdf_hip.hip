@@ -1313,18 +1313,21 @@ __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __res
         for (uint32_t j = threadIdx.x; j < s_cnt[l]; j += 256u) out[l][s_base[l] + j] = s_list[l][j];
 }
 
-// short lists (<= 64 entries): one LANE per active tile, rank sort
+// short lists (<= 64 entries): SORT_LANES lanes per active tile, rank sort (every lane ranks every SORT_LANES-th
+// entry; the lanes of a group read the same addresses in the inner loop)
+#define SORT_LANES 8
 __global__ void __launch_bounds__(256) bin_sort_small_kernel(const uint32_t* __restrict__ active, uint32_t n_active,
                                                             const uint32_t* __restrict__ off,
                                                             const uint32_t* __restrict__ in,
                                                             uint32_t* __restrict__ out)
 {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t w = gid / SORT_LANES, sub = gid % SORT_LANES;
     if (w >= n_active) return;
     const uint32_t t = active[w];
     const uint32_t b = off[t], n = off[t + 1] - b;
     if (n > 64) return;
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = sub; i < n; i += SORT_LANES) {
         const uint32_t v = in[b + i];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < n; ++j) rank += (in[b + j] < v) ? 1u : 0u;
@@ -2081,12 +2084,12 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->hot.as<uint8_t>());
     // lists longer than 64 entries only occur when the grid is coarse relative to the mesh (few tiles)
     if (n_active) {
-        bin_sort_small_kernel<<<(n_active + 255) / 256, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
+        bin_sort_small_kernel<<<(n_active * SORT_LANES + 255) / 256, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
         if (P->h_pinned[6] > 64u)
             bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>());
     }
     if (n_active_sign) {
-        bin_sort_small_kernel<<<(n_active_sign + 255) / 256, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>());
+        bin_sort_small_kernel<<<(n_active_sign * SORT_LANES + 255) / 256, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>());
         if (P->h_pinned[7] > 64u)
             bin_sort_kernel<<<(n_active_sign + 3) / 4, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>());
     }
