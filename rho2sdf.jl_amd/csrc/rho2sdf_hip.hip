@@ -288,7 +288,7 @@ template <class ET>
 __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __restrict__ IEN,
                                  const double* __restrict__ rho_n, int64_t nel, int64_t nnp, double rho_t,
                                  GridDev g, typename ET::Rec* __restrict__ erec, uint8_t* __restrict__ cls,
-                                 uint32_t* __restrict__ fmask, uint32_t* __restrict__ nitems)
+                                 uint32_t* __restrict__ fmask, uint32_t* __restrict__ nitems, SlabInfo sl, double delta)
 {
     int64_t el = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (el >= nel) return;
@@ -318,6 +318,25 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
     }
     R.rmax = rmax;
     R.rmin = rmin;
+    {
+        // An element none of whose lattice planes (AABB widened by the band, one plane of slack on either side) belongs
+        // to this call's share of the grid contributes nothing here: no record, no items.  One rank of eight sees an
+        // eighth (Z-slabs) to a half (interleaved tile layers) of the elements.
+        int a = (int)floor((R.mn[2] - delta - g.amin[2]) / g.cell) - 1, b = (int)ceil((R.mx[2] + delta - g.amin[2]) / g.cell) + 1;
+        if (a < 0) a = 0;
+        if (b > g.nz - 1) b = g.nz - 1;
+        int la, lb;
+        if (a > b || !slab_local_range(sl, a, b, la, lb)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { erec[el].mn[i] = R.mn[i]; erec[el].mx[i] = R.mx[i]; }   // (the bin kernels look at the AABB)
+            erec[el].rmax = rmax;
+            erec[el].rmin = rmin;
+            cls[el] = CLS_SKIP;
+            fmask[el] = 0u;
+            nitems[el] = 0u;
+            return;
+        }
+    }
     ET::finish(R, g, rho_t);
     erec[el] = R;
     int c = CLS_SKIP;
@@ -1958,7 +1977,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     // (host order: the long kernel of this stream first, then the chain of short ones for the other stream)
     elem_prep_kernel<ET><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
         dX, dIEN, d_rho_n, nel, nnp, rho_t, g, P->erec.as<typename ET::Rec>(),
-        P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->nitems.as<uint32_t>());
+        P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(), P->nitems.as<uint32_t>(), s, delta);
     HIP_TRY(hipEventRecord(P->ev2[5], st));
     HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[0], 0));
     {
