@@ -15,6 +15,10 @@ With N > 1 the fixed 512^3 grid is partitioned along Z (one rank per GPU; defaul
 ("scaling": "strong"): by default only the 4x4x4 tiles that can differ from the sentinel travel
 (one padded all_gather_into_tensor of tile payloads + ids after a tiny count exchange; --stitch dense
 gathers the full Float64 volume instead).
+
+At N = 1 rank 0 also times the CPU oracle ("cpu_baseline", kind "port") on a plane sample of the same workload:
+up to 16 single-thread worker processes, worker w on the Z planes k % --cpu-stride == w (about 25 s of CPU work);
+--check compares worker 0's planes with the GPU result bit for bit.
 """
 import argparse
 import json
