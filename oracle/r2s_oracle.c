@@ -281,7 +281,11 @@ static inline double tri_eval_value(const double *c, int st, const double xi[3])
 /* (10,10,10) like the reference's failure path (:106).                */
 /* ------------------------------------------------------------------ */
 #define INV_MAXIT 50
-#define INV_TOL 1e-10
+/* Step tolerance: Newton converges quadratically here, so the iterate AFTER a step below 1e-7 is within ~1e-14
+ * of the root - the accuracy a 1e-10 tolerance delivers, one iteration earlier (the last iteration of that rule
+ * only confirms a step of ~1e-15).  The reference's own optimiser stops at xtol_rel 1e-6 / ftol_abs 1e-10
+ * (FindLocalCoordinates.jl:79-87). */
+#define INV_TOL 1e-7
 static int inv_map_hex8(const double Xe[16][3] /* nodes + monomials */, const double x[3], double xi[3])
 {
     xi[0] = xi[1] = xi[2] = 0.0;

@@ -256,6 +256,7 @@ R2S_DEV double dot3(double a0, double a1, double a2, double b0, double b1, doubl
     return fma(a2, b2, fma(a1, b1, a0 * b0));
 }
 
+#define R2S_INV_TOL 1e-7   // step tolerance of the inverse map = the oracle's INV_TOL (see the note there)
 template <class ER>
 R2S_DEV bool inv_map_hex8(const ER& E, const double x[3], double xi[3])
 {
@@ -273,7 +274,7 @@ R2S_DEV bool inv_map_hex8(const ER& E, const double x[3], double xi[3])
         const double n2 = fmin(fmax(xi[2] + d2, -1.1), 1.1);
         const double step = fmax(fabs(n0 - xi[0]), fmax(fabs(n1 - xi[1]), fabs(n2 - xi[2])));
         xi[0] = n0; xi[1] = n1; xi[2] = n2;
-        if (!(step > 1e-10)) {
+        if (!(step > R2S_INV_TOL)) {
             if (step != step) { xi[0] = xi[1] = xi[2] = 10.0; return false; }
             return true;
         }
@@ -305,7 +306,7 @@ R2S_DEV bool inv_map_hex8(const ER& E, const double x[3], double xi[3])
         double n2 = fmin(fmax(xi[2] + d2, -1.1), 1.1);
         double step = fmax(fabs(n0 - xi[0]), fmax(fabs(n1 - xi[1]), fabs(n2 - xi[2])));
         xi[0] = n0; xi[1] = n1; xi[2] = n2;
-        if (!(step > 1e-10)) {
+        if (!(step > R2S_INV_TOL)) {
             if (step != step) break;
             return true;
         }
