@@ -467,7 +467,7 @@ R2S_DEV void iso_eval_fc(const ER& E, const double x[3], double rt, const double
 
 #define R2S_QP_WALK 8   // active-set steps before the exhaustive fallback
 #define R2S_ISO_MAXIT 60
-#define R2S_ISO_TOL 1e-8
+#define R2S_ISO_TOL 1e-6   // = the oracle's ISO_TOL (see the note there)
 
 // ---- the SQP as a per-lane state machine ---------------------------------------------
 // The oracle's iso_project_hex8 (oracle/r2s_oracle.c) cut into phases so that the lanes of a wavefront can
