@@ -10,7 +10,8 @@ Partitions (equal-sized contributions to ONE all_gather_into_tensor):
 
 Stitching:
   dense        the whole Float64 volume travels (8 B/voxel)
-  sparse       only the 4x4x4 tiles that can differ from the sentinel travel, in ONE all_gather_into_tensor:
+  sparse       only the 4x4x4 tiles that can differ from the sentinel travel, in ONE all_gather_into_tensor
+               (plus a count exchange on the very first step, or when the tile counts outgrow the agreed capacity):
                tiles with band items as 64 values + a tile id, tiles that only carry the sign (every voxel
                +-1e10) as a 64-bit mask + a tile id; every rank pre-fills its volume with the sentinel and
                scatters what it receives.  Interleaved partition only (tile layers are aligned by construction).
@@ -67,6 +68,8 @@ class SlabGather:
             self.k0, self.k1 = self.bounds[rank]
             self.my_planes = self.k1 - self.k0
         self._ordered = None
+        self._cap = None          # sparse stitching: agreed segment capacities (band tiles, sign-only tiles)
+        self.n_collectives = 0
         self.last_counts = None
         if self.sparse:
             self.local = torch.empty(max(self.my_planes, 1) * self.plane, dtype=self.dtype, device=device)
@@ -105,30 +108,47 @@ class SlabGather:
             if self.world > 1:
                 dist.all_gather_into_tensor(self.gathered, self.mine)
             return
-        # ---- sparse: counts, ONE padded all-gather of [payload | ids | masks | mask ids], scatter ----
+        # ---- sparse: ONE padded all-gather of [counts | payload | ids | masks | mask ids], scatter ----
+        # Segment capacities are agreed once (a count exchange on the first step) and kept with 25 % head-room;
+        # every segment starts with its rank's two counts, so later steps need no separate exchange.  If some
+        # rank's tiles do not fit any more, every rank sees that in the headers it received, all grow the
+        # capacities from those (true) counts and the gather is repeated - the same decision everywhere.
         nf_mine, nm_mine = (int(counts[0]), int(counts[1])) if self.my_planes > 0 else (0, 0)
-        allc = torch.zeros(2 * self.world, dtype=torch.int64, device=self.device)
-        mine_cnt = torch.tensor([nf_mine, nm_mine], dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(allc, mine_cnt)
-        allc = allc.view(self.world, 2).tolist()
+        grow = lambda n: max(1, n + n // 4 + 16)
+        if self._cap is None:
+            allc = torch.zeros(2 * self.world, dtype=torch.int64, device=self.device)
+            mine_cnt = torch.tensor([nf_mine, nm_mine], dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(allc, mine_cnt)
+            allc = allc.view(self.world, 2).tolist()
+            self.n_collectives += 1
+            self._cap = (grow(max(int(c[0]) for c in allc)), grow(max(int(c[1]) for c in allc)))
+        filled = False
+        while True:
+            mf, mm = self._cap
+            seglen = 2 + mf * 64 + (mf + 1) // 2 + mm + (mm + 1) // 2
+            buf = torch.empty(self.world * seglen, dtype=self.dtype, device=self.device)
+            seg = buf[self.rank * seglen:(self.rank + 1) * seglen]
+            seg[:2].view(torch.int64).copy_(torch.tensor([nf_mine, nm_mine], dtype=torch.int64))
+            if nf_mine <= mf and nm_mine <= mm and (nf_mine or nm_mine):
+                payload, ids, masks, mids = self._segment_views(seg[2:], mf, mm)
+                got = self.ops.pack2(self.my_slab, payload, ids, masks, mids)
+                assert tuple(got) == (nf_mine, nm_mine), (got, nf_mine, nm_mine)
+            # the collective runs on the communicator's stream: the sentinel pre-fill of the whole volume
+            # (1 GB of HBM writes at 512^3) overlaps with it instead of preceding it
+            work = dist.all_gather_into_tensor(buf, seg, async_op=True)
+            self.n_collectives += 1
+            if not filled:
+                self.ops.fill(self.full, SENTINEL)
+                filled = True
+            work.wait()
+            allc = buf.view(self.world, seglen)[:, :2].contiguous().view(torch.int64).tolist()
+            if all(int(c[0]) <= mf and int(c[1]) <= mm for c in allc):
+                break
+            self._cap = (grow(max(int(c[0]) for c in allc)), grow(max(int(c[1]) for c in allc)))
         self.last_counts = allc
-        mf = max(max(int(c[0]) for c in allc), 1)
-        mm = max(max(int(c[1]) for c in allc), 1)
-        seglen = mf * 64 + (mf + 1) // 2 + mm + (mm + 1) // 2
-        buf = torch.empty(self.world * seglen, dtype=self.dtype, device=self.device)
-        seg = buf[self.rank * seglen:(self.rank + 1) * seglen]
-        payload, ids, masks, mids = self._segment_views(seg, mf, mm)
-        if nf_mine or nm_mine:
-            got = self.ops.pack2(self.my_slab, payload, ids, masks, mids)
-            assert tuple(got) == (nf_mine, nm_mine), (got, nf_mine, nm_mine)
-        # the collective runs on the communicator's stream: the sentinel pre-fill of the whole volume
-        # (1 GB of HBM writes at 512^3) overlaps with it instead of preceding it
-        work = dist.all_gather_into_tensor(buf, seg, async_op=True)
-        self.ops.fill(self.full, SENTINEL)
-        work.wait()
         self.last_bytes = buf.numel() * buf.element_size()
         for r, (cf, cm) in enumerate(allc):
-            payload, ids, masks, mids = self._segment_views(buf[r * seglen:(r + 1) * seglen], mf, mm)
+            payload, ids, masks, mids = self._segment_views(buf[r * seglen + 2:(r + 1) * seglen], mf, mm)
             if cf:
                 self.ops.unpack(payload[:int(cf) * 64], ids[:int(cf)], int(cf), self.full)
             if cm:

@@ -118,6 +118,22 @@ def _worker(rank, world, port, ref_path, dims, interleaved, sparse=False):
 
     slabs.run_step(sg, compute_slab)
     ok = torch.equal(sg.volume().reshape(-1), ref)
+    if sparse:
+        # later steps: no count exchange (capacities agreed on the first step); more tiles than the capacity: one
+        # repeated gather, decided identically on every rank from the headers; then steady state again
+        full_ref = ref
+        assert sg.n_collectives == 2
+        ref = full_ref.clone()
+        ref.view(nz, -1)[nz // 3:] = -1.0e10                 # far fewer tiles
+        slabs.run_step(sg, compute_slab)
+        ok = ok and torch.equal(sg.volume().reshape(-1), ref) and sg.n_collectives == 3
+        cap = sg._cap
+        sg._cap = (1, 1)                                       # pretend the agreed capacity is far too small
+        ref = full_ref
+        slabs.run_step(sg, compute_slab)
+        ok = ok and torch.equal(sg.volume().reshape(-1), ref) and sg.n_collectives == 5 and sg._cap[0] > 1
+        slabs.run_step(sg, compute_slab)
+        ok = ok and torch.equal(sg.volume().reshape(-1), ref) and sg.n_collectives == 6
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
