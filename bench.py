@@ -13,7 +13,7 @@ timed region; the output SDF stays in HBM.
 With N > 1 the fixed 512^3 grid is partitioned along Z (one rank per GPU; default: interleaved
 4-plane tile layers, balanced) and stitched over RCCL/xGMI so that every rank holds the whole volume
 ("scaling": "strong"): by default only the 4x4x4 tiles that can differ from the sentinel travel
-(one padded all_gather_into_tensor of tile payloads + ids after a tiny count exchange; --stitch dense
+(one padded all_gather_into_tensor of counts + tile payloads + ids per step; --stitch dense
 gathers the full Float64 volume instead).
 
 At N = 1 rank 0 also times the CPU oracle ("cpu_baseline", kind "port") on a plane sample of the same workload:
