@@ -34,7 +34,87 @@ import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_VOXEL = 8.0      # one Float64 store per voxel; + mesh bytes / ngp
-DOMINANT_KERNEL = "iso_project_hex_pl_kernel"
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 FLOP x 2.4 GHz)
+DOMINANT_KERNEL = {"HEX8": "iso_project_hex_pl_kernel", "TET4": "iso_project_kernel"}
+PROFILE_ROUND = "r02"          # profiles/<round>_traffic.json, <round>_valu_counters.json (tools/collect_traffic.py)
+
+
+def load_committed_profile(kernel):
+    """PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command (separate --pmc runs,
+    tools/collect_traffic.py): they are NOT measured in the timed run and are labelled so.  None when absent."""
+    for rnd in (PROFILE_ROUND, "r01"):
+        tfile = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
+        vfile = os.path.join(ROOT, "profiles", f"{rnd}_valu_counters.json")
+        if not (os.path.exists(tfile) and os.path.exists(vfile)):
+            continue
+        t = json.load(open(tfile))["kernels"].get(kernel)
+        v = json.load(open(vfile)).get(kernel)
+        if not t or not v:
+            continue
+        traffic = None
+        if t.get("FETCH_SIZE_KB") is not None and t.get("WRITE_SIZE_KB") is not None:
+            traffic = (t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024.0
+        fp = {"source": f"committed profile profiles/{rnd}_valu_counters.json (not measured in this run)",
+              "valu_insts_per_launch": v.get("SQ_INSTS_VALU"),
+              "lane_utilisation": (v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
+                                   if v.get("SQ_ACTIVE_INST_VALU") else None)}
+        # FP64 FLOP per launch from the per-type instruction counters (wave64 instructions x 64 lanes x lane
+        # utilisation; FMA = 2 FLOP) when they were collected
+        if all(v.get(k) is not None for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64")):
+            lu = fp["lane_utilisation"] or 1.0
+            fp["fp64_insts_per_launch"] = {k[14:]: v[k] for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64",
+                                                                   "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")
+                                           if v.get(k) is not None}
+            fp["flop_per_launch"] = 64.0 * lu * (2.0 * v["SQ_INSTS_VALU_FMA_F64"] + v["SQ_INSTS_VALU_MUL_F64"]
+                                                 + v["SQ_INSTS_VALU_ADD_F64"])
+        return {"traffic": traffic, "traffic_source": f"committed profile profiles/{rnd}_traffic.json (separate --pmc passes, "
+                                                      "not measured in this run)", "fp64": fp}
+    return None
+
+
+def e2e_leg(pkg, X, IEN, rho_n, rho_t, grid, dev_index, sg):
+    """SURVEY 8(d)'s end-to-end figure through the drop-in entry point the Julia binding ccalls (r2s_sdf on host
+    pointers: H2D of the mesh + all kernels + D2H of the Float64 volume), once into ordinary pageable memory and once
+    into a buffer from r2s_host_alloc (pinned; what the Julia wrapper allocates its result arrays from)."""
+    mesh = pkg.Mesh(X, IEN)
+    res = {}
+    for kind in ("pinned", "pageable"):
+        out = pkg.host_array(grid.ngp) if kind == "pinned" else np.empty(grid.ngp)
+        times = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            pkg.sdf_fused(mesh, grid, rho_n, rho_t, device=dev_index, out=out)
+            times.append(time.perf_counter() - t0)
+        best = min(times[1:])
+        res[kind] = {"ms_per_call": best * 1e3, "Mvoxels_per_s": grid.ngp / best / 1e6, "first_call_ms": times[0] * 1e3}
+        same = np.array_equal(out.reshape(sg.nz, sg.ny, sg.nx)[::32], sg.volume()[::32].cpu().numpy())
+        res[kind]["equals_device_path"] = bool(same)
+        del out
+    res["note"] = "r2s_sdf(host pointers): H2D mesh + kernels + D2H of 8 B/voxel; never `value`"
+    return res
+
+
+
+
+def make_workload(args):
+    """the named workload -> (X, IEN (1-based), rho_n, rho_t, n_max, label).  All deterministic; chapadlo256 reads the
+    committed fixture tests/golden/chapadlo.npz (nodal densities by the product's own DenseInNodes would need the GPU,
+    so the fixture's element densities are projected with the library in main() and with the oracle in the CPU workers -
+    both are compared bit for bit by tests/test_stages_gpu.py)."""
+    from rho2sdf_jl_amd import synthetic
+    if args.workload == "ns":
+        X, IEN, rho_n = synthetic.hex_mesh(args.mesh or 46)
+        n_max = synthetic.grid_n_max_for_points(args.grid or 512)
+        return X, IEN, rho_n, 0.5, n_max, f"NS: synthetic jittered HEX8 {args.mesh or 46}^3"
+    if args.workload == "tet5":
+        X, IEN, rho_n = synthetic.tet_mesh(args.mesh or 55)
+        n_max = synthetic.grid_n_max_for_points(args.grid or 1024)
+        return X, IEN, rho_n, 0.5, n_max, f"config 5: synthetic jittered Schlafli TET4 6x{args.mesh or 55}^3"
+    if args.workload == "chapadlo256":
+        d = np.load(os.path.join(ROOT, "tests", "golden", "chapadlo.npz"))
+        X, IEN, rho = d["X"], d["IEN"].astype(np.int64), d["rho"]
+        return X, IEN, rho, 0.5, 249, "config 4: chapadlo.mat HEX8 (element densities -> DenseInNodes)"
+    raise SystemExit(f"unknown workload {args.workload}")
 
 
 def _oracle_planes(X, IEN, rho_n, rho_t, n_max, stride, phase):
@@ -55,10 +135,10 @@ def _oracle_planes(X, IEN, rho_n, rho_t, n_max, stride, phase):
 def cpu_worker(args):
     """child process of cpu_baseline (never touches torch or the GPU): one phase of the plane sample"""
     graft.load_package()
-    from rho2sdf_jl_amd import synthetic
-    X, IEN, rho_n = synthetic.hex_mesh(args.mesh)
-    n_max = synthetic.grid_n_max_for_points(args.grid)
-    dt, sdf, dims = _oracle_planes(X, IEN, rho_n, 0.5, n_max, args.cpu_stride, args.cpu_worker)
+    X, IEN, rho_n, rho_t, n_max, _ = make_workload(args)
+    if args.workload == "chapadlo256":
+        rho_n = graft.load_oracle().dense_in_nodes(X, IEN, rho_n)
+    dt, sdf, dims = _oracle_planes(X, IEN, rho_n, rho_t, n_max, args.cpu_stride, args.cpu_worker)
     nx, ny, nz = dims
     if args.cpu_save:
         np.save(args.cpu_save, sdf)
@@ -76,8 +156,8 @@ def cpu_baseline(args, threads):
     threads = max(1, min(threads, args.cpu_stride))
     with tempfile.TemporaryDirectory() as tmp:
         save = os.path.join(tmp, "planes0.npy")
-        base = [sys.executable, os.path.abspath(__file__), "--grid", str(args.grid), "--mesh", str(args.mesh),
-                "--cpu-stride", str(args.cpu_stride)]
+        base = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--grid", str(args.grid),
+                "--mesh", str(args.mesh), "--cpu-stride", str(args.cpu_stride)]
         procs = [subprocess.Popen(base + ["--cpu-worker", str(w)] + (["--cpu-save", save] if w == 0 else []),
                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for w in range(threads)]
         outs = []
@@ -104,23 +184,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--grid", type=int, default=512, help="grid points per axis (512 = north star)")
-    ap.add_argument("--mesh", type=int, default=46, help="HEX8 cells per axis (46 -> 97 336 elements)")
-    ap.add_argument("--cpu-stride", type=int, default=32, help="CPU baseline: worker w takes the Z planes k %% stride == w")
+    ap.add_argument("--workload", choices=["ns", "tet5", "chapadlo256"], default="ns",
+                    help="ns: north star (BASELINE metric); tet5: config 5 (998 250 TET4, 1024^3); chapadlo256: config 4")
+    ap.add_argument("--grid", type=int, default=0, help="grid points per axis (default 512 for ns, 1024 for tet5)")
+    ap.add_argument("--mesh", type=int, default=0, help="hex cells per axis (default 46 for ns, 55 for tet5)")
+    ap.add_argument("--cpu-stride", type=int, default=0, help="CPU baseline: worker w takes the Z planes k %% stride == w "
+                                                              "(default 32; 64 for tet5; 16 for chapadlo256)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline processes (0: host cores available, at most 16)")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-save", default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="compare the sampled planes with the oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and with it the check)")
+    ap.add_argument("--check", action="store_true", help="(kept for compatibility: the check runs whenever the oracle planes exist)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer end-to-end leg (r2s_sdf: H2D + kernels + D2H)")
     ap.add_argument("--partition", choices=["interleaved", "contiguous"], default="interleaved",
                     help="Z partition across GPUs (N > 1): interleaved 4-plane tile layers (balanced) or slabs")
     ap.add_argument("--stitch", choices=["sparse", "dense"], default="sparse",
                     help="N > 1: all-gather only the non-sentinel 4x4x4 tiles (sparse, interleaved partition) "
                          "or the whole Float64 volume (dense)")
     args = ap.parse_args()
+    if not args.cpu_stride:
+        args.cpu_stride = {"ns": 32, "tet5": 64, "chapadlo256": 16}[args.workload]
     if args.cpu_worker is not None:
         return cpu_worker(args)
 
+    # before anything initialises the HIP runtime (the host driver only supports dmabuf IPC)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -130,7 +218,6 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     pkg = graft.build()
-    from rho2sdf_jl_amd import synthetic
 
     # R2S_BENCH_REHEARSAL=1: functional rehearsal of the N > 1 path on ONE GPU (all ranks on cuda:0, gloo);
     # never used for reported numbers
@@ -139,16 +226,16 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    # ---- workload (synthetic, deterministic) ----
-    X, IEN, rho_n = synthetic.hex_mesh(args.mesh)
-    rho_t = 0.5
-    n_max = synthetic.grid_n_max_for_points(args.grid)
+    # ---- workload (deterministic) ----
+    X, IEN, rho_n, rho_t, n_max, label = make_workload(args)
+    if args.workload == "chapadlo256":
+        rho_n = pkg.DenseInNodes(pkg.Mesh(X, IEN), rho_n, device=dev_index)   # element densities -> nodal (GPU)
+    elem = "HEX8" if IEN.shape[1] == 8 else "TET4"
     grid = pkg.Grid(X.min(0), X.max(0), n_max, 3)
     nx, ny, nz = grid.dims
     ngp = grid.ngp
@@ -203,72 +290,65 @@ def main():
         nvox_rank = sg.my_planes * plane
         mesh_bytes = X.nbytes + IEN.nbytes + rho_n.nbytes
         alg_bytes = ALG_BYTES_PER_VOXEL * nvox_rank + mesh_bytes
+        dominant = DOMINANT_KERNEL[elem]
         main_s = avg["ms_main"] * 1e-3
         achieved = alg_bytes / main_s / 1e9 if main_s > 0 else 0.0
-        # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are
-        # collected in separate rocprofv3 runs - tools/collect_traffic.py); only valid for the default workload
-        traffic = None
-        valu = None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        vfile = os.path.join(ROOT, "profiles", "r01_valu_counters.json")
-        if os.path.exists(tfile) and args.grid == 512 and args.mesh == 46 and world == 1:
-            k = json.load(open(tfile))["kernels"].get(DOMINANT_KERNEL)
-            if k and k.get("FETCH_SIZE_KB") is not None and k.get("WRITE_SIZE_KB") is not None:
-                traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
-        if os.path.exists(vfile) and args.grid == 512 and args.mesh == 46 and world == 1:
-            k = json.load(open(vfile)).get(DOMINANT_KERNEL)
-            if k:
-                # the kernel's real limiter (committed SQ counter passes, profiles/r01_valu_counters.json):
-                # FP64 VALU instructions per launch and the fraction of lanes doing useful work in them
-                # issue estimate: a wave64 FP64 instruction occupies a SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
-                valu = {"valu_insts_per_launch": k.get("SQ_INSTS_VALU"),
-                        "lane_utilisation": (k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"])
-                                             if k.get("SQ_ACTIVE_INST_VALU") else None),
-                        "valu_issue_frac_est": (k["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * main_s)
-                                                if k.get("SQ_INSTS_VALU") and main_s > 0 else None)}
-                if valu["lane_utilisation"] and valu["valu_issue_frac_est"]:
-                    # useful FP64-rate lane-instructions against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
-                    # (78.6 TFLOP/s FP64 vector peak when every instruction is an FMA)
-                    valu["fp64_valu_frac_est"] = valu["lane_utilisation"] * valu["valu_issue_frac_est"]
+        default_ns = args.workload == "ns" and not args.grid and not args.mesh and world == 1
+        prof = load_committed_profile(dominant) if default_ns else None
+        roof = {"bound": "hbm", "kernel": dominant,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": prof["traffic"] if prof else None,
+                "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["ms_main"],
+                "avg_launch_ms_source": "HIP events around the kernel on its launch stream, this run",
+                "real_limiter": "fp64-valu",
+                "note": "the dominant kernel is FP64-VALU bound (SURVEY.md 0.7), not HBM bound: achieved/peak/frac are the "
+                        "contract's algorithmic-bytes figures (8 B/voxel of the slab + mesh bytes over the kernel's measured "
+                        "duration); the kernel's own roofline is `fp64` below; the HBM-bound kernel of the path is `fill_kernel`"}
+        if prof:
+            roof["traffic_source"] = prof["traffic_source"]
+            fp = dict(prof["fp64"])
+            if fp.get("flop_per_launch") and main_s > 0:
+                fp["achieved"] = fp["flop_per_launch"] / main_s / 1e12
+                fp["peak"] = FP64_VALU_PEAK_TFLOPS
+                fp["unit"] = "TFLOP/s"
+                fp["frac"] = fp["achieved"] / FP64_VALU_PEAK_TFLOPS
+            roof["fp64"] = fp
         out = {
             "metric": "Mvoxels/s SDF extract on 512^3 grid over 100k HEX8; max|err| vs ref",
             "value": value, "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"NS: synthetic jittered HEX8 {args.mesh}^3 = {len(IEN)} elements, "
-                                   f"{nx}x{ny}x{nz} grid (N_max={n_max}), rho_t=0.5, band factor 1.1, "
-                                   f"fused dist*sign, Z-slabs over {world} GPU(s)",
-                       "elements": int(len(IEN)), "voxels": int(ngp), "parallelism": (f"z-{args.partition}-{'sparse' if sg.sparse else 'dense'}-allgather-{world}"
+            "dtype": "f64", "data": "synthetic" if args.workload != "chapadlo256" else "reference fixture chapadlo.mat",
+            "config": {"workload": f"{label} = {len(IEN)} {elem} elements, {nx}x{ny}x{nz} grid (N_max={n_max}), "
+                                   f"rho_t={rho_t}, band factor 1.1, fused dist*sign, Z partition over {world} GPU(s)",
+                       "name": args.workload, "elements": int(len(IEN)), "voxels": int(ngp),
+                       "parallelism": (f"z-{args.partition}-{'sparse' if sg.sparse else 'dense'}-allgather-{world}"
                                        if world > 1 else "single-gpu")},
-            "roofline": {"bound": "hbm", "kernel": DOMINANT_KERNEL,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["ms_main"],
-                         "valu": valu,
-                         "note": "FP64-VALU-bound kernel (SURVEY.md 0.7), co-running with sign_project_kernel on "
-                                 "a second stream; algorithmic bytes = 8 B/voxel of the slab + mesh bytes; "
-                                 "see DESIGN.md section 4"},
+            "roofline": roof,
             "stages_ms": avg,
             "fill_kernel": {"GBps": (8.0 * nvox_rank) / (avg["ms_fill"] * 1e-3) / 1e9 if avg["ms_fill"] > 0 else None,
                             "frac_of_hbm_peak": (8.0 * nvox_rank) / (avg["ms_fill"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                             if avg["ms_fill"] > 0 else None},
             "work": {k: int(st0[k]) for k in ("n_items", "n_band_entries", "n_sign_entries", "n_tiles", "n_active_tiles", "n_active_sign_tiles")},
         }
-        if (world == 1 and not args.no_cpu_baseline) or args.check:
+        if world == 1 and not args.no_e2e:
+            out["e2e"] = e2e_leg(pkg, X, IEN, rho_n, rho_t, grid, dev_index, sg)
+        if not args.no_cpu_baseline:
             threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
             cb, ref = cpu_baseline(args, threads)
             if world == 1:
                 out["cpu_baseline"] = cb      # timed on rank 0 at N = 1 only
-            if args.check:
-                got = sg.volume()[::args.cpu_stride].cpu().numpy().ravel()
-                want = ref.ravel()
-                sent = np.abs(want) > 1e9
-                real = ~sent
-                rel = np.abs(got[real] - want[real]) / np.maximum(np.abs(want[real]), 1e-300)
-                out["check"] = {"voxels": int(want.size), "sentinel_mismatch": int((sent != (np.abs(got) > 1e9)).sum()),
-                                "sign_mismatch": int((np.sign(got) != np.sign(want)).sum()),
-                                "max_rel_err": float(rel.max()) if rel.size else 0.0,
-                                "bit_equal": int((got == want).sum())}
+            # the `max|err| vs ref` half of the metric: worker 0's planes against the stitched GPU volume
+            got = sg.volume()[::args.cpu_stride].cpu().numpy().ravel()
+            want = ref.ravel()
+            sent = np.abs(want) > 1e9
+            real = ~sent
+            rel = np.abs(got[real] - want[real]) / np.maximum(np.abs(want[real]), 1e-300)
+            out["check"] = {"against": "CPU oracle (oracle/r2s_oracle.c), Z planes k % %d == 0" % args.cpu_stride,
+                            "voxels": int(want.size), "sentinel_mismatch": int((sent != (np.abs(got) > 1e9)).sum()),
+                            "sign_mismatch": int((np.sign(got) != np.sign(want)).sum()),
+                            "max_rel_err": float(rel.max()) if rel.size else 0.0,
+                            "max_abs_err": float(np.abs(got[real] - want[real]).max()) if rel.size else 0.0,
+                            "bit_equal": int((got == want).sum())}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

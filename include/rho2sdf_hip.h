@@ -24,6 +24,7 @@
 #ifndef RHO2SDF_HIP_H
 #define RHO2SDF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -62,7 +63,11 @@ typedef struct {
      * plane 4*(i*G + zphase) + l; the output then has 4*ceil((layers - zphase)/G) planes. */
     int32_t zstride;
     int32_t zphase;
-    int32_t reserved[2];
+    /* host-pointer entry points (r2s_sdf, r2s_eval_distances, r2s_sign_detection): number of devices the ONE call
+     * fans out over (single process, one host thread per device 0..n_gpus-1, interleaved tile layers, every
+     * device sends its layers straight to their place in the caller's array); <= 1 = the device named above */
+    int32_t n_gpus;
+    int32_t reserved;
 } r2s_params;
 
 /* per-call counters (optional; pass NULL) */
@@ -114,6 +119,54 @@ int r2s_sign_detection(const double *X, int64_t nnp, const int64_t *IEN, int64_t
 int r2s_sdf(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_n,
             double rho_t, const r2s_grid *grid, const r2s_params *params, double *sdf_out,
             r2s_stats *stats);
+
+/* ---- the whole of rho2sdf() in one call ---------------------------------------------
+ * rho2sdf(taskName, X, IEN, rho; options)                          src/RhoToSDF.jl:116-242
+ * minus the file exports (which stay with the caller): mesh volume (:128) -> DenseInNodes (:148) ->
+ * find_threshold_for_volume (:151-156) -> evalDistances / Sign_Detection / product (:169-171) ->
+ * remove_sdf_artifacts! (:174-208) -> RBFs_smoothing (:222-224).  The mesh goes up once, every stage
+ * runs on HBM-resident data, the results come down once.  Fields mirror Rho2sdfOptions (:9-77). */
+typedef struct {
+    double threshold_density;            /* NaN = nothing: find_threshold_for_volume (TET4: the TET4 iso-volume) */
+    double band_factor;                  /* 1.1 */
+    double artifact_min_component_ratio; /* 0.01 */
+    double rbf_kernel_threshold;         /* 1e-3 (RBFs4Smoothing.jl:328) */
+    int32_t elem_type;                   /* R2S_HEX8 / R2S_TET4 */
+    int32_t rbf_interp;                  /* 1 */
+    int32_t rbf_smooth;                  /* 1 = rbf_grid :same, 2 = :fine */
+    int32_t remove_artifacts;            /* 1 */
+    int32_t device;                      /* -1 = current */
+    int32_t n_gpus;                      /* > 1: raw SDF on devices 0..n_gpus-1 (tile layers gathered on device 0 over xGMI) */
+    int32_t skip_rbf;                    /* 1: stop after artifact removal (fine_sdf_out may be NULL) */
+    int32_t reserved[5];
+} r2s_options;
+
+typedef struct {
+    double V_domain, V_frac;             /* calculate_mesh_volume */
+    double rho_t;                        /* threshold used */
+    int64_t n_flipped;                   /* remove_sdf_artifacts! */
+    float level_shift;                   /* LS_Threshold `th` */
+    int32_t cg_iters;
+    int32_t threshold_iters;
+    int32_t pad;
+    /* wall-clock milliseconds of the stages of this call */
+    double ms_upload, ms_pre, ms_sdf, ms_sdf_kernels, ms_artifacts, ms_rbf, ms_download, ms_total;
+} r2s_run_info;
+
+void r2s_default_options(r2s_options *o);
+
+/* grid: from r2s_grid_make / r2s_auto_grid (the caller sizes its result arrays from it).
+ * Optional outputs (NULL = not wanted): rho_n_out[nnp] nodal densities, sdf_raw_out[ngp] the field before
+ * artifact removal, sdf_dists_out[ngp] the returned `sdf_dists`; fine_sdf_out[prod(N*rbf_smooth+1)] Float32
+ * is required unless skip_rbf.  Result arrays from r2s_host_alloc come down by plain DMA. */
+int r2s_rho2sdf(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_e,
+                const r2s_options *options, const r2s_grid *grid, double *rho_n_out, double *sdf_raw_out,
+                double *sdf_dists_out, float *fine_sdf_out, r2s_run_info *info);
+
+/* Pinned host memory for result arrays (the Julia wrapper `unsafe_wrap`s it): device -> host copies into it run
+ * at PCIe rate with no staging.  Any other host pointer works too (staged, multi-threaded). */
+void *r2s_host_alloc(size_t bytes);
+void r2s_host_free(void *p);
 
 /* ---- device-resident plan API (bench, multi-GPU Z-slabs) ------------------ */
 typedef struct r2s_plan r2s_plan;
@@ -173,6 +226,19 @@ int r2s_dense_in_nodes(const double *X, int64_t nnp, const int64_t *IEN, int64_t
 int r2s_find_threshold(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_n,
                        double target_volume, double tol, int32_t maxit, int32_t device, double *rho_t_out,
                        int32_t *iters_out);
+
+/* the same bisection for either element type.  TET4 has no iso-volume in the reference
+ * (calculate_isocontour_volume hard-codes 8 nodes, Isocontour_volume.jl:27-38): it is assembled
+ * from the reference's own pieces - the skip / whole / cut classification of :40-52 with the collapsed-cube
+ * rule of MeshVolume.jl:75-117 (3^3 points for whole elements, 15^3 with the point test for cut ones) - so that
+ * volume(0) == V_domain of calculate_mesh_volume for TET4. */
+int r2s_find_threshold_et(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int32_t elem_type,
+                          const double *rho_n, double target_volume, double tol, int32_t maxit, int32_t device,
+                          double *rho_t_out, int32_t *iters_out);
+
+/* calculate_isocontour_volume(mesh, nodal_values, iso_threshold)     src/MeshGrid/Isocontour_volume.jl:1-75 */
+int r2s_isocontour_volume(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, int32_t elem_type,
+                          const double *rho_n, double threshold, int32_t device, double *volume_out);
 
 /* ---- post-processing ---------------------------------------------------------------- */
 

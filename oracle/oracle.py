@@ -165,7 +165,7 @@ def mesh_volume(X, IEN, rho_e):
 def isocontour_volume(X, IEN, rho_n, thr):
     X, IEN, et = _mesh(X, IEN)
     rho_n = np.ascontiguousarray(rho_n, dtype=np.float64)
-    f = lib().orc_isocontour_volume
+    f = lib().orc_isocontour_volume if et == 0 else lib().orc_isocontour_volume_tet4
     f.restype = ctypes.c_double
     return f(_d(X), _i(IEN), ctypes.c_int64(len(IEN)), _d(rho_n), ctypes.c_double(thr))
 
@@ -174,7 +174,7 @@ def find_threshold(X, IEN, rho_n, target_volume, tol=1e-4, maxit=60):
     X, IEN, et = _mesh(X, IEN)
     rho_n = np.ascontiguousarray(rho_n, dtype=np.float64)
     rt, it = ctypes.c_double(), ctypes.c_int()
-    rc = lib().orc_find_threshold(_d(X), ctypes.c_int64(len(X)), _i(IEN), ctypes.c_int64(len(IEN)), _d(rho_n),
+    rc = (lib().orc_find_threshold if et == 0 else lib().orc_find_threshold_tet4)(_d(X), ctypes.c_int64(len(X)), _i(IEN), ctypes.c_int64(len(IEN)), _d(rho_n),
                                   ctypes.c_double(target_volume), ctypes.c_double(tol), ctypes.c_int(maxit),
                                   ctypes.byref(rt), ctypes.byref(it))
     if rc:

@@ -23,7 +23,28 @@ class R2SGrid(ctypes.Structure):
 class R2SParams(ctypes.Structure):
     _fields_ = [("band_factor", ctypes.c_double), ("elem_type", ctypes.c_int32),
                 ("device", ctypes.c_int32), ("zstride", ctypes.c_int32), ("zphase", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 2)]
+                ("n_gpus", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class R2SOptions(ctypes.Structure):
+    """mirrors r2s_options (= Rho2sdfOptions, reference src/RhoToSDF.jl:9-77)"""
+    _fields_ = [("threshold_density", ctypes.c_double), ("band_factor", ctypes.c_double),
+                ("artifact_min_component_ratio", ctypes.c_double), ("rbf_kernel_threshold", ctypes.c_double),
+                ("elem_type", ctypes.c_int32), ("rbf_interp", ctypes.c_int32), ("rbf_smooth", ctypes.c_int32),
+                ("remove_artifacts", ctypes.c_int32), ("device", ctypes.c_int32), ("n_gpus", ctypes.c_int32),
+                ("skip_rbf", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
+
+
+class R2SRunInfo(ctypes.Structure):
+    _fields_ = [("V_domain", ctypes.c_double), ("V_frac", ctypes.c_double), ("rho_t", ctypes.c_double),
+                ("n_flipped", ctypes.c_int64), ("level_shift", ctypes.c_float), ("cg_iters", ctypes.c_int32),
+                ("threshold_iters", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("ms_upload", ctypes.c_double), ("ms_pre", ctypes.c_double), ("ms_sdf", ctypes.c_double),
+                ("ms_sdf_kernels", ctypes.c_double), ("ms_artifacts", ctypes.c_double), ("ms_rbf", ctypes.c_double),
+                ("ms_download", ctypes.c_double), ("ms_total", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
 
 
 class R2SStats(ctypes.Structure):
@@ -78,6 +99,16 @@ SYMBOLS = [
     ("r2s_dense_in_nodes", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_int32, c_double_p]),
     ("r2s_find_threshold", ctypes.c_int, _MESH + [c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
                                                   ctypes.c_int32, c_double_p, ctypes.POINTER(ctypes.c_int32)]),
+    ("r2s_find_threshold_et", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_double, ctypes.c_double,
+                                                     ctypes.c_int32, ctypes.c_int32, c_double_p,
+                                                     ctypes.POINTER(ctypes.c_int32)]),
+    ("r2s_isocontour_volume", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_double, ctypes.c_int32,
+                                                     c_double_p]),
+    ("r2s_default_options", None, [ctypes.POINTER(R2SOptions)]),
+    ("r2s_rho2sdf", ctypes.c_int, _MESH + [c_double_p, ctypes.POINTER(R2SOptions), ctypes.POINTER(R2SGrid), c_double_p,
+                                           c_double_p, c_double_p, c_float_p, ctypes.POINTER(R2SRunInfo)]),
+    ("r2s_host_alloc", ctypes.c_void_p, [ctypes.c_size_t]),
+    ("r2s_host_free", None, [ctypes.c_void_p]),
     ("r2s_remove_artifacts", ctypes.c_int, [c_double_p, ctypes.POINTER(R2SGrid), ctypes.c_double, ctypes.c_double,
                                             ctypes.c_int32, c_int64_p]),
     ("r2s_remove_artifacts_dev", ctypes.c_int, [_P, ctypes.POINTER(R2SGrid), ctypes.c_double, ctypes.c_double, _P,

@@ -75,13 +75,37 @@ def _i(a):
     return a.ctypes.data_as(L.c_int64_p)
 
 
-def _params(mesh, band_factor, device):
+def _params(mesh, band_factor, device, n_gpus=1):
     p = L.R2SParams()
     L.lib().r2s_default_params(ctypes.byref(p))
     p.band_factor = float(band_factor)
     p.elem_type = mesh.element_type
     p.device = int(device)
+    p.n_gpus = int(n_gpus)
     return p
+
+
+def host_array(n, dtype=np.float64):
+    """numpy array over pinned host memory from r2s_host_alloc (what the Julia wrapper `unsafe_wrap`s its result
+    arrays from): device -> host copies into it are plain DMA.  Freed with r2s_host_free when the array dies."""
+    import weakref
+    dtype = np.dtype(dtype)
+    nbytes = int(n) * dtype.itemsize
+    ptr = L.lib().r2s_host_alloc(max(nbytes, 1))
+    if not ptr:
+        raise L.R2SError("r2s_host_alloc failed: " + L.lib().r2s_last_error().decode())
+    buf = (ctypes.c_char * max(nbytes, 1)).from_address(ptr)
+    a = np.frombuffer(buf, dtype=dtype, count=int(n))
+    weakref.finalize(buf, L.lib().r2s_host_free, ctypes.c_void_p(ptr))
+    return a
+
+
+def _out(out, n, dtype=np.float64):
+    if out is None:
+        return np.empty(n, dtype=dtype)
+    if out.dtype != dtype or not out.flags.c_contiguous or out.size != n:
+        raise L.R2SError("`out` must be a contiguous %s array of %d values" % (np.dtype(dtype).name, n))
+    return out
 
 
 def _rho(mesh, rho_n):
@@ -91,14 +115,14 @@ def _rho(mesh, rho_n):
     return r
 
 
-def evalDistances(mesh, grid, rho_n, rho_t, *, band_factor=1.1, want_xp=True, device=-1, stats=None):
+def evalDistances(mesh, grid, rho_n, rho_t, *, band_factor=1.1, want_xp=True, device=-1, stats=None, n_gpus=1, out=None):
     """evalDistances(mesh, grid, points, rho_n, rho_t) -> (dist, xp)
     src/SignedDistances/sdfOnDensityField.jl:139-486 (`points` is implied by `grid`)."""
     r = _rho(mesh, rho_n)
-    dist = np.empty(grid.ngp)
+    dist = _out(out, grid.ngp)
     xp = np.empty((grid.ngp, 3)) if want_xp else None
     st = L.R2SStats()
-    p = _params(mesh, band_factor, device)
+    p = _params(mesh, band_factor, device, n_gpus)
     L.check(L.lib().r2s_eval_distances(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(rho_t),
                                        ctypes.byref(grid.c), ctypes.byref(p), _d(dist),
                                        _d(xp) if want_xp else None, ctypes.byref(st)))
@@ -107,12 +131,12 @@ def evalDistances(mesh, grid, rho_n, rho_t, *, band_factor=1.1, want_xp=True, de
     return dist, xp
 
 
-def Sign_Detection(mesh, grid, rho_n, rho_t, *, device=-1, stats=None):
+def Sign_Detection(mesh, grid, rho_n, rho_t, *, device=-1, stats=None, n_gpus=1, out=None):
     """Sign_Detection(mesh, grid, points, rho_n, rho_t) -> signs  (SignDetection.jl:275-283)"""
     r = _rho(mesh, rho_n)
-    s = np.empty(grid.ngp)
+    s = _out(out, grid.ngp)
     st = L.R2SStats()
-    p = _params(mesh, 1.1, device)
+    p = _params(mesh, 1.1, device, n_gpus)
     L.check(L.lib().r2s_sign_detection(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(rho_t),
                                        ctypes.byref(grid.c), ctypes.byref(p), _d(s), ctypes.byref(st)))
     if stats is not None:
@@ -120,12 +144,12 @@ def Sign_Detection(mesh, grid, rho_n, rho_t, *, device=-1, stats=None):
     return s
 
 
-def sdf_fused(mesh, grid, rho_n, rho_t, *, band_factor=1.1, device=-1, stats=None):
-    """`dists .* signs` in one pass (RhoToSDF.jl:169-171)."""
+def sdf_fused(mesh, grid, rho_n, rho_t, *, band_factor=1.1, device=-1, stats=None, n_gpus=1, out=None):
+    """`dists .* signs` in one pass (RhoToSDF.jl:169-171).  `out`: result array to fill (e.g. from host_array)."""
     r = _rho(mesh, rho_n)
-    out = np.empty(grid.ngp)
+    out = _out(out, grid.ngp)
     st = L.R2SStats()
-    p = _params(mesh, band_factor, device)
+    p = _params(mesh, band_factor, device, n_gpus)
     L.check(L.lib().r2s_sdf(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(rho_t),
                             ctypes.byref(grid.c), ctypes.byref(p), _d(out), ctypes.byref(st)))
     if stats is not None:
@@ -266,10 +290,20 @@ def find_threshold_for_volume(mesh, rho_n, target_volume, tolerance=1e-4, max_it
     r = _rho(mesh, rho_n)
     rt = ctypes.c_double()
     it = ctypes.c_int32()
-    L.check(L.lib().r2s_find_threshold(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(target_volume),
-                                       float(tolerance), int(max_iterations), int(device), ctypes.byref(rt),
-                                       ctypes.byref(it)))
+    L.check(L.lib().r2s_find_threshold_et(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, mesh.element_type, _d(r),
+                                          float(target_volume), float(tolerance), int(max_iterations), int(device),
+                                          ctypes.byref(rt), ctypes.byref(it)))
     return rt.value
+
+
+def calculate_isocontour_volume(mesh, rho_n, iso_threshold, *, device=-1):
+    """calculate_isocontour_volume(mesh, nodal_values, iso_threshold)   src/MeshGrid/Isocontour_volume.jl:1-75
+    (TET4: the iso-volume assembled from the reference's TET4 quadrature, see include/rho2sdf_hip.h)"""
+    r = _rho(mesh, rho_n)
+    v = ctypes.c_double()
+    L.check(L.lib().r2s_isocontour_volume(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, mesh.element_type, _d(r),
+                                          float(iso_threshold), int(device), ctypes.byref(v)))
+    return v.value
 
 
 def remove_sdf_artifacts(sdf, grid, *, threshold=0.0, min_component_ratio=0.01, device=-1):
@@ -400,48 +434,50 @@ class Rho2sdfOptions:
         self.element_type = element_type
 
 
-def rho2sdf(taskName, X, IEN, rho, *, options=None, sdf_grid=None, device=-1, export_results=False):
+def rho2sdf(taskName, X, IEN, rho, *, options=None, sdf_grid=None, device=-1, export_results=False, n_gpus=1,
+            info=None, pinned_results=True):
     """rho2sdf(taskName, X, IEN, rho; options) -> (fine_sdf, fine_grid, sdf_grid, sdf_dists)
-    src/RhoToSDF.jl:116-242.  `sdf_grid` replaces the interactive prompt of sdf_grid_setup = :manual
-    (Grid_setup.jl:111-154 is out of scope).  fine_grid is returned as (origin, spacing, dims) instead of one
-    heap vector per voxel.  export_results=True writes the final `.vti` like RhoToSDF.jl:230-238 (the .jld2
-    dumps and the optional intermediate exports stay in the Julia package)."""
+    src/RhoToSDF.jl:116-242.  ONE call into the library (r2s_rho2sdf): the mesh goes up once, mesh volume ->
+    nodal densities -> threshold -> raw SDF -> artifact removal -> RBF smoothing run on HBM-resident data, the two
+    result arrays come down once (into pinned arrays from r2s_host_alloc unless pinned_results=False).
+    `sdf_grid` replaces the interactive prompt of sdf_grid_setup = :manual (Grid_setup.jl:111-154 is out of scope).
+    fine_grid is returned as (origin, spacing, dims) instead of one heap vector per voxel.  export_results=True
+    writes the final `.vti` like RhoToSDF.jl:230-238 (the .jld2 dumps stay in the Julia package).  `info` (a dict)
+    receives V_domain, V_frac, rho_t, n_flipped, level_shift, cg_iters, per-stage milliseconds and rho_n."""
     options = options or Rho2sdfOptions()
     mesh = Mesh(X, IEN, options.element_type)
-    V_domain, V_frac = calculate_mesh_volume(mesh, rho, device=device)                      # :128
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    if rho.shape != (mesh.nel,):
+        raise L.R2SError("length of element densities does not match number of elements")
     if sdf_grid is None:
         if options.sdf_grid_setup != "automatic":
             raise L.R2SError("sdf_grid_setup = :manual needs an explicit sdf_grid here")
         sdf_grid = noninteractive_sdf_grid_setup(mesh)                                       # :141-145
-    rho_n = DenseInNodes(mesh, rho, device=device)                                           # :148
-    rho_t = options.threshold_density                                                        # :151-156
-    if rho_t is None:
-        rho_t = find_threshold_for_volume(mesh, rho_n, V_domain * V_frac, device=device)
     smooth = 1 if options.rbf_grid == "same" else 2                                          # :222
-    # raw SDF -> artifact removal -> RBF smoothing stay in HBM (torch tensors only own the buffers); the two
-    # returned arrays are downloaded once each
-    import torch
-    dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else int(device))
-    with torch.cuda.device(dev):
-        dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (mesh.X, mesh.IEN, np.ascontiguousarray(rho_n, dtype=np.float64)))
-        d_sdf = torch.empty(sdf_grid.ngp, dtype=torch.float64, device=dev)
-        plan = DevicePlan(dev.index)
-        try:
-            plan.run(dX, dI, dR, rho_t, sdf_grid, sdf=d_sdf, elem_type=mesh.element_type)    # :169-171
-        finally:
-            plan.close()
-        stream = DevicePlan._stream(None)
-        if options.remove_artifacts:                                                         # :174-208
-            n = ctypes.c_int64()
-            L.check(L.lib().r2s_remove_artifacts_dev(ctypes.c_void_p(d_sdf.data_ptr()), ctypes.byref(sdf_grid.c), 0.0,
-                                                     float(options.artifact_min_component_ratio), stream, ctypes.byref(n)))
-        dims = tuple(int(nn) * smooth + 1 for nn in sdf_grid.c.N)
-        d_fine = torch.empty(dims[0] * dims[1] * dims[2], dtype=torch.float32, device=dev)
-        L.check(L.lib().r2s_rbf_smooth_dev(ctypes.c_void_p(d_sdf.data_ptr()), ctypes.byref(sdf_grid.c),
-                                           int(bool(options.rbf_interp)), int(smooth), 1e-3, float(V_frac * V_domain),
-                                           ctypes.c_void_p(d_fine.data_ptr()), None, None, stream))
-        sdf_dists = d_sdf.cpu().numpy()
-        fine_sdf = d_fine.cpu().numpy().reshape(dims[2], dims[1], dims[0])
+    o = L.R2SOptions()
+    L.lib().r2s_default_options(ctypes.byref(o))
+    if options.threshold_density is not None:                                                # :151-156
+        o.threshold_density = float(options.threshold_density)
+    o.elem_type = mesh.element_type
+    o.rbf_interp = int(bool(options.rbf_interp))
+    o.rbf_smooth = smooth
+    o.remove_artifacts = int(bool(options.remove_artifacts))
+    o.artifact_min_component_ratio = float(options.artifact_min_component_ratio)
+    o.device = int(device)
+    o.n_gpus = int(n_gpus)
+    dims = tuple(int(nn) * smooth + 1 for nn in sdf_grid.c.N)
+    nfine = dims[0] * dims[1] * dims[2]
+    alloc = host_array if pinned_results else (lambda n, dt=np.float64: np.empty(n, dtype=dt))
+    sdf_dists = alloc(sdf_grid.ngp)
+    fine = alloc(nfine, np.float32)
+    rho_n = np.empty(mesh.nnp)
+    ri = L.R2SRunInfo()
+    L.check(L.lib().r2s_rho2sdf(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(rho), ctypes.byref(o),
+                                ctypes.byref(sdf_grid.c), _d(rho_n), None, _d(sdf_dists), _f(fine), ctypes.byref(ri)))
+    if info is not None:
+        info.update(ri.as_dict())
+        info["rho_n"] = rho_n
+    fine_sdf = fine.reshape(dims[2], dims[1], dims[0])
     xmin, xmax = np.float32(sdf_grid.AABB_min[0]), np.float32(sdf_grid.AABB_max[0])
     spacing = (xmax - xmin) / np.float32(fine_sdf.shape[2] - 1)
     fine_grid = (sdf_grid.AABB_min.astype(np.float32), float(spacing), fine_sdf.shape[::-1])

@@ -1,0 +1,620 @@
+// Host-pointer entry points of the C ABI - what the Julia `ccall` layer binds (include/rho2sdf_hip.h):
+//   r2s_eval_distances / r2s_sign_detection / r2s_sdf   the three hot lines of rho2sdf() (RhoToSDF.jl:169-171)
+//   r2s_rho2sdf                                          the whole of rho2sdf() (RhoToSDF.jl:116-242) minus file I/O,
+//                                                        every stage chained in HBM
+//   r2s_host_alloc / r2s_host_free                       pinned result arrays for the caller
+//
+// Everything that costs time but is not work is kept between calls in a per-device session (released by
+// r2s_release_cache): the plan with its work arrays, the device copies of the mesh, the output volumes and two
+// pinned staging buffers.  Results go to the caller by DMA: directly when the destination is pinned
+// (r2s_host_alloc, or registered by the caller), otherwise through the staging buffers in chunks, the next
+// chunk's DMA overlapping a multi-threaded copy of the previous one into the caller's pageable pages.
+//
+// n_gpus > 1 (r2s_params.n_gpus): single process, one host thread per device, interleaved 4-plane tile layers
+// (r2s_params.zstride/zphase); every device sends its layers straight to their place in the caller's array over
+// its own PCIe link, so the host result needs no device-side stitching.  r2s_rho2sdf gathers the layers on device
+// 0 by peer copies over xGMI (hipMemcpyPeerAsync) and post-processes there.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "r2s_common.hpp"
+#include "r2s_internal.hpp"
+
+namespace {
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- a small persistent pool that copies one staged chunk into pageable memory on several cores ----
+class CopyPool {
+  public:
+    explicit CopyPool(int n) : n_(n)
+    {
+        for (int i = 0; i < n_; ++i) th_.emplace_back([this, i] { loop(i); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void copy(void* dst, const void* src, size_t bytes)
+    {
+        if (bytes < (1u << 20) || n_ <= 1) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        std::unique_lock<std::mutex> l(mu_);
+        dst_ = (char*)dst; src_ = (const char*)src; bytes_ = bytes;
+        pending_ = n_;
+        ++gen_;
+        cv_.notify_all();
+        done_.wait(l, [this] { return pending_ == 0; });
+    }
+
+  private:
+    void loop(int id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> l(mu_);
+            cv_.wait(l, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            char* d = dst_;
+            const char* s = src_;
+            const size_t b = bytes_;
+            l.unlock();
+            // 4 KiB-aligned slices: every destination page is first touched by exactly one thread
+            const size_t per = ((b + n_ - 1) / n_ + 4095) & ~(size_t)4095;
+            const size_t lo = std::min(b, per * (size_t)id), hi = std::min(b, per * (size_t)(id + 1));
+            if (hi > lo) memcpy(d + lo, s + lo, hi - lo);
+            l.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+    char* dst_ = nullptr;
+    const char* src_ = nullptr;
+    size_t bytes_ = 0;
+    int pending_ = 0;
+};
+
+constexpr size_t STAGE_BYTES = 32u << 20;
+
+struct HostSession {
+    int device = 0;
+    std::mutex mu;   // one host call at a time per device
+    r2s_plan* plan = nullptr;
+    DevBuf dX, dI, dR, dE;
+    DevBuf out[4];   // dist, sign, sdf, xp
+    DevBuf fine, raw;
+    void* stage[2] = {nullptr, nullptr};
+    hipStream_t cs = nullptr;   // copy stream
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    CopyPool* pool = nullptr;
+
+    int init(int dev)
+    {
+        device = dev;
+        HIP_TRY(hipSetDevice(dev));
+        int rc = r2s_plan_create(dev, &plan);
+        if (rc) return rc;
+        HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        {   // direct xGMI peer copies for the multi-device gather (no-op on a one-GPU box)
+            int n = 0;
+            if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+            for (int d = 0; d < n; ++d) {
+                int can = 0;
+                if (d != dev && hipDeviceCanAccessPeer(&can, dev, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0);
+            }
+            (void)hipGetLastError();
+        }
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipHostMalloc(&stage[i], STAGE_BYTES, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        return 0;
+    }
+    void release()
+    {
+        (void)hipSetDevice(device);
+        if (plan) r2s_plan_destroy(plan);
+        plan = nullptr;
+        DevBuf* all[] = {&dX, &dI, &dR, &dE, &out[0], &out[1], &out[2], &out[3], &fine, &raw};
+        for (DevBuf* b : all) b->release();
+        for (int i = 0; i < 2; ++i) {
+            if (stage[i]) (void)hipHostFree(stage[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            stage[i] = nullptr;
+            ev[i] = nullptr;
+        }
+        if (cs) (void)hipStreamDestroy(cs);
+        cs = nullptr;
+        delete pool;
+        pool = nullptr;
+    }
+};
+
+std::mutex g_sessions_mu;
+std::map<int, HostSession*> g_sessions;
+
+int get_session(int device, HostSession** out)
+{
+    std::lock_guard<std::mutex> l(g_sessions_mu);
+    auto it = g_sessions.find(device);
+    if (it != g_sessions.end()) {
+        *out = it->second;
+        return 0;
+    }
+    HostSession* S = new HostSession();
+    int rc = S->init(device);
+    if (rc) {
+        S->release();
+        delete S;
+        return rc;
+    }
+    g_sessions[device] = S;
+    *out = S;
+    return 0;
+}
+
+bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // ordinary pageable memory: not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+struct Segment {   // one contiguous piece of a result: device source -> host destination
+    char* dst;
+    const char* src;
+    size_t bytes;
+};
+
+// device -> host.  Pinned destination: plain DMA.  Pageable: DMA into the two staging buffers, each staged chunk
+// spread over the pool's threads while the next chunk is in flight.
+int download(HostSession* S, const std::vector<Segment>& segs, bool pinned)
+{
+    if (pinned) {
+        for (const Segment& g : segs)
+            if (g.bytes) HIP_TRY(hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyDeviceToHost, S->cs));
+        HIP_TRY(hipStreamSynchronize(S->cs));
+        return 0;
+    }
+    if (!S->pool) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        S->pool = new CopyPool((int)std::min(8u, std::max(2u, hw / 2)));
+    }
+    std::vector<Segment> chunks;
+    for (const Segment& g : segs)
+        for (size_t o = 0; o < g.bytes; o += STAGE_BYTES)
+            chunks.push_back({g.dst + o, g.src + o, std::min(STAGE_BYTES, g.bytes - o)});
+    const size_t n = chunks.size();
+    if (!n) return 0;
+    HIP_TRY(hipMemcpyAsync(S->stage[0], chunks[0].src, chunks[0].bytes, hipMemcpyDeviceToHost, S->cs));
+    HIP_TRY(hipEventRecord(S->ev[0], S->cs));
+    for (size_t c = 0; c < n; ++c) {
+        if (c + 1 < n) {   // (its staging buffer was drained by the copy of chunk c-1, which has returned)
+            HIP_TRY(hipMemcpyAsync(S->stage[(c + 1) & 1], chunks[c + 1].src, chunks[c + 1].bytes, hipMemcpyDeviceToHost, S->cs));
+            HIP_TRY(hipEventRecord(S->ev[(c + 1) & 1], S->cs));
+        }
+        HIP_TRY(hipEventSynchronize(S->ev[c & 1]));
+        S->pool->copy(chunks[c].dst, S->stage[c & 1], chunks[c].bytes);
+    }
+    return 0;
+}
+
+int upload(void* d, const void* h, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Z partition of one device among G (interleaved 4-plane tile layers, the plan API's zstride/zphase): the
+// segments of its local output in the caller's (nz, ny, nx) array
+void layer_segments(const r2s_grid* grid, int G, int r, const char* d_local, char* h_full, size_t elem_bytes,
+                    std::vector<Segment>& segs, int64_t* local_planes)
+{
+    const int64_t nz = grid->N[2] + 1, plane = (grid->N[0] + 1) * (grid->N[1] + 1);
+    if (G <= 1) {
+        segs.push_back({h_full, d_local, (size_t)(nz * plane) * elem_bytes});
+        if (local_planes) *local_planes = nz;
+        return;
+    }
+    const int64_t layers = (nz + 3) / 4;
+    int64_t li = 0;
+    for (int64_t t = r; t < layers; t += G, ++li) {
+        const int64_t k0 = 4 * t, k1 = std::min<int64_t>(nz, k0 + 4);
+        segs.push_back({h_full + (size_t)(k0 * plane) * elem_bytes, d_local + (size_t)(4 * li * plane) * elem_bytes,
+                        (size_t)((k1 - k0) * plane) * elem_bytes});
+    }
+    if (local_planes) *local_planes = 4 * li;
+}
+
+struct HostCall {
+    const double* X; int64_t nnp; const int64_t* IEN; int64_t nel; const double* rho_n; double rho_t;
+    const r2s_grid* grid; r2s_params prm; int mode;
+    double *dist, *sign, *sdf, *xp;
+};
+
+// one device's share of a host-pointer call
+int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stats, double* ms3 /* upload, run, download */)
+{
+    HostSession* S = nullptr;
+    int rc = get_session(device, &S);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(S->mu);
+    HIP_TRY(hipSetDevice(device));
+    const int nen = c.prm.elem_type == R2S_TET4 ? 4 : 8;
+    const int64_t nz = c.grid->N[2] + 1, plane = (c.grid->N[0] + 1) * (c.grid->N[1] + 1);
+    int64_t owned_planes = nz;
+    if (G > 1) {
+        const int64_t layers = (nz + 3) / 4;
+        if (layers <= r) return 0;   // more devices than tile layers: nothing for this one
+        owned_planes = 4 * ((layers - r + G - 1) / G);
+    }
+    const size_t nvox = (size_t)(owned_planes * plane);
+    const double t0 = now_ms();
+    ENSURE(S->dX, sizeof(double) * 3 * (size_t)c.nnp);
+    ENSURE(S->dR, sizeof(double) * (size_t)c.nnp);
+    ENSURE(S->dI, sizeof(int64_t) * nen * (size_t)c.nel);
+    if ((rc = upload(S->dX.p, c.X, sizeof(double) * 3 * (size_t)c.nnp))) return rc;
+    if ((rc = upload(S->dR.p, c.rho_n, sizeof(double) * (size_t)c.nnp))) return rc;
+    if ((rc = upload(S->dI.p, c.IEN, sizeof(int64_t) * nen * (size_t)c.nel))) return rc;
+    double* host[4] = {c.dist, c.sign, c.sdf, c.xp};
+    const int bits[4] = {R2S_OUT_DIST, R2S_OUT_SIGN, R2S_OUT_SDF, R2S_OUT_XP};
+    for (int i = 0; i < 4; ++i)
+        if (c.mode & bits[i]) {
+            if (S->out[i].ensure_exact(sizeof(double) * (i == 3 ? 3 : 1) * nvox))
+                return fail(R2S_ERR_NOMEM, "hipMalloc of an output volume (%zu voxels) failed", nvox);
+        }
+    r2s_params prm = c.prm;
+    prm.device = device;
+    prm.zstride = G > 1 ? G : 0;
+    prm.zphase = G > 1 ? r : 0;
+    prm.n_gpus = 1;
+    const double t1 = now_ms();
+    rc = r2s_plan_run_dev(S->plan, S->dX.as<double>(), c.nnp, S->dI.as<int64_t>(), c.nel, S->dR.as<double>(), c.rho_t, c.grid,
+                          &prm, 0, nz, c.mode, S->out[0].as<double>(), S->out[1].as<double>(), S->out[2].as<double>(),
+                          S->out[3].as<double>(), nullptr, stats);
+    if (rc) return rc;
+    const double t2 = now_ms();
+    for (int i = 0; i < 4; ++i)
+        if (c.mode & bits[i]) {
+            std::vector<Segment> segs;
+            const size_t eb = sizeof(double) * (i == 3 ? 3 : 1);
+            layer_segments(c.grid, G, r, (const char*)S->out[i].p, (char*)host[i], eb, segs, nullptr);
+            if ((rc = download(S, segs, is_pinned(host[i])))) return rc;
+        }
+    if (ms3) { ms3[0] = t1 - t0; ms3[1] = t2 - t1; ms3[2] = now_ms() - t2; }
+    return 0;
+}
+
+int resolve_device(int device, int* out)
+{
+    int rc = check_device(device < 0 ? 0 : device);
+    if (rc) return rc;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    *out = device;
+    return 0;
+}
+
+int n_gpus_of(const r2s_params& p, int* G)
+{
+    int g = p.n_gpus > 1 ? p.n_gpus : 1;
+    if (g > 1) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        if (g > n) return fail(R2S_ERR_ARG, "n_gpus = %d but only %d HIP device(s) are visible", g, n);
+    }
+    *G = g;
+    return 0;
+}
+
+// runs fn(device index r of G) on G host threads (one per device); first error wins
+int fan_out(int G, const std::function<int(int)>& fn)
+{
+    if (G <= 1) return fn(0);
+    std::vector<int> rcs((size_t)G, 0);
+    std::vector<std::string> errs((size_t)G);
+    std::vector<std::thread> th;
+    for (int r = 0; r < G; ++r)
+        th.emplace_back([&, r] {
+            rcs[(size_t)r] = fn(r);
+            if (rcs[(size_t)r]) errs[(size_t)r] = g_err;   // the error text is thread-local
+        });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < G; ++r)
+        if (rcs[(size_t)r]) return fail(rcs[(size_t)r], "device %d: %s", r, errs[(size_t)r].c_str());
+    return 0;
+}
+
+int run_host(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n, double rho_t,
+             const r2s_grid* grid, const r2s_params* params, int mode, double* dist, double* sign, double* sdf,
+             double* xp, r2s_stats* stats)
+{
+    if (!X || !IEN || !rho_n || !grid) return fail(R2S_ERR_ARG, "null argument");
+    HostCall c{X, nnp, IEN, nel, rho_n, rho_t, grid, {}, mode, dist, sign, sdf, xp};
+    if (params) c.prm = *params; else r2s_default_params(&c.prm);
+    int G = 1, dev0 = 0, rc;
+    if ((rc = resolve_device(c.prm.device, &dev0))) return rc;
+    if ((rc = n_gpus_of(c.prm, &G))) return rc;
+    if (G == 1) return run_host_device(c, dev0, 1, 0, stats, nullptr);
+    // devices 0..G-1; the stats of device 0's share are reported
+    return fan_out(G, [&](int r) { return run_host_device(c, r, G, r, r == 0 ? stats : nullptr, nullptr); });
+}
+
+}  // namespace
+
+namespace r2s_int {
+void release_host_sessions()
+{
+    std::lock_guard<std::mutex> l(g_sessions_mu);
+    for (auto& kv : g_sessions) {
+        std::lock_guard<std::mutex> l2(kv.second->mu);
+        kv.second->release();
+    }
+    for (auto& kv : g_sessions) delete kv.second;
+    g_sessions.clear();
+}
+}  // namespace r2s_int
+
+extern "C" {
+
+void* r2s_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (check_device(0)) return nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(R2S_ERR_NOMEM, "hipHostMalloc of %zu bytes failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void r2s_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+int r2s_eval_distances(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
+                       double rho_t, const r2s_grid* grid, const r2s_params* params, double* dist_out,
+                       double* xp_out, r2s_stats* stats)
+{
+    if (!dist_out) return fail(R2S_ERR_ARG, "dist_out is null");
+    return run_host(X, nnp, IEN, nel, rho_n, rho_t, grid, params, R2S_OUT_DIST | (xp_out ? R2S_OUT_XP : 0),
+                    dist_out, nullptr, nullptr, xp_out, stats);
+}
+
+int r2s_sign_detection(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
+                       double rho_t, const r2s_grid* grid, const r2s_params* params, double* signs_out,
+                       r2s_stats* stats)
+{
+    if (!signs_out) return fail(R2S_ERR_ARG, "signs_out is null");
+    return run_host(X, nnp, IEN, nel, rho_n, rho_t, grid, params, R2S_OUT_SIGN, nullptr, signs_out, nullptr,
+                    nullptr, stats);
+}
+
+int r2s_sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n, double rho_t,
+            const r2s_grid* grid, const r2s_params* params, double* sdf_out, r2s_stats* stats)
+{
+    if (!sdf_out) return fail(R2S_ERR_ARG, "sdf_out is null");
+    return run_host(X, nnp, IEN, nel, rho_n, rho_t, grid, params, R2S_OUT_SDF, nullptr, nullptr, sdf_out,
+                    nullptr, stats);
+}
+
+void r2s_default_options(r2s_options* o)
+{
+    memset(o, 0, sizeof *o);
+    o->threshold_density = NAN;               // Rho2sdfOptions: nothing -> find_threshold_for_volume
+    o->band_factor = 1.1;                     // sdfOnDensityField.jl:158
+    o->artifact_min_component_ratio = 0.01;   // RhoToSDF.jl:33
+    o->rbf_kernel_threshold = 1e-3;           // RBFs4Smoothing.jl:328
+    o->elem_type = R2S_HEX8;
+    o->rbf_interp = 1;
+    o->rbf_smooth = 1;
+    o->remove_artifacts = 1;
+    o->device = -1;
+    o->n_gpus = 1;
+}
+
+int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_e,
+                const r2s_options* options, const r2s_grid* grid, double* rho_n_out, double* sdf_raw_out,
+                double* sdf_dists_out, float* fine_sdf_out, r2s_run_info* info)
+{
+    if (!X || !IEN || !rho_e || !grid || nnp <= 0 || nel <= 0) return fail(R2S_ERR_ARG, "r2s_rho2sdf: null / empty argument");
+    r2s_options o;
+    if (options) o = *options; else r2s_default_options(&o);
+    if (o.elem_type != R2S_HEX8 && o.elem_type != R2S_TET4) return fail(R2S_ERR_UNSUPPORTED, "unknown element type %d", o.elem_type);
+    if (!o.skip_rbf && !fine_sdf_out) return fail(R2S_ERR_ARG, "fine_sdf_out is null (set skip_rbf to stop after the raw SDF)");
+    if (o.rbf_smooth < 1) o.rbf_smooth = 1;
+    int dev0 = 0, rc, G = o.n_gpus > 1 ? o.n_gpus : 1;
+    if ((rc = resolve_device(o.device, &dev0))) return rc;
+    if (G > 1) {
+        r2s_params t;
+        r2s_default_params(&t);
+        t.n_gpus = G;
+        if ((rc = n_gpus_of(t, &G))) return rc;
+        dev0 = 0;
+    }
+    HostSession* S = nullptr;
+    if ((rc = get_session(dev0, &S))) return rc;
+    std::unique_lock<std::mutex> lock(S->mu);
+    HIP_TRY(hipSetDevice(dev0));
+    r2s_run_info ri;
+    memset(&ri, 0, sizeof ri);
+    const double t_start = now_ms();
+    const int nen = o.elem_type == R2S_TET4 ? 4 : 8;
+    const int64_t ngp = grid->ngp;
+    // ---- upload: X, IEN, element densities (RhoToSDF.jl:128) ----
+    ENSURE(S->dX, sizeof(double) * 3 * (size_t)nnp);
+    ENSURE(S->dR, sizeof(double) * (size_t)nnp);
+    ENSURE(S->dE, sizeof(double) * (size_t)nel);
+    ENSURE(S->dI, sizeof(int64_t) * nen * (size_t)nel);
+    if ((rc = upload(S->dX.p, X, sizeof(double) * 3 * (size_t)nnp))) return rc;
+    if ((rc = upload(S->dI.p, IEN, sizeof(int64_t) * nen * (size_t)nel))) return rc;
+    if ((rc = upload(S->dE.p, rho_e, sizeof(double) * (size_t)nel))) return rc;
+    double t = now_ms();
+    ri.ms_upload = t - t_start;
+    // ---- pre-stage: mesh volume (:128), nodal densities (:148), threshold (:151-156) ----
+    if ((rc = r2s_int::mesh_volume_dev(S->dX.as<double>(), S->dI.as<int64_t>(), nel, o.elem_type, S->dE.as<double>(),
+                                       &ri.V_domain, &ri.V_frac)))
+        return rc;
+    if ((rc = r2s_int::dense_in_nodes_dev(S->dX.as<double>(), nnp, S->dI.as<int64_t>(), IEN, nel, o.elem_type,
+                                          S->dE.as<double>(), S->dR.as<double>())))
+        return rc;
+    if (std::isnan(o.threshold_density)) {
+        int it = 0;
+        if ((rc = r2s_int::find_threshold_dev(S->dX.as<double>(), S->dI.as<int64_t>(), nel, o.elem_type, S->dR.as<double>(),
+                                              ri.V_domain * ri.V_frac, 1e-4, 60, &ri.rho_t, &it)))
+            return rc;
+        ri.threshold_iters = it;
+    } else {
+        ri.rho_t = o.threshold_density;
+    }
+    if (rho_n_out) HIP_TRY(hipMemcpy(rho_n_out, S->dR.p, sizeof(double) * (size_t)nnp, hipMemcpyDeviceToHost));
+    double t2 = now_ms();
+    ri.ms_pre = t2 - t;
+    // ---- raw SDF = dists .* signs (:169-171) ----
+    if (S->out[2].ensure_exact(sizeof(double) * (size_t)ngp)) return fail(R2S_ERR_NOMEM, "hipMalloc of the SDF volume failed");
+    r2s_params prm;
+    r2s_default_params(&prm);
+    prm.band_factor = o.band_factor;
+    prm.elem_type = o.elem_type;
+    prm.device = dev0;
+    r2s_stats st;
+    if (G == 1) {
+        if ((rc = r2s_plan_run_dev(S->plan, S->dX.as<double>(), nnp, S->dI.as<int64_t>(), nel, S->dR.as<double>(), ri.rho_t, grid,
+                                   &prm, 0, grid->N[2] + 1, R2S_OUT_SDF, nullptr, nullptr, S->out[2].as<double>(), nullptr,
+                                   nullptr, &st)))
+            return rc;
+    } else {
+        // every device computes its interleaved tile layers from its own copy of (X, IEN, rho_n) and sends them to
+        // their place in device 0's volume over xGMI (peer copies; device 0 writes in place)
+        std::vector<double> h_rn((size_t)nnp);
+        HIP_TRY(hipMemcpy(h_rn.data(), S->dR.p, sizeof(double) * (size_t)nnp, hipMemcpyDeviceToHost));
+        double* d_full = S->out[2].as<double>();
+        lock.unlock();   // device 0's own share takes the session lock again
+        rc = fan_out(G, [&](int r) -> int {
+            HostSession* T = nullptr;
+            int rc2 = get_session(r, &T);
+            if (rc2) return rc2;
+            std::lock_guard<std::mutex> l2(T->mu);
+            HIP_TRY(hipSetDevice(r));
+            const int64_t nz = grid->N[2] + 1, plane = (grid->N[0] + 1) * (grid->N[1] + 1), layers = (nz + 3) / 4;
+            if (layers <= r) return 0;
+            const int64_t owned = 4 * ((layers - r + G - 1) / G);
+            if (r != 0) {
+                ENSURE(T->dX, sizeof(double) * 3 * (size_t)nnp);
+                ENSURE(T->dR, sizeof(double) * (size_t)nnp);
+                ENSURE(T->dI, sizeof(int64_t) * nen * (size_t)nel);
+                if ((rc2 = upload(T->dX.p, X, sizeof(double) * 3 * (size_t)nnp))) return rc2;
+                if ((rc2 = upload(T->dI.p, IEN, sizeof(int64_t) * nen * (size_t)nel))) return rc2;
+                if ((rc2 = upload(T->dR.p, h_rn.data(), sizeof(double) * (size_t)nnp))) return rc2;
+            }
+            if (T->raw.ensure_exact(sizeof(double) * (size_t)(owned * plane))) return fail(R2S_ERR_NOMEM, "hipMalloc failed");
+            r2s_params p2 = prm;
+            p2.device = r;
+            p2.zstride = G;
+            p2.zphase = r;
+            r2s_stats st2;
+            if ((rc2 = r2s_plan_run_dev(T->plan, T->dX.as<double>(), nnp, T->dI.as<int64_t>(), nel, T->dR.as<double>(), ri.rho_t,
+                                        grid, &p2, 0, nz, R2S_OUT_SDF, nullptr, nullptr, T->raw.as<double>(), nullptr, nullptr,
+                                        &st2)))
+                return rc2;
+            if (r == 0) st = st2;
+            int64_t li = 0;
+            for (int64_t tl = r; tl < layers; tl += G, ++li) {
+                const int64_t k0 = 4 * tl, k1 = std::min<int64_t>(nz, k0 + 4);
+                HIP_TRY(hipMemcpyPeerAsync(d_full + k0 * plane, 0, T->raw.as<double>() + 4 * li * plane, r,
+                                           sizeof(double) * (size_t)((k1 - k0) * plane), T->cs));
+            }
+            HIP_TRY(hipStreamSynchronize(T->cs));
+            return 0;
+        });
+        lock.lock();
+        HIP_TRY(hipSetDevice(dev0));
+        if (rc) return rc;
+    }
+    double t3 = now_ms();
+    ri.ms_sdf = t3 - t2;
+    ri.ms_sdf_kernels = st.ms_prep + st.ms_bins + st.ms_main + st.ms_gather;
+    const bool pin_d = sdf_dists_out && is_pinned(sdf_dists_out);
+    if (sdf_raw_out) {   // the field before artifact removal (export_analysis, RhoToSDF.jl:181-189)
+        std::vector<Segment> segs{{(char*)sdf_raw_out, (const char*)S->out[2].p, sizeof(double) * (size_t)ngp}};
+        if ((rc = download(S, segs, is_pinned(sdf_raw_out)))) return rc;
+    }
+    // ---- artifact removal (:174-208) ----
+    if (o.remove_artifacts) {
+        if ((rc = r2s_int::remove_artifacts_dev(S->out[2].as<double>(), grid, 0.0, o.artifact_min_component_ratio, nullptr,
+                                                &ri.n_flipped)))
+            return rc;
+    }
+    double t4 = now_ms();
+    ri.ms_artifacts = t4 - t3;
+    // the cleaned field starts its way to the host while the smoothing runs (pinned destination: one DMA)
+    bool dists_in_flight = false;
+    if (sdf_dists_out && pin_d) {
+        HIP_TRY(hipMemcpyAsync(sdf_dists_out, S->out[2].p, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost, S->cs));
+        dists_in_flight = true;
+    }
+    // ---- RBF smoothing (:222-224) ----
+    size_t nfine = 0;
+    if (!o.skip_rbf) {
+        nfine = 1;
+        for (int i = 0; i < 3; ++i) nfine *= (size_t)(grid->N[i] * o.rbf_smooth + 1);
+        if (S->fine.ensure_exact(sizeof(float) * nfine)) return fail(R2S_ERR_NOMEM, "hipMalloc of the fine grid failed");
+        int its = 0;
+        if ((rc = r2s_int::rbf_smooth_dev(S->out[2].as<double>(), grid, o.rbf_interp, o.rbf_smooth, o.rbf_kernel_threshold,
+                                          ri.V_frac * ri.V_domain, S->fine.as<float>(), &ri.level_shift, &its)))
+            return rc;
+        ri.cg_iters = its;
+    }
+    double t5 = now_ms();
+    ri.ms_rbf = t5 - t4;
+    // ---- results to the caller ----
+    if (sdf_dists_out && !dists_in_flight) {
+        std::vector<Segment> segs{{(char*)sdf_dists_out, (const char*)S->out[2].p, sizeof(double) * (size_t)ngp}};
+        if ((rc = download(S, segs, false))) return rc;
+    }
+    if (!o.skip_rbf) {
+        std::vector<Segment> segs{{(char*)fine_sdf_out, (const char*)S->fine.p, sizeof(float) * nfine}};
+        if ((rc = download(S, segs, is_pinned(fine_sdf_out)))) return rc;
+    }
+    if (dists_in_flight) HIP_TRY(hipStreamSynchronize(S->cs));
+    const double t6 = now_ms();
+    ri.ms_download = t6 - t5;
+    ri.ms_total = t6 - t_start;
+    if (info) *info = ri;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// Cross-file internals of the library (C++ linkage, not part of the C ABI): device-pointer forms of the
+// pre-stage and post-processing stages, used by the host-pointer entry points of their own files and by the
+// chained r2s_rho2sdf() in r2s_host.hip.  All of them run on the CURRENT device and are synchronous on return.
+#pragma once
+#include <cstdint>
+
+#include "r2s_common.hpp"
+
+namespace r2s_int {
+
+// calculate_mesh_volume (MeshVolume.jl:4-42): d_rho_e[nel] element densities
+int mesh_volume_dev(const double* dX, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_e,
+                    double* V_domain, double* V_frac);
+
+// DenseInNodes (NodalDensities.jl:89-218); hIEN is the HOST copy of the connectivity (the ascending node ->
+// element lists are built on the host, mesh-sized)
+int dense_in_nodes_dev(const double* dX, int64_t nnp, const int64_t* dIEN, const int64_t* hIEN, int64_t nel,
+                       int elem_type, const double* d_rho_e, double* d_rho_n_out);
+
+// find_threshold_for_volume (Isocontour_volume.jl:77-154); TET4: the same bisection over the TET4 iso-volume
+// (the reference has none, SURVEY 8(f)2 - see r2s_pre.hip)
+int find_threshold_dev(const double* dX, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_n,
+                       double target_volume, double tol, int maxit, double* rho_t_out, int* iters_out);
+
+// calculate_isocontour_volume (Isocontour_volume.jl:1-75) at one threshold
+int isocontour_volume_dev(const double* dX, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_n,
+                          double thr, double* volume_out);
+
+// remove_sdf_artifacts! on a device-resident field (SdfArtifactRemoval.jl:134-245)
+int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, double min_ratio, hipStream_t st,
+                         int64_t* n_flipped);
+
+// RBFs_smoothing with device-resident input / output (RBFs4Smoothing.jl:321-377)
+int rbf_smooth_dev(const double* d_sdf, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
+                   float* d_fine_out, float* th_out, int* cg_iters);
+
+// frees the cached per-device host sessions (r2s_host.hip); called by r2s_release_cache()
+void release_host_sessions();
+
+}  // namespace r2s_int

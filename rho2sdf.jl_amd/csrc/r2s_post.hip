@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "r2s_common.hpp"
+#include "r2s_internal.hpp"
 
 // ====================================================================================
 // connected components of {sdf >= threshold}, 6-connectivity: lock-free union-find with
@@ -862,6 +863,19 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     return 0;
 }
 
+namespace r2s_int {
+int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, double min_ratio, hipStream_t st,
+                         int64_t* n_flipped)
+{
+    return ::remove_artifacts_dev(d_sdf, g, threshold, min_ratio, st, n_flipped);
+}
+int rbf_smooth_dev(const double* d_sdf, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
+                   float* d_fine_out, float* th_out, int* cg_iters)
+{
+    return rbf_smooth_host(d_sdf, g, is_interp, smooth, kthr, target_volume, d_fine_out, th_out, cg_iters, nullptr, true, true);
+}
+}  // namespace r2s_int
+
 extern "C" {
 
 int r2s_remove_artifacts(double* sdf_inout, const r2s_grid* grid, double threshold, double min_ratio, int32_t device,
@@ -940,8 +954,11 @@ int r2s_rbf_smooth_dev(const double* d_sdf, const r2s_grid* grid, int32_t is_int
 /* frees the process-wide work buffers kept between calls (the materialised RBF matrix) */
 void r2s_release_cache(void)
 {
-    std::lock_guard<std::mutex> lock(g_rbf_kv_mutex);
-    g_rbf_kv.release();
+    {
+        std::lock_guard<std::mutex> lock(g_rbf_kv_mutex);
+        g_rbf_kv.release();
+    }
+    r2s_int::release_host_sessions();
 }
 
 }  // extern "C"

@@ -11,6 +11,7 @@
 
 #include "r2s_common.hpp"
 #include "r2s_device_math.hpp"
+#include "r2s_internal.hpp"
 
 using namespace r2s;
 
@@ -121,6 +122,62 @@ __global__ void tet_volume_kernel(const double* __restrict__ X, const int64_t* _
                 v += g3.gw[i] * g3.gw[j] * g3.gw[k] * adet * jt;
             }
     vol[e] = v;
+}
+
+// TET4 iso-volume (the reference has none: calculate_isocontour_volume hard-codes 8 nodes, Isocontour_volume.jl:27-38;
+// SURVEY 8(f)2).  Built from the reference's own pieces so that volume(thr = 0) equals calculate_mesh_volume's
+// V_domain for TET4 (which the target V_domain*V_frac is expressed in): the classification of :40-52 (skip /
+// whole element / cut element) with the collapsed-cube rule of MeshVolume.jl:75-117 - 3^3 points for whole
+// elements, 15^3 points with the point test N(xi).rho_e >= thr (:62-64) for cut ones, the same
+// `jacobian_transform` (and with it the same 25 % deficit) in both.  One wavefront per element, lanes split the
+// points, fixed butterfly.
+__global__ void __launch_bounds__(256) tet_iso_volume_kernel(const double* __restrict__ X, const int64_t* __restrict__ IEN,
+                                                            const double* __restrict__ rho_n, int64_t nel, double thr,
+                                                            GaussTab g3, GaussTab g15, double* __restrict__ vol)
+{
+    const int64_t e = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (e >= nel) return;
+    const int lane = threadIdx.x & 63;
+    double xe[4][3], re[4], J[3][3], mn = INFINITY, mx = -INFINITY;
+    for (int a = 0; a < 4; ++a) {
+        const int64_t n = IEN[e * 4 + a] - 1;
+        for (int i = 0; i < 3; ++i) xe[a][i] = X[3 * n + i];
+        re[a] = rho_n[n];
+        mn = fmin(mn, re[a]);
+        mx = fmax(mx, re[a]);
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (int a = 0; a < 4; ++a) {
+                const double dn = (a == c) ? 1.0 : ((a == 3) ? -1.0 : 0.0);
+                s += xe[a][r] * dn;
+            }
+            J[r][c] = s;
+        }
+    const double adet = fabs(det3(J));
+    double acc = 0.0;
+    if (!(mx < thr)) {
+        const bool whole = mn >= thr;
+        const int n = whole ? 3 : 15;
+        const GaussTab& g = whole ? g3 : g15;
+        for (int p = lane; p < n * n * n; p += 64) {
+            const int i = p % n, j = (p / n) % n, k = p / (n * n);
+            const double xi = (g.gp[i] + 1.0) / 2.0;
+            const double eta = (g.gp[j] + 1.0) / 2.0 * (1.0 - xi);
+            const double zeta = (g.gp[k] + 1.0) / 2.0 * (1.0 - xi - eta);
+            if (xi < 0 || eta < 0 || zeta < 0 || xi + eta + zeta > 1.0) continue;
+            if (!whole) {   // N = [xi, eta, zeta, 1 - xi - eta - zeta] (ShapeFunctions.jl:53-72)
+                const double v = xi * re[0] + eta * re[1] + zeta * re[2] + (1.0 - xi - eta - zeta) * re[3];
+                if (v < thr) continue;
+            }
+            const double jt = (1.0 - xi) * (1.0 - xi) * (1.0 - xi - eta) / 8.0;
+            acc += g.gw[i] * g.gw[j] * g.gw[k] * adet * jt;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) vol[e] = acc;
 }
 
 // sums v[i] and v[i]*s[i] (s may be null) in a fixed order: grid-stride partials, block tree
@@ -354,6 +411,121 @@ static void tables(GaussTab& g3, GaussTab& g15)
     r2s_internal_gauss_legendre(15, g15.gp, g15.gw);
 }
 
+// ---- device-pointer forms (current device; synchronous) -------------------------------------------------
+namespace r2s_int {
+
+int mesh_volume_dev(const double* dX, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_e,
+                    double* V_domain, double* V_frac)
+{
+    DevBuf vol, part;
+    GaussTab g3, g15;
+    tables(g3, g15);
+    auto done = [&](int r) { vol.release(); part.release(); return r; };
+    if (vol.ensure(sizeof(double) * (size_t)nel)) return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
+    if (elem_type == R2S_HEX8)
+        elem_volume_kernel<<<(unsigned)((nel + 3) / 4), 256>>>(dX, dIEN, nullptr, nel, 0, 0.0, g3, g15, vol.as<double>());
+    else
+        tet_volume_kernel<<<(unsigned)((nel + 255) / 256), 256>>>(dX, dIEN, nel, g3, vol.as<double>());
+    double s[2];
+    int rc = sum2(vol.as<double>(), d_rho_e, nel, part, s);
+    if (rc) return done(rc);
+    *V_domain = s[0];
+    *V_frac = s[1] / s[0];   // MeshVolume.jl:41
+    return done(0);
+}
+
+int dense_in_nodes_dev(const double* dX, int64_t nnp, const int64_t* dIEN, const int64_t* hIEN, int64_t nel,
+                       int elem_type, const double* d_rho_e, double* d_rho_n_out)
+{
+    const int nen = elem_type == R2S_HEX8 ? 8 : 4;
+    std::vector<uint32_t> ptr, ine;
+    int rc = build_ine_host(hIEN, nel, nen, nnp, ptr, ine);
+    if (rc) return rc;
+    DevBuf dptr, dine, C;
+    auto done = [&](int r) { dptr.release(); dine.release(); C.release(); return r; };
+    if (dptr.ensure(4 * ptr.size()) || dine.ensure(4 * ine.size()) || C.ensure(sizeof(double) * 3 * (size_t)nel))
+        return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
+    if (hipMemcpy(dptr.p, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dine.p, ine.data(), 4 * ine.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(R2S_ERR_HIP, "hipMemcpy failed"));
+    centroid_kernel<<<(unsigned)((nel + 255) / 256), 256>>>(dX, dIEN, nel, nen, C.as<double>());
+    dense_in_nodes_kernel<<<(unsigned)((nnp + 127) / 128), 128>>>(dX, nnp, dptr.as<uint32_t>(), dine.as<uint32_t>(),
+                                                                 C.as<double>(), d_rho_e, d_rho_n_out);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return done(fail(R2S_ERR_HIP, "dense_in_nodes kernels failed: %s", hipGetErrorString(e)));
+    return done(0);
+}
+
+struct IsoVolume {   // calculate_isocontour_volume (:1-75) for a sequence of thresholds
+    const double* dX;
+    const int64_t* dIEN;
+    int64_t nel;
+    int elem_type;
+    const double* d_rho_n;
+    DevBuf vol, part;
+    GaussTab g3, g15;
+    int init()
+    {
+        tables(g3, g15);
+        if (vol.ensure(sizeof(double) * (size_t)nel)) return fail(R2S_ERR_NOMEM, "hipMalloc failed");
+        return 0;
+    }
+    int run(double thr, double* out)
+    {
+        if (elem_type == R2S_HEX8)
+            elem_volume_kernel<<<(unsigned)((nel + 3) / 4), 256>>>(dX, dIEN, d_rho_n, nel, 1, thr, g3, g15, vol.as<double>());
+        else
+            tet_iso_volume_kernel<<<(unsigned)((nel + 3) / 4), 256>>>(dX, dIEN, d_rho_n, nel, thr, g3, g15, vol.as<double>());
+        double s[2] = {0, 0};
+        int rc = sum2(vol.as<double>(), nullptr, nel, part, s);
+        *out = s[0];
+        return rc;
+    }
+    void release() { vol.release(); part.release(); }
+};
+
+int isocontour_volume_dev(const double* dX, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_n,
+                          double thr, double* volume_out)
+{
+    IsoVolume iv{dX, dIEN, nel, elem_type, d_rho_n};
+    int rc = iv.init();
+    if (!rc) rc = iv.run(thr, volume_out);
+    iv.release();
+    return rc;
+}
+
+int find_threshold_dev(const double* dX, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_n,
+                       double target_volume, double tol, int maxit, double* rho_t_out, int* iters_out)
+{
+    IsoVolume iv{dX, dIEN, nel, elem_type, d_rho_n};
+    int rc = iv.init();
+    auto done = [&](int r) { iv.release(); return r; };
+    if (rc) return done(rc);
+    double lo = 0.0, hi = 1.0, vmin = 0.0, vmax = 0.0;
+    if ((rc = iv.run(hi, &vmin)) || (rc = iv.run(lo, &vmax))) return done(rc);
+    if (target_volume > vmax || target_volume < vmin)   // Isocontour_volume.jl:93-95
+        return done(fail(R2S_ERR_ARG, "Requested volume %.17g is outside the possible range [%.17g, %.17g]",
+                         target_volume, vmin, vmax));
+    int it = 0;
+    double best = 0.0, best_err = INFINITY;
+    while (it < maxit) {
+        const double thr = (lo + hi) / 2;
+        double v = 0.0;
+        if ((rc = iv.run(thr, &v))) return done(rc);
+        const double e = std::fabs(v - target_volume) / target_volume;
+        if (e < best_err) { best = thr; best_err = e; }
+        if (e < tol) break;
+        if (v > target_volume) lo = thr; else hi = thr;
+        it++;
+    }
+    *rho_t_out = best;
+    if (iters_out) *iters_out = it;
+    return done(0);
+}
+
+}  // namespace r2s_int
+
 extern "C" {
 
 int r2s_mesh_volume(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, int32_t elem_type,
@@ -365,103 +537,89 @@ int r2s_mesh_volume(const double* X, int64_t nnp, const int64_t* IEN, int64_t ne
     int rc = use_device(device);
     if (rc) return rc;
     MeshDev m;
-    DevBuf vol, rho, part;
-    GaussTab g3, g15;
-    tables(g3, g15);
-    auto done = [&](int r) { m.release(); vol.release(); rho.release(); part.release(); return r; };
+    DevBuf rho;
+    auto done = [&](int r) { m.release(); rho.release(); return r; };
     if ((rc = upload_mesh(m, X, nnp, IEN, nel, nen))) return done(rc);
-    if (vol.ensure(sizeof(double) * (size_t)nel) || rho.ensure(sizeof(double) * (size_t)nel))
-        return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
+    if (rho.ensure(sizeof(double) * (size_t)nel)) return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
     if (hipMemcpy(rho.p, rho_e, sizeof(double) * (size_t)nel, hipMemcpyHostToDevice) != hipSuccess)
         return done(fail(R2S_ERR_HIP, "hipMemcpy failed"));
-    if (elem_type == R2S_HEX8)
-        elem_volume_kernel<<<(unsigned)((nel + 3) / 4), 256>>>(m.X.as<double>(), m.IEN.as<int64_t>(), nullptr, nel, 0,
-                                                              0.0, g3, g15, vol.as<double>());
-    else
-        tet_volume_kernel<<<(unsigned)((nel + 255) / 256), 256>>>(m.X.as<double>(), m.IEN.as<int64_t>(), nel, g3,
-                                                                 vol.as<double>());
-    double s[2];
-    if ((rc = sum2(vol.as<double>(), rho.as<double>(), nel, part, s))) return done(rc);
-    *V_domain = s[0];
-    *V_frac = s[1] / s[0];   // MeshVolume.jl:41
-    return done(0);
+    return done(r2s_int::mesh_volume_dev(m.X.as<double>(), m.IEN.as<int64_t>(), nel, elem_type, rho.as<double>(), V_domain, V_frac));
 }
 
 int r2s_dense_in_nodes(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, int32_t elem_type,
                        const double* rho_e, int32_t device, double* rho_n_out)
 {
     if (!X || !IEN || !rho_e || !rho_n_out || nnp <= 0 || nel <= 0) return fail(R2S_ERR_ARG, "bad argument");
+    if (elem_type != R2S_HEX8 && elem_type != R2S_TET4) return fail(R2S_ERR_UNSUPPORTED, "unknown element type %d", elem_type);
     const int nen = elem_type == R2S_HEX8 ? 8 : 4;
     int rc = use_device(device);
     if (rc) return rc;
-    std::vector<uint32_t> ptr, ine;
-    if ((rc = build_ine_host(IEN, nel, nen, nnp, ptr, ine))) return rc;
     MeshDev m;
-    DevBuf dptr, dine, C, rho, out;
-    auto done = [&](int r) { m.release(); dptr.release(); dine.release(); C.release(); rho.release(); out.release(); return r; };
+    DevBuf rho, out;
+    auto done = [&](int r) { m.release(); rho.release(); out.release(); return r; };
     if ((rc = upload_mesh(m, X, nnp, IEN, nel, nen))) return done(rc);
-    if (dptr.ensure(4 * ptr.size()) || dine.ensure(4 * ine.size()) || C.ensure(sizeof(double) * 3 * (size_t)nel) ||
-        rho.ensure(sizeof(double) * (size_t)nel) || out.ensure(sizeof(double) * (size_t)nnp))
+    if (rho.ensure(sizeof(double) * (size_t)nel) || out.ensure(sizeof(double) * (size_t)nnp))
         return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
-    if (hipMemcpy(dptr.p, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dine.p, ine.data(), 4 * ine.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(rho.p, rho_e, sizeof(double) * (size_t)nel, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(rho.p, rho_e, sizeof(double) * (size_t)nel, hipMemcpyHostToDevice) != hipSuccess)
         return done(fail(R2S_ERR_HIP, "hipMemcpy failed"));
-    centroid_kernel<<<(unsigned)((nel + 255) / 256), 256>>>(m.X.as<double>(), m.IEN.as<int64_t>(), nel, nen, C.as<double>());
-    dense_in_nodes_kernel<<<(unsigned)((nnp + 127) / 128), 128>>>(m.X.as<double>(), nnp, dptr.as<uint32_t>(),
-                                                                 dine.as<uint32_t>(), C.as<double>(), rho.as<double>(),
-                                                                 out.as<double>());
+    if ((rc = r2s_int::dense_in_nodes_dev(m.X.as<double>(), nnp, m.IEN.as<int64_t>(), IEN, nel, elem_type, rho.as<double>(),
+                                          out.as<double>())))
+        return done(rc);
     if (hipMemcpy(rho_n_out, out.p, sizeof(double) * (size_t)nnp, hipMemcpyDeviceToHost) != hipSuccess)
-        return done(fail(R2S_ERR_HIP, "kernel or copy failed: %s", hipGetErrorString(hipGetLastError())));
+        return done(fail(R2S_ERR_HIP, "copy failed: %s", hipGetErrorString(hipGetLastError())));
     return done(0);
+}
+
+static int upload_nodal(MeshDev& m, DevBuf& rho, const double* X, int64_t nnp, const int64_t* IEN, int64_t nel,
+                        int32_t elem_type, const double* rho_n)
+{
+    const int nen = elem_type == R2S_HEX8 ? 8 : 4;
+    int rc = upload_mesh(m, X, nnp, IEN, nel, nen);
+    if (rc) return rc;
+    ENSURE(rho, sizeof(double) * (size_t)nnp);
+    HIP_TRY(hipMemcpy(rho.p, rho_n, sizeof(double) * (size_t)nnp, hipMemcpyHostToDevice));
+    return 0;
 }
 
 int r2s_find_threshold(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
                        double target_volume, double tol, int32_t maxit, int32_t device, double* rho_t_out,
                        int32_t* iters_out)
 {
+    return r2s_find_threshold_et(X, nnp, IEN, nel, R2S_HEX8, rho_n, target_volume, tol, maxit, device, rho_t_out, iters_out);
+}
+
+int r2s_find_threshold_et(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, int32_t elem_type,
+                          const double* rho_n, double target_volume, double tol, int32_t maxit, int32_t device,
+                          double* rho_t_out, int32_t* iters_out)
+{
     if (!X || !IEN || !rho_n || !rho_t_out || nnp <= 0 || nel <= 0) return fail(R2S_ERR_ARG, "bad argument");
+    if (elem_type != R2S_HEX8 && elem_type != R2S_TET4) return fail(R2S_ERR_UNSUPPORTED, "unknown element type %d", elem_type);
     int rc = use_device(device);
     if (rc) return rc;
     MeshDev m;
-    DevBuf vol, rho, part;
-    GaussTab g3, g15;
-    tables(g3, g15);
-    auto done = [&](int r) { m.release(); vol.release(); rho.release(); part.release(); return r; };
-    if ((rc = upload_mesh(m, X, nnp, IEN, nel, 8))) return done(rc);
-    if (vol.ensure(sizeof(double) * (size_t)nel) || rho.ensure(sizeof(double) * (size_t)nnp))
-        return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
-    if (hipMemcpy(rho.p, rho_n, sizeof(double) * (size_t)nnp, hipMemcpyHostToDevice) != hipSuccess)
-        return done(fail(R2S_ERR_HIP, "hipMemcpy failed"));
-    int err = 0;
-    auto volume = [&](double thr) -> double {   // calculate_isocontour_volume (:1-75)
-        elem_volume_kernel<<<(unsigned)((nel + 3) / 4), 256>>>(m.X.as<double>(), m.IEN.as<int64_t>(), rho.as<double>(), nel,
-                                                              1, thr, g3, g15, vol.as<double>());
-        double s[2] = {0, 0};
-        if (sum2(vol.as<double>(), nullptr, nel, part, s)) err = 1;
-        return s[0];
-    };
-    double lo = 0.0, hi = 1.0;
-    const double vmin = volume(hi), vmax = volume(lo);
-    if (err) return done(R2S_ERR_HIP);
-    if (target_volume > vmax || target_volume < vmin)   // Isocontour_volume.jl:93-95
-        return done(fail(R2S_ERR_ARG, "Requested volume %.17g is outside the possible range [%.17g, %.17g]",
-                         target_volume, vmin, vmax));
+    DevBuf rho;
+    auto done = [&](int r) { m.release(); rho.release(); return r; };
+    if ((rc = upload_nodal(m, rho, X, nnp, IEN, nel, elem_type, rho_n))) return done(rc);
     int it = 0;
-    double best = 0.0, best_err = INFINITY;
-    while (it < maxit) {
-        const double thr = (lo + hi) / 2;
-        const double v = volume(thr);
-        if (err) return done(R2S_ERR_HIP);
-        const double e = std::fabs(v - target_volume) / target_volume;
-        if (e < best_err) { best = thr; best_err = e; }
-        if (e < tol) break;
-        if (v > target_volume) lo = thr; else hi = thr;
-        it++;
-    }
-    *rho_t_out = best;
+    rc = r2s_int::find_threshold_dev(m.X.as<double>(), m.IEN.as<int64_t>(), nel, elem_type, rho.as<double>(), target_volume,
+                                     tol, maxit, rho_t_out, &it);
     if (iters_out) *iters_out = it;
-    return done(0);
+    return done(rc);
+}
+
+int r2s_isocontour_volume(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, int32_t elem_type,
+                          const double* rho_n, double threshold, int32_t device, double* volume_out)
+{
+    if (!X || !IEN || !rho_n || !volume_out || nnp <= 0 || nel <= 0) return fail(R2S_ERR_ARG, "bad argument");
+    if (elem_type != R2S_HEX8 && elem_type != R2S_TET4) return fail(R2S_ERR_UNSUPPORTED, "unknown element type %d", elem_type);
+    int rc = use_device(device);
+    if (rc) return rc;
+    MeshDev m;
+    DevBuf rho;
+    auto done = [&](int r) { m.release(); rho.release(); return r; };
+    if ((rc = upload_nodal(m, rho, X, nnp, IEN, nel, elem_type, rho_n))) return done(rc);
+    return done(r2s_int::isocontour_volume_dev(m.X.as<double>(), m.IEN.as<int64_t>(), nel, elem_type, rho.as<double>(),
+                                               threshold, volume_out));
 }
 
 }  // extern "C"

@@ -2321,55 +2321,6 @@ int r2s_plan_run_dev(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* 
     return fail(R2S_ERR_UNSUPPORTED, "unknown element type %d", et);
 }
 
-// ---- host-pointer entry points (what the Julia wrapper ccalls) ------------------------
-static int run_host(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
-                    double rho_t, const r2s_grid* grid, const r2s_params* params, int mode, double* dist,
-                    double* sign, double* sdf, double* xp, r2s_stats* stats)
-{
-    if (!X || !IEN || !rho_n || !grid) return fail(R2S_ERR_ARG, "null argument");
-    r2s_params prm;
-    if (params) prm = *params; else r2s_default_params(&prm);
-    r2s_plan* P = nullptr;
-    int rc = r2s_plan_create(prm.device, &P);
-    if (rc) return rc;
-    const int64_t ngp = grid->ngp;
-    double *dX = nullptr, *dR = nullptr, *dD = nullptr, *dS = nullptr, *dF = nullptr, *dP = nullptr;
-    int64_t* dI = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(dX); (void)hipFree(dR); (void)hipFree(dI); (void)hipFree(dD); (void)hipFree(dS);
-        (void)hipFree(dF); (void)hipFree(dP);
-        r2s_plan_destroy(P);
-    };
-#define HIP_TRY_C(expr)                                                                       \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) {                                                               \
-            cleanup();                                                                        \
-            return fail(R2S_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
-        }                                                                                     \
-    } while (0)
-    HIP_TRY_C(hipMalloc((void**)&dX, sizeof(double) * 3 * (size_t)nnp));
-    HIP_TRY_C(hipMalloc((void**)&dR, sizeof(double) * (size_t)nnp));
-    const int nen = prm.elem_type == R2S_TET4 ? 4 : 8;
-    HIP_TRY_C(hipMalloc((void**)&dI, sizeof(int64_t) * nen * (size_t)nel));
-    HIP_TRY_C(hipMemcpy(dX, X, sizeof(double) * 3 * (size_t)nnp, hipMemcpyHostToDevice));
-    HIP_TRY_C(hipMemcpy(dR, rho_n, sizeof(double) * (size_t)nnp, hipMemcpyHostToDevice));
-    HIP_TRY_C(hipMemcpy(dI, IEN, sizeof(int64_t) * nen * (size_t)nel, hipMemcpyHostToDevice));
-    if (mode & R2S_OUT_DIST) HIP_TRY_C(hipMalloc((void**)&dD, sizeof(double) * (size_t)ngp));
-    if (mode & R2S_OUT_SIGN) HIP_TRY_C(hipMalloc((void**)&dS, sizeof(double) * (size_t)ngp));
-    if (mode & R2S_OUT_SDF) HIP_TRY_C(hipMalloc((void**)&dF, sizeof(double) * (size_t)ngp));
-    if (mode & R2S_OUT_XP) HIP_TRY_C(hipMalloc((void**)&dP, sizeof(double) * 3 * (size_t)ngp));
-    rc = r2s_plan_run_dev(P, dX, nnp, dI, nel, dR, rho_t, grid, &prm, 0, grid->N[2] + 1, mode, dD, dS, dF, dP,
-                          nullptr, stats);
-    if (rc) { cleanup(); return rc; }
-    if (mode & R2S_OUT_DIST) HIP_TRY_C(hipMemcpy(dist, dD, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost));
-    if (mode & R2S_OUT_SIGN) HIP_TRY_C(hipMemcpy(sign, dS, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost));
-    if (mode & R2S_OUT_SDF) HIP_TRY_C(hipMemcpy(sdf, dF, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost));
-    if (mode & R2S_OUT_XP) HIP_TRY_C(hipMemcpy(xp, dP, sizeof(double) * 3 * (size_t)ngp, hipMemcpyDeviceToHost));
-    cleanup();
-    return 0;
-}
-
 int r2s_plan_pack_tiles_dev(r2s_plan* P, const double* d_local, double* d_payload, uint32_t* d_ids,
                             int64_t capacity_tiles, int64_t* n_tiles_out, void* stream)
 {
@@ -2441,32 +2392,6 @@ int r2s_fill_dev(double* d, int64_t n, double value, void* stream)
     if (n) fill_kernel<<<256 * 8, 256, 0, (hipStream_t)stream>>>(d, n, value);
     HIP_TRY(hipGetLastError());
     return 0;
-}
-
-int r2s_eval_distances(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
-                       double rho_t, const r2s_grid* grid, const r2s_params* params, double* dist_out,
-                       double* xp_out, r2s_stats* stats)
-{
-    if (!dist_out) return fail(R2S_ERR_ARG, "dist_out is null");
-    return run_host(X, nnp, IEN, nel, rho_n, rho_t, grid, params, R2S_OUT_DIST | (xp_out ? R2S_OUT_XP : 0),
-                    dist_out, nullptr, nullptr, xp_out, stats);
-}
-
-int r2s_sign_detection(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
-                       double rho_t, const r2s_grid* grid, const r2s_params* params, double* signs_out,
-                       r2s_stats* stats)
-{
-    if (!signs_out) return fail(R2S_ERR_ARG, "signs_out is null");
-    return run_host(X, nnp, IEN, nel, rho_n, rho_t, grid, params, R2S_OUT_SIGN, nullptr, signs_out, nullptr,
-                    nullptr, stats);
-}
-
-int r2s_sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n, double rho_t,
-            const r2s_grid* grid, const r2s_params* params, double* sdf_out, r2s_stats* stats)
-{
-    if (!sdf_out) return fail(R2S_ERR_ARG, "sdf_out is null");
-    return run_host(X, nnp, IEN, nel, rho_n, rho_t, grid, params, R2S_OUT_SDF, nullptr, nullptr, sdf_out,
-                    nullptr, stats);
 }
 
 }  // extern "C"
