@@ -343,7 +343,7 @@ def main():
             sent = np.abs(want) > 1e9
             real = ~sent
             rel = np.abs(got[real] - want[real]) / np.maximum(np.abs(want[real]), 1e-300)
-            out["check"] = {"against": "CPU oracle (oracle/r2s_oracle.c), Z planes k % %d == 0" % args.cpu_stride,
+            out["check"] = {"against": f"CPU oracle (oracle/r2s_oracle.c), Z planes k % {args.cpu_stride} == 0",
                             "voxels": int(want.size), "sentinel_mismatch": int((sent != (np.abs(got) > 1e9)).sum()),
                             "sign_mismatch": int((np.sign(got) != np.sign(want)).sum()),
                             "max_rel_err": float(rel.max()) if rel.size else 0.0,

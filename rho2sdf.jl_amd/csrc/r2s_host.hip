@@ -21,6 +21,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -161,10 +162,29 @@ struct HostSession {
 std::mutex g_sessions_mu;
 std::map<int, HostSession*> g_sessions;
 
-int get_session(int device, HostSession** out)
+// Test hook: R2S_MULTI_OVERSUBSCRIBE=1 lets n_gpus exceed the visible devices; logical device r then runs on
+// physical device r % visible (its own session, plan and buffers).  It exists so that the single-process fan-out
+// (threads, tile-layer segments, peer copies) can be exercised on a one-GPU box; never for performance.
+bool oversubscribe()
 {
+    const char* e = getenv("R2S_MULTI_OVERSUBSCRIBE");   // read per call: tests switch it on for single cases
+    return e && atoi(e);
+}
+int physical_device(int r)
+{
+    if (!oversubscribe()) return r;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return r;
+    return r % n;
+}
+
+// `key`: logical device of a fan-out (= the physical one unless oversubscribed)
+int get_session(int key, HostSession** out)
+{
+    const int device = physical_device(key);
+    if (oversubscribe()) key += 1000;
     std::lock_guard<std::mutex> l(g_sessions_mu);
-    auto it = g_sessions.find(device);
+    auto it = g_sessions.find(key);
     if (it != g_sessions.end()) {
         *out = it->second;
         return 0;
@@ -176,7 +196,7 @@ int get_session(int device, HostSession** out)
         delete S;
         return rc;
     }
-    g_sessions[device] = S;
+    g_sessions[key] = S;
     *out = S;
     return 0;
 }
@@ -271,7 +291,7 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
     int rc = get_session(device, &S);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(S->mu);
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(S->device));
     const int nen = c.prm.elem_type == R2S_TET4 ? 4 : 8;
     const int64_t nz = c.grid->N[2] + 1, plane = (c.grid->N[0] + 1) * (c.grid->N[1] + 1);
     int64_t owned_planes = nz;
@@ -296,7 +316,7 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
                 return fail(R2S_ERR_NOMEM, "hipMalloc of an output volume (%zu voxels) failed", nvox);
         }
     r2s_params prm = c.prm;
-    prm.device = device;
+    prm.device = S->device;
     prm.zstride = G > 1 ? G : 0;
     prm.zphase = G > 1 ? r : 0;
     prm.n_gpus = 1;
@@ -332,7 +352,8 @@ int n_gpus_of(const r2s_params& p, int* G)
     if (g > 1) {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
-        if (g > n) return fail(R2S_ERR_ARG, "n_gpus = %d but only %d HIP device(s) are visible", g, n);
+        if (g > n && !oversubscribe()) return fail(R2S_ERR_ARG, "n_gpus = %d but only %d HIP device(s) are visible", g, n);
+        if (g > 64) return fail(R2S_ERR_ARG, "n_gpus = %d is not a node", g);
     }
     *G = g;
     return 0;
@@ -463,11 +484,12 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
         r2s_default_params(&t);
         t.n_gpus = G;
         if ((rc = n_gpus_of(t, &G))) return rc;
-        dev0 = 0;
+        dev0 = 0;   // logical device 0 of the fan-out
     }
     HostSession* S = nullptr;
     if ((rc = get_session(dev0, &S))) return rc;
     std::unique_lock<std::mutex> lock(S->mu);
+    dev0 = S->device;
     HIP_TRY(hipSetDevice(dev0));
     r2s_run_info ri;
     memset(&ri, 0, sizeof ri);
@@ -528,7 +550,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
             int rc2 = get_session(r, &T);
             if (rc2) return rc2;
             std::lock_guard<std::mutex> l2(T->mu);
-            HIP_TRY(hipSetDevice(r));
+            HIP_TRY(hipSetDevice(T->device));
             const int64_t nz = grid->N[2] + 1, plane = (grid->N[0] + 1) * (grid->N[1] + 1), layers = (nz + 3) / 4;
             if (layers <= r) return 0;
             const int64_t owned = 4 * ((layers - r + G - 1) / G);
@@ -542,7 +564,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
             }
             if (T->raw.ensure_exact(sizeof(double) * (size_t)(owned * plane))) return fail(R2S_ERR_NOMEM, "hipMalloc failed");
             r2s_params p2 = prm;
-            p2.device = r;
+            p2.device = T->device;
             p2.zstride = G;
             p2.zphase = r;
             r2s_stats st2;
@@ -554,7 +576,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
             int64_t li = 0;
             for (int64_t tl = r; tl < layers; tl += G, ++li) {
                 const int64_t k0 = 4 * tl, k1 = std::min<int64_t>(nz, k0 + 4);
-                HIP_TRY(hipMemcpyPeerAsync(d_full + k0 * plane, 0, T->raw.as<double>() + 4 * li * plane, r,
+                HIP_TRY(hipMemcpyPeerAsync(d_full + k0 * plane, S->device, T->raw.as<double>() + 4 * li * plane, T->device,
                                            sizeof(double) * (size_t)((k1 - k0) * plane), T->cs));
             }
             HIP_TRY(hipStreamSynchronize(T->cs));

@@ -190,3 +190,34 @@ def test_host_entry_points_reuse_their_session(pkg, oracle, pinned):
     X, IEN, rn = synthetic.hex_mesh(4)
     pg = pkg.Grid(X.min(0), X.max(0), 17, 3)
     assert np.isfinite(pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5)).all()     # sessions come back after a release
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_single_process_fan_out(pkg, oracle, G, monkeypatch):
+    """r2s_params.n_gpus / r2s_options.n_gpus: ONE call fans out over G devices (one host thread each, interleaved
+    tile layers, every device's layers sent straight to their place in the caller's array; r2s_rho2sdf gathers them
+    on device 0 by peer copies).  A one-GPU box has one device, so the test hook R2S_MULTI_OVERSUBSCRIBE maps the G
+    logical devices onto it (separate sessions, plans and buffers): the partition, the threads and the copies are the
+    ones an 8-GPU node runs.  Results must equal the single-device call bit for bit."""
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, rn = synthetic.hex_mesh(8)
+    pg = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(70), 3)     # 70 planes: a partial last layer
+    mesh = pkg.Mesh(X, IEN)
+    want = pkg.sdf_fused(mesh, pg, rn, 0.5)
+    wd, _ = pkg.evalDistances(mesh, pg, rn, 0.5, want_xp=False)
+    with pytest.raises(pkg._lib.R2SError, match="visible"):
+        pkg.sdf_fused(mesh, pg, rn, 0.5, n_gpus=G + 100)
+    monkeypatch.setenv("R2S_MULTI_OVERSUBSCRIBE", "1")
+    for out in (None, pkg.host_array(pg.ngp)):
+        got = pkg.sdf_fused(mesh, pg, rn, 0.5, n_gpus=G, out=out)
+        assert np.array_equal(got, want)
+    d, xp = pkg.evalDistances(mesh, pg, rn, 0.5, n_gpus=G)
+    d1, xp1 = pkg.evalDistances(mesh, pg, rn, 0.5)
+    assert np.array_equal(d, wd) and np.array_equal(xp, xp1)
+    # the chained call with the raw SDF spread over G devices
+    rho = np.clip(rn[IEN - 1].mean(axis=1), 0, 1)
+    opts = pkg.Rho2sdfOptions(rbf_interp=False)
+    a = pkg.rho2sdf("t", X, IEN, rho, options=opts, sdf_grid=pg)
+    b = pkg.rho2sdf("t", X, IEN, rho, options=opts, sdf_grid=pg, n_gpus=G)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0])
+    pkg._lib.lib().r2s_release_cache()
