@@ -40,7 +40,7 @@ if a.worker is not None:      # child: oracle on its planes, compare with the st
                       "not_bit_equal": int((got != want).sum()), "max_rel_err": float(rel.max()) if rel.size else 0.0}))
     sys.exit(0)
 
-pkg = graft.build()
+pkg = graft.load_built()
 import torch
 g = pkg.Grid(X.min(0), X.max(0), n_max, 3)
 nx, ny, nz = g.dims

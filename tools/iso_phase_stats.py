@@ -5,7 +5,7 @@ R2S_LIB_OVERRIDE=build_ab/stats.so python tools/iso_phase_stats.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
-pkg = graft.build()
+pkg = graft.load_built()
 import torch
 from rho2sdf_jl_amd import synthetic
 X, IEN, rn = synthetic.hex_mesh(46)

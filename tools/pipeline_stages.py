@@ -12,7 +12,7 @@ ap.add_argument("--mesh", type=int, default=24)
 ap.add_argument("--interp", action="store_true")
 ap.add_argument("--smooth", type=int, default=1)
 a = ap.parse_args()
-pkg = graft.build()
+pkg = graft.load_built()
 from rho2sdf_jl_amd import synthetic
 X, IEN, rn0 = synthetic.hex_mesh(a.mesh)
 # element densities from the nodal field (mean of the 8 nodes) so the pre-stage has real work

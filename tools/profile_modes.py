@@ -10,7 +10,7 @@ ap.add_argument("--mesh", type=int, default=46)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--modes", default="dist,sign,sdf")
 a = ap.parse_args()
-pkg = graft.build()
+pkg = graft.load_built()
 import torch
 from rho2sdf_jl_amd import synthetic
 X, IEN, rn = synthetic.hex_mesh(a.mesh)

@@ -5,7 +5,7 @@ its share of the grid (interleaved tile layers), the packing of its tiles, and t
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
-pkg = graft.build()
+pkg = graft.load_built()
 import torch
 from rho2sdf_jl_amd import synthetic, slabs
 X, IEN, rn = synthetic.hex_mesh(46)

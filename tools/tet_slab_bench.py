@@ -14,7 +14,7 @@ ap.add_argument("--rank", type=int, default=3)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--check-planes", type=int, default=2)
 a = ap.parse_args()
-pkg = graft.build()
+pkg = graft.load_built()
 import torch
 from rho2sdf_jl_amd import synthetic, slabs
 X, IEN, rn = synthetic.tet_mesh(a.cells)
