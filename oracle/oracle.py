@@ -28,22 +28,95 @@ class OrcStats(ctypes.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB) or \
-            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "r2s_oracle.c")):
+    tight_lib = os.path.join(_HERE, "libr2s_oracle_tight.so")
+    src_t = os.path.getmtime(os.path.join(_HERE, "r2s_oracle.c"))
+    if force or not os.path.exists(_LIB) or not os.path.exists(tight_lib) or \
+            os.path.getmtime(_LIB) < src_t or os.path.getmtime(tight_lib) < src_t:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
 
 
 _lib = None
+_lib_tight = None
+_use_tight = False
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int64)
 
 
 def lib():
-    global _lib
+    global _lib, _lib_tight
+    if _use_tight:
+        if _lib_tight is None:
+            build()
+            _lib_tight = ctypes.CDLL(os.path.join(_HERE, "libr2s_oracle_tight.so"))
+        return _lib_tight
     if _lib is None:
         _lib = ctypes.CDLL(build())
     return _lib
+
+
+class tight:
+    """context manager: route every call to the frozen tight-tolerance build (-DORC_TIGHT)"""
+
+    def __enter__(self):
+        global _use_tight
+        self.prev, _use_tight = _use_tight, True
+
+    def __exit__(self, *a):
+        global _use_tight
+        _use_tight = self.prev
+
+
+def inv_map_hex8(x, Xe):
+    """find_local_coordinates restatement for one (element, point) -> (ok, xi)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    Xe = np.ascontiguousarray(Xe, dtype=np.float64)
+    xi = np.zeros(3)
+    ok = lib().orc_inv_map_hex8(_d(x), _d(Xe), _d(xi))
+    return bool(ok), xi
+
+
+def iso_project_tet4(x, Xe4, re4, rt):
+    """compute_coords_on_iso (TET4) restatement -> lambda[3]"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    Xe4 = np.ascontiguousarray(Xe4, dtype=np.float64)
+    re4 = np.ascontiguousarray(re4, dtype=np.float64)
+    lam = np.zeros(3)
+    lib().orc_iso_project_tet4(_d(x), _d(Xe4), _d(re4), ctypes.c_double(rt), _d(lam))
+    return lam
+
+
+class iso_pair_log:
+    """records every (element, voxel, xi) iso pair of the HEX8 eval_distances calls made inside the block"""
+
+    def __init__(self, cap):
+        self.el = np.zeros(cap, np.int64)
+        self.v = np.zeros(cap, np.int64)
+        self.xi = np.zeros((cap, 3))
+        self.n = 0
+
+    def __enter__(self):
+        lib().orc_iso_log(ctypes.c_int64(len(self.el)), _i(self.el), _i(self.v), _d(self.xi))
+        return self
+
+    def __exit__(self, *a):
+        f = lib().orc_iso_log_count
+        f.restype = ctypes.c_int64
+        self.n = int(f())
+        lib().orc_iso_log(ctypes.c_int64(0), None, None, None)
+
+
+class iso_override:
+    """replaces the iso-surface solver of HEX8 eval_distances by a table of local coordinates (pair-log order)"""
+
+    def __init__(self, xi):
+        self.xi = np.ascontiguousarray(xi, dtype=np.float64)
+
+    def __enter__(self):
+        lib().orc_iso_override(_d(self.xi), ctypes.c_int64(len(self.xi)))
+
+    def __exit__(self, *a):
+        lib().orc_iso_override(None, ctypes.c_int64(0))
 
 
 def _d(a):

@@ -280,12 +280,24 @@ static inline double tri_eval_value(const double *c, int st, const double xi[3])
 /* rejects the reference's boundary minimiser.  Non-convergence returns */
 /* (10,10,10) like the reference's failure path (:106).                */
 /* ------------------------------------------------------------------ */
+/* -DORC_TIGHT builds the FROZEN tight-tolerance variant (libr2s_oracle_tight.so): same algorithm, step
+ * tolerances 1e-13 / 1e-12 and generous iteration caps.  tests/test_oracle_drift.py holds the production
+ * tolerances below against it on every fixture, so that an edit which trades accuracy for speed shows up as
+ * a number instead of passing silently ("freeze the oracle"). */
+#ifdef ORC_TIGHT
+#define INV_MAXIT 200
+#else
 #define INV_MAXIT 50
+#endif
 /* Step tolerance: Newton converges quadratically here, so the iterate AFTER a step below 1e-7 is within ~1e-14
  * of the root - the accuracy a 1e-10 tolerance delivers, one iteration earlier (the last iteration of that rule
  * only confirms a step of ~1e-15).  The reference's own optimiser stops at xtol_rel 1e-6 / ftol_abs 1e-10
  * (FindLocalCoordinates.jl:79-87). */
+#ifdef ORC_TIGHT
+#define INV_TOL 1e-13
+#else
 #define INV_TOL 1e-7
+#endif
 static int inv_map_hex8(const double Xe[16][3] /* nodes + monomials */, const double x[3], double xi[3])
 {
     xi[0] = xi[1] = xi[2] = 0.0;
@@ -326,6 +338,16 @@ static int inv_map_hex8(const double Xe[16][3] /* nodes + monomials */, const do
     return 0;
 }
 
+/* find_local_coordinates for one (element, point): tests compare it with 9-start L-BFGS-B vectors */
+int orc_inv_map_hex8(const double x[3], const double *Xe_flat /* 8*3 */, double xi[3])
+{
+    double Xe[16][3], re[16] = {0};
+    for (int a = 0; a < 8; ++a)
+        for (int i = 0; i < 3; ++i) Xe[a][i] = Xe_flat[3 * a + i];
+    hex8_monomials(Xe, re);
+    return inv_map_hex8(Xe, x, xi);
+}
+
 /* ------------------------------------------------------------------ */
 /* Projection onto the density iso-surface inside one HEX8             */
 /* (src/SignedDistances/ComputeCoordsOnIso.jl:16-87)                   */
@@ -347,14 +369,22 @@ static int inv_map_hex8(const double Xe[16][3] /* nodes + monomials */, const do
 /*     goes to the box corner that comes closest to meeting it;         */
 /*   - backtracking on the L1 merit f + mu |c|.                         */
 /* ------------------------------------------------------------------ */
+#ifdef ORC_TIGHT
+#define ISO_MAXIT 400
+#else
 #define ISO_MAXIT 60
+#endif
 /* Step tolerance.  The iteration ends AFTER applying a step below it; with the exact Lagrangian Hessian the steps
  * shrink quadratically, so the final iterate is within ~1e-12 of the minimiser (1e-8 only added an iteration that
  * confirmed a step of ~1e-15: 4.26 -> 3.94 iterations per pair on the north-star mesh).  Measured against 1e-8 on
  * 149 000 pairs: largest relative change of a distance 3.3e-10, xi moves by more than 1e-9 in 2 pairs (linearly
  * converging Gauss-Newton cases on degenerate faces, where the distance is flat).  The reference stops its SLSQP at
  * xtol_rel = ftol_rel = 1e-5 (ComputeCoordsOnIso.jl:20-22). */
+#ifdef ORC_TIGHT
+#define ISO_TOL 1e-12
+#else
 #define ISO_TOL 1e-6
+#endif
 #define QP_PTOL 1e-12
 
 typedef struct {
@@ -1004,6 +1034,21 @@ static void init_sampled_planes(const orc_grid *g, double *a, double value, doub
     }
 }
 
+/* Test hooks around the iso-surface projections of orc_eval_distances (HEX8): a log of every (element, voxel)
+ * pair in processing order, and an override that replaces the solver by a table of local coordinates in that
+ * same order - tests/golden/make_slsqp_field_vectors.py feeds the field with an independent SLSQP run at the
+ * reference's own tolerances and counts the voxels whose distance changes. */
+static int64_t g_iso_log_cap = 0, g_iso_log_n = 0, g_iso_ovr_n = 0;
+static int64_t *g_iso_log_el = NULL, *g_iso_log_v = NULL;
+static double *g_iso_log_xi = NULL;
+static const double *g_iso_ovr_xi = NULL;
+void orc_iso_log(int64_t cap, int64_t *el, int64_t *v, double *xi /* 3*cap */)
+{
+    g_iso_log_cap = cap; g_iso_log_n = 0; g_iso_log_el = el; g_iso_log_v = v; g_iso_log_xi = xi;
+}
+int64_t orc_iso_log_count(void) { return g_iso_log_n; }
+void orc_iso_override(const double *xi /* 3*n, log order; NULL = off */, int64_t n) { g_iso_ovr_xi = xi; g_iso_ovr_n = n; }
+
 int orc_eval_distances_tet4(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, const double *rho_n,
                             double rho_t, const orc_grid *g, double band_factor, double *dist_out,
                             double *xp_out, orc_stats *stats);
@@ -1078,7 +1123,19 @@ int orc_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
                         int64_t vk = v / ((g->N[0] + 1) * (g->N[1] + 1));
                         double x[3], xi[3], N[8], xp[3], dv[3];
                         grid_point(g, vi, vj, vk, x);
-                        int it = iso_project_hex8(x, Xe, re, rho_t, xi); /* :616 */
+                        int it = 0;
+                        if (g_iso_ovr_xi && c.n_iso_solves < g_iso_ovr_n) {
+                            for (int i = 0; i < 3; ++i) xi[i] = g_iso_ovr_xi[3 * c.n_iso_solves + i];
+                        } else {
+                            it = iso_project_hex8(x, Xe, re, rho_t, xi); /* :616 */
+                        }
+                        if (g_iso_log_el) {
+                            if (g_iso_log_n < g_iso_log_cap) {
+                                g_iso_log_el[g_iso_log_n] = el; g_iso_log_v[g_iso_log_n] = v;
+                                for (int i = 0; i < 3; ++i) g_iso_log_xi[3 * g_iso_log_n + i] = xi[i];
+                            }
+                            g_iso_log_n++;
+                        }
                         c.n_iso_solves++;
                         if (it > ISO_MAXIT) c.n_iso_fail++;
                         hex8_shape(xi, N);

@@ -1,0 +1,135 @@
+"""What stands between the oracle and the Julia reference, as numbers (VERDICT r1 "pin what can be pinned").
+
+1. the production oracle (step tolerances 1e-6 / 1e-7, 60 / 50 iterations) against its FROZEN tight build
+   (-DORC_TIGHT: 1e-12 / 1e-13, 400 / 200 iterations) on every fixture: sentinel sets and signs must be identical, and
+   the number of band voxels whose distance moves by more than 1e-6 is asserted - an edit of the production
+   tolerances or of the solver rules that trades accuracy for speed changes these counts;
+2. find_local_coordinates: the single-start clamped Newton against 9-start L-BFGS-B vectors (the reference's problem
+   statement, FindLocalCoordinates.jl:27-104) on strongly distorted hexahedra - the booleans the callers use;
+3. compute_coords_on_iso, TET4: the closed form against SLSQP vectors (ComputeCoordsOnIso.jl:90-181);
+4. evalDistances on the reference's own fixtures with every iso projection done by scipy's SLSQP (golden FIELDS,
+   tests/golden/make_slsqp_field_vectors.py): converged, and at the reference's own 1e-5 tolerances.
+The GPU path is bit-identical to the production oracle on these fixtures (tests/test_parity_gpu.py), so every count
+below is also the product's.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_fixture
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _cases(oracle):
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, rho = load_fixture("sphere")
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    yield "sphere N25", X, IEN, rn, 0.5, oracle.grid_make(X.min(0), X.max(0), 25, 3), 1.1, 0
+    yield "sphere N10 band 2.5", X, IEN, rn, 0.5, oracle.grid_make(X.min(0), X.max(0), 10, 3), 2.5, 0
+    for name, rt, n in (("beam_vfrac_03", 0.5, 6), ("beam_vfrac_04", 0.518555, 0), ("chapadlo", 0.5, 1)):
+        X, IEN, rho = load_fixture(name)
+        rn = oracle.dense_in_nodes(X, IEN, rho)
+        yield name, X, IEN, rn, rt, oracle.auto_grid(X, IEN)[0], 1.1, n
+    X, IEN, rn = synthetic.hex_mesh(12)
+    yield "synthetic 12^3 / 64^3", X, IEN, rn, 0.5, oracle.grid_make(X.min(0), X.max(0), synthetic.grid_n_max_for_points(64), 3), 1.1, 0
+    for seed, jit, n in ((1, .30, 9), (2, .35, 11), (3, .25, 7)):
+        X, IEN, _ = synthetic.hex_mesh(7, jitter=jit, seed=20240501 + seed)
+        rn = np.clip(np.random.default_rng(seed).normal(0.5, 0.35, len(X)), 0, 1)
+        yield f"distorted hex, random density, seed {seed}", X, IEN, rn, 0.5, \
+            oracle.grid_make(X.min(0), X.max(0), synthetic.grid_n_max_for_points(48), 3), 1.1, n
+
+
+def test_production_tolerances_against_the_frozen_tight_oracle(pkg, oracle):
+    """the last column of _cases: band voxels (of 9 298 / 17 875 / 91 125 ...) whose distance differs by more than
+    1e-6 between the production and the tight build - pairs whose SQP runs into the iteration cap or creeps along a
+    degenerate face; everywhere else the two agree to 1e-9"""
+    rows = []
+    for name, X, IEN, rn, rt, g, bf, expect in _cases(oracle):
+        d, _, _ = oracle.eval_distances(X, IEN, rn, rt, g, bf, want_xp=False)
+        s = oracle.sign_detection(X, IEN, rn, rt, g)
+        with oracle.tight():
+            d2, _, _ = oracle.eval_distances(X, IEN, rn, rt, g, bf, want_xp=False)
+            s2 = oracle.sign_detection(X, IEN, rn, rt, g)
+        assert np.array_equal(d == 1e10, d2 == 1e10), f"{name}: sentinel set moves with the tolerances"
+        assert np.array_equal(s, s2), f"{name}: {int((s != s2).sum())} signs move with the tolerances"
+        real = d < 1e9
+        rel = np.abs(d[real] - d2[real]) / np.maximum(d2[real], 1e-300)
+        n6 = int((rel > 1e-6).sum())
+        rows.append((name, int(real.sum()), n6, int((rel > 1e-9).sum())))
+        assert n6 <= expect, f"{name}: {n6} band voxels beyond 1e-6 of the tight oracle (frozen: {expect})"
+    for r in rows:
+        print("drift vs tight oracle: %-42s band voxels %6d  > 1e-6: %3d  > 1e-9: %3d" % r)
+
+
+def test_inverse_map_against_nine_start_lbfgs(oracle):
+    """3 000 (distorted element, point) cases: where the bounded minimiser is a root of the map inside the +-1.1 box
+    the Newton restatement must find the same root; the three comparisons the callers make (max|xi| < 0.95 / 1.001 /
+    1.01: SignDetection.jl:56-62, sdfOnDensityField.jl:92-101) must agree everywhere except within 1e-6 of a threshold"""
+    d = np.load(os.path.join(GOLD, "lbfgs_invmap.npz"))
+    n_root = n_bool = n_amb = n_fail = 0
+    worst = 0.0
+    for k in range(len(d["x"])):
+        ok, xi = oracle.inv_map_hex8(d["x"][k], d["Xe"][k])
+        m_g, m = np.abs(d["xi"][k]).max(), np.abs(xi).max()
+        has_root = d["fmin"][k] < 1e-20
+        n_fail += not ok
+        amb = any(abs(m_g - t) < 1e-6 for t in (0.95, 1.001, 1.01))
+        n_amb += amb
+        if not amb and (m_g < 0.95, m_g < 1.001, m_g < 1.01) != (m < 0.95, m < 1.001, m < 1.01):
+            n_bool += 1
+        if has_root and m_g < 1.1 - 1e-9:
+            n_root += 1
+            assert ok, f"case {k}: Newton from 0 fails although the map has a root in the box"
+            worst = max(worst, float(np.abs(xi - d["xi"][k]).max()))
+    assert n_bool == 0, f"{n_bool} boolean decisions differ from the multi-start minimiser"
+    assert n_root > 1500 and worst < 1e-9
+    print(f"inverse map: {len(d['x'])} cases, {n_root} with a root in the box (max |dxi| {worst:.1e}), "
+          f"{n_fail} Newton failures (all without a root in the box), {n_amb} within 1e-6 of a threshold, 0 boolean differences")
+
+
+def test_tet4_projection_against_slsqp(oracle):
+    d = np.load(os.path.join(GOLD, "slsqp_tet4_projection.npz"))
+    worst = 0.0
+    for k in range(len(d["x"])):
+        lam = oracle.iso_project_tet4(d["x"][k], d["Xe"][k], d["re"][k], float(d["rt"][k]))
+        N = np.array([lam[0], lam[1], lam[2], 1.0 - lam.sum()])
+        assert lam.min() >= -1e-12 and lam.sum() <= 1 + 1e-12 and abs(d["re"][k] @ N - d["rt"][k]) < 1e-12
+        dist = np.linalg.norm(d["x"][k] - d["Xe"][k].T @ N)
+        worst = max(worst, abs(dist - d["dist"][k]) / max(d["dist"][k], 1e-300))
+    assert worst < 1e-9, worst                    # 600 cases; achieved 7e-15
+    print(f"TET4 projection: {len(d['x'])} SLSQP vectors, max rel distance error {worst:.1e}")
+
+
+# fixture -> (band voxels, voxels beyond 1e-6 of the CONVERGED SLSQP field, beyond 1e-6 of the field at the reference's
+#             own 1e-5 tolerances, voxels on which the two SLSQP fields differ by more than 1e-6 between themselves)
+SLSQP_FIELD_COUNTS = {"beam_vfrac_03": (9298, 12, 941, 929), "chapadlo": (17875, 89, 1224, 1163)}
+
+
+@pytest.mark.parametrize("name", sorted(SLSQP_FIELD_COUNTS))
+def test_fields_against_independent_slsqp(oracle, name):
+    """the whole evalDistances field of the reference's fixtures (automatic grid) with the iso projections by scipy's
+    SLSQP.  Converged SLSQP: the product differs on 12 of 9 298 (beam) and 89 of 17 875 (chapadlo) band voxels - pairs
+    where one of the two solvers ends in another local minimum or not on the constraint (the reference uses whatever
+    NLopt returns, ComputeCoordsOnIso.jl:79-86).  At the reference's own tolerances (1e-5) SLSQP itself is 1e-6 away
+    from its converged answer on 929 / 1 163 voxels: that, not the restatement, bounds parity with a Julia run."""
+    F = np.load(os.path.join(GOLD, "slsqp_fields.npz"))
+    X, IEN, rho = load_fixture(name)
+    rn = oracle.dense_in_nodes(X, IEN, rho)
+    g, _ = oracle.auto_grid(X, IEN)
+    d, _, _ = oracle.eval_distances(X, IEN, rn, 0.5, g, 1.1, want_xp=False)
+    band, n_tight, n_ref, n_self = SLSQP_FIELD_COUNTS[name]
+    real = d < 1e9
+    assert int(real.sum()) == band
+    got = {}
+    for tag in ("tight", "ref"):
+        r = F[f"{name}_{tag}"]
+        assert np.array_equal(r == 1e10, d == 1e10)
+        rel = np.abs(d[real] - r[real]) / np.maximum(r[real], 1e-300)
+        got[tag] = int((rel > 1e-6).sum())
+    r1, r2 = F[f"{name}_ref"][real], F[f"{name}_tight"][real]
+    got["self"] = int((np.abs(r1 - r2) / np.maximum(r2, 1e-300) > 1e-6).sum())
+    print(f"{name}: {band} band voxels; beyond 1e-6 of converged SLSQP {got['tight']}, of SLSQP at 1e-5 {got['ref']}, "
+          f"SLSQP 1e-5 vs converged {got['self']}")
+    assert got["tight"] <= n_tight and got["ref"] <= n_ref + 5 and abs(got["self"] - n_self) <= 5
