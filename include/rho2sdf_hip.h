@@ -279,6 +279,11 @@ int r2s_rbf_smooth_dev(const double *d_sdf, const r2s_grid *grid, int32_t is_int
 int r2s_export_vti(const char *filename, const r2s_grid *grid, const void *values, int32_t is_float32,
                    int64_t n_values, const char *value_label, int32_t smooth);
 
+/* the same data set with the payload deflated block-wise (compressor="vtkZLibDataCompressor", WriteVTK's default
+ * on-disk form): level 0 = raw appended (r2s_export_vti), 1..9 = zlib level */
+int r2s_export_vti_z(const char *filename, const r2s_grid *grid, const void *values, int32_t is_float32,
+                     int64_t n_values, const char *value_label, int32_t smooth, int32_t level);
+
 /* exportToVTU(fileName, X, IEN, VTK_CODE, rho)                       src/DataExport/ExportToVTU.jl:2-99
  * ASCII UnstructuredGrid of the mesh (VTK_CODE 12 = hexahedron, 10 = tetra), optional nodal "density". */
 int r2s_export_vtu(const char *filename, const double *X, int64_t nnp, const int64_t *IEN, int64_t nel,
@@ -289,7 +294,8 @@ int r2s_export_vtu(const char *filename, const double *X, int64_t nnp, const int
  * cells are skipped and counted; IEN comes back 1-based.  Element densities (:117-226): the first cell-data
  * field named density / rho / volfrac / ... (the reference's list), else the first cell-data field, else 1.0;
  * taken by position, padded with 1.0.  The arrays are malloc'ed by the library: release them with
- * r2s_free_vtu_mesh.  Binary / appended files (which the reference reads through ReadVTK) are refused. */
+ * r2s_free_vtu_mesh.  Every DataArray encoding ReadVTK reads is understood: ascii, binary (inline base64) and
+ * appended (raw / base64), plain or zlib-compressed, header_type UInt32 / UInt64, little endian. */
 typedef struct r2s_vtu_mesh {
     int64_t nnp, nel;
     int32_t nen;         /* 8 or 4 */
@@ -302,6 +308,12 @@ typedef struct r2s_vtu_mesh {
 } r2s_vtu_mesh;
 int r2s_import_vtu(const char *filename, r2s_vtu_mesh *out);
 void r2s_free_vtu_mesh(r2s_vtu_mesh *mesh);
+
+/* MeshInformations(matread(file)) -> (X, IEN, rho)                    src/MeshGrid/MeshInformations.jl:3-12
+ * MATLAB level-5 .mat file (compressed or not) with `rho` [nel] and the struct `msh` holding X (3 x nnp) and IEN
+ * (nen x nel; IEN + 1 is returned, as the reference adds 1, :8).  Same result struct and ownership as
+ * r2s_import_vtu (release with r2s_free_vtu_mesh).  v7.3 (HDF5) files are refused. */
+int r2s_import_mat(const char *filename, r2s_vtu_mesh *out);
 
 /* frees the process-wide work buffers the library keeps between calls (the materialised RBF matrix of the CG:
  * up to a quarter of the device memory, see r2s_post.hip) */

@@ -8,9 +8,9 @@ from . import _lib
 from .api import (DenseInNodes, DevicePlan, Grid, Mesh, RBFs_smoothing, Rho2sdfOptions, Sign_Detection,
                   calculate_mesh_volume, calculate_volume_from_sdf, evalDistances, find_threshold_for_volume,
                   exportSdfToVTI, exportToVTU, export_sdf_results, getMesh_AABB, import_vtu_mesh, noninteractive_sdf_grid_setup,
-                  remove_sdf_artifacts, rho2sdf, sdf_fused, host_array, calculate_isocontour_volume)
+                  remove_sdf_artifacts, rho2sdf, sdf_fused, host_array, calculate_isocontour_volume, MeshInformations)
 
 __all__ = ["DenseInNodes", "DevicePlan", "Grid", "Mesh", "RBFs_smoothing", "Rho2sdfOptions", "Sign_Detection",
            "calculate_mesh_volume", "calculate_volume_from_sdf", "evalDistances", "find_threshold_for_volume",
            "exportSdfToVTI", "exportToVTU", "export_sdf_results", "getMesh_AABB", "import_vtu_mesh", "noninteractive_sdf_grid_setup", "remove_sdf_artifacts",
-           "rho2sdf", "sdf_fused", "host_array", "calculate_isocontour_volume", "_lib"]
+           "rho2sdf", "sdf_fused", "host_array", "calculate_isocontour_volume", "MeshInformations", "_lib"]

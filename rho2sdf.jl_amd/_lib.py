@@ -124,6 +124,9 @@ SYMBOLS = [
     ("r2s_free_vtu_mesh", None, [ctypes.POINTER(R2SVtuMesh)]),
     ("r2s_export_vti", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(R2SGrid), _P, ctypes.c_int32, ctypes.c_int64,
                                       ctypes.c_char_p, ctypes.c_int32]),
+    ("r2s_export_vti_z", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(R2SGrid), _P, ctypes.c_int32, ctypes.c_int64,
+                                        ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]),
+    ("r2s_import_mat", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(R2SVtuMesh)]),
     ("r2s_rbf_smooth_dev", ctypes.c_int, [_P, ctypes.POINTER(R2SGrid), ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
                                           ctypes.c_double, _P, c_float_p, ctypes.POINTER(ctypes.c_int32), _P]),
 ]

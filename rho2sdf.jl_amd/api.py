@@ -348,16 +348,16 @@ def RBFs_smoothing(sdf, grid, Is_interpolation, smooth, target_volume, threshold
     return fine.reshape(dims[2], dims[1], dims[0])
 
 
-def exportSdfToVTI(filename, grid, values, value_label, smooth=None):
+def exportSdfToVTI(filename, grid, values, value_label, smooth=None, compress=0):
     """exportSdfToVTI(filename, grid, values, value_label, smooth) - VTK ImageData (.vti)
     src/DataExport/ExportToVTI.jl:22-67: dimensions N(*smooth)+1, origin AABB_min, spacing cell_size(/smooth).
     `values` is float32 or float64, x fastest (any shape).  Returns the path written."""
     a = np.ascontiguousarray(values)
     if a.dtype not in (np.float32, np.float64):
         a = a.astype(np.float64)
-    L.check(L.lib().r2s_export_vti(str(filename).encode(), ctypes.byref(grid.c), a.ctypes.data_as(ctypes.c_void_p),
-                                   int(a.dtype == np.float32), int(a.size), str(value_label).encode(),
-                                   0 if smooth is None else int(smooth)))
+    L.check(L.lib().r2s_export_vti_z(str(filename).encode(), ctypes.byref(grid.c), a.ctypes.data_as(ctypes.c_void_p),
+                                     int(a.dtype == np.float32), int(a.size), str(value_label).encode(),
+                                     0 if smooth is None else int(smooth), int(compress)))
     filename = str(filename)
     return filename if filename.endswith(".vti") else filename + ".vti"
 
@@ -391,6 +391,20 @@ def import_vtu_mesh(vtu_file, info=None):
         if info is not None:
             info.update(element_type=int(m.elem_type), n_skipped=int(m.n_skipped),
                         density_field=m.density_field.decode())
+    finally:
+        L.lib().r2s_free_vtu_mesh(ctypes.byref(m))
+    return X, IEN, rho
+
+
+def MeshInformations(mat_file):
+    """MeshInformations(matread(file)) -> (X, IEN, rho)   (src/MeshGrid/MeshInformations.jl:3-12) for MATLAB level-5
+    .mat files: X (nnp, 3), IEN (nel, nen) = stored connectivity + 1, rho (nel,)."""
+    m = L.R2SVtuMesh()
+    L.check(L.lib().r2s_import_mat(str(mat_file).encode(), ctypes.byref(m)))
+    try:
+        X = np.ctypeslib.as_array(m.X, shape=(m.nnp, 3)).copy()
+        IEN = np.ctypeslib.as_array(m.IEN, shape=(m.nel, m.nen)).copy()
+        rho = np.ctypeslib.as_array(m.rho, shape=(m.nel,)).copy()
     finally:
         L.lib().r2s_free_vtu_mesh(ctypes.byref(m))
     return X, IEN, rho

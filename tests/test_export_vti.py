@@ -142,6 +142,115 @@ def test_vtu_import_errors(pkg, tmp_path):
     p.write_text(_vtu(pts + [(0, 0, 1)], [0, 1, 2, 7], [4], [10]))
     with pytest.raises(pkg._lib.R2SError, match="refers to point"):
         pkg.import_vtu_mesh(str(p))
-    p.write_text(_vtu(pts + [(0, 0, 1)], [0, 1, 2, 3], [4], [10], fmt="binary"))
-    with pytest.raises(pkg._lib.R2SError, match="ASCII .vtu only"):
+    p.write_text(_vtu(pts + [(0, 0, 1)], [0, 1, 2, 3], [4], [10], fmt="binary"))     # "binary" arrays that hold text
+    with pytest.raises(pkg._lib.R2SError, match="malformed"):
         pkg.import_vtu_mesh(str(p))
+
+
+# ---- binary / appended / compressed .vtu (what ReadVTK reads, VTUImport.jl:33) and zlib .vti, .mat import --------
+def _vtk_block(a, h64, compressed, encoding):
+    """one DataArray payload as VTK writes it: header (+ deflated blocks), raw bytes or base64 text"""
+    import base64
+    import zlib
+    raw = np.ascontiguousarray(a).tobytes()
+    ht = "<u8" if h64 else "<u4"
+    if not compressed:
+        blob = np.array([len(raw)], dtype=ht).tobytes() + raw
+        return blob if encoding == "raw" else base64.b64encode(blob)
+    bs = 64                                       # tiny blocks: several of them and a partial last one
+    blocks = [raw[i:i + bs] for i in range(0, len(raw), bs)] or [b""]
+    comp = [zlib.compress(b) for b in blocks]
+    last = len(blocks[-1])
+    hdr = np.array([len(blocks), bs, 0 if last == bs else last] + [len(c) for c in comp], dtype=ht).tobytes()
+    if encoding == "raw":
+        return hdr + b"".join(comp)
+    return base64.b64encode(hdr) + base64.b64encode(b"".join(comp))
+
+
+def _binary_vtu(X, IEN0, rho, mode, h64, compressed):
+    nel, nen = IEN0.shape
+    arrays = [("Points", "", "Float64", X.astype("<f8"), ' NumberOfComponents="3"'),
+              ("Cells", "connectivity", "Int64", IEN0.astype("<i8").ravel(), ""),
+              ("Cells", "offsets", "Int32", (nen * np.arange(1, nel + 1)).astype("<i4"), ""),
+              ("Cells", "types", "UInt8", np.full(nel, 12 if nen == 8 else 10, dtype="u1"), ""),
+              ("CellData", "density", "Float32", rho.astype("<f4"), "")]
+    enc = "raw" if mode == "appended-raw" else "base64"
+    appended = b""
+    tags = {}
+    for sec, name, typ, a, extra in arrays:
+        blob = _vtk_block(a, h64, compressed, enc)
+        if mode == "inline":
+            t = f'<DataArray type="{typ}" Name="{name}" format="binary"{extra}>{blob.decode()}</DataArray>'
+        else:
+            t = f'<DataArray type="{typ}" Name="{name}" format="appended" offset="{len(appended)}"{extra}/>'
+            appended += blob
+        tags.setdefault(sec, []).append(t)
+    attrs = f' header_type="{"UInt64" if h64 else "UInt32"}"' + (' compressor="vtkZLibDataCompressor"' if compressed else "")
+    head = (f'<?xml version="1.0"?>\n<VTKFile type="UnstructuredGrid" version="1.0" byte_order="LittleEndian"{attrs}>\n'
+            f'<UnstructuredGrid><Piece NumberOfPoints="{len(X)}" NumberOfCells="{nel}">\n'
+            f'<Points>{"".join(tags["Points"])}</Points>\n<Cells>{"".join(tags["Cells"])}</Cells>\n'
+            f'<CellData>{"".join(tags["CellData"])}</CellData>\n</Piece></UnstructuredGrid>\n').encode()
+    if mode != "inline":
+        head += f'<AppendedData encoding="{enc}">\n_'.encode() + appended + b"\n</AppendedData>\n"
+    return head + b"</VTKFile>\n"
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+@pytest.mark.parametrize("h64", [False, True])
+@pytest.mark.parametrize("mode", ["inline", "appended-raw", "appended-base64"])
+def test_vtu_import_binary_encodings(pkg, tmp_path, mode, h64, compressed):
+    X, IEN, rho = load_fixture("sphere")
+    p = tmp_path / "m.vtu"
+    p.write_bytes(_binary_vtu(X, IEN - 1, rho, mode, h64, compressed))
+    info = {}
+    X2, IEN2, rho2 = pkg.import_vtu_mesh(str(p), info)
+    assert np.array_equal(X2, X) and np.array_equal(IEN2, IEN)
+    assert np.array_equal(rho2, rho.astype(np.float32).astype(np.float64)) and info["density_field"] == "density"
+
+
+def test_vti_zlib_round_trip(pkg, tmp_path):
+    """the compressed appended form WriteVTK writes by default (ExportToVTI.jl:55-64 goes through vtk_grid)"""
+    import zlib
+    g = pkg.Grid(np.array([-1.0, 0.5, 2.0]), np.array([3.0, 2.5, 2.75]), 130, 2)
+    dims = g.dims
+    vals = np.random.default_rng(6).normal(size=dims[2] * dims[1] * dims[0])      # > 1 MiB: several blocks
+    path = pkg.exportSdfToVTI(str(tmp_path / "z"), g, vals, "distance", None, compress=6)
+    raw = open(path, "rb").read()
+    head, _, tail = raw.partition(b'<AppendedData encoding="raw">\n_')
+    assert b'compressor="vtkZLibDataCompressor"' in head and b'header_type="UInt64"' in head
+    nb, bs, last = (int(v) for v in np.frombuffer(tail[:24], dtype="<u8"))
+    cs = np.frombuffer(tail[24:24 + 8 * nb], dtype="<u8").astype(int)
+    o = 24 + 8 * nb
+    out = b""
+    for c in cs:
+        out += zlib.decompress(tail[o:o + c])
+        o += c
+    assert nb > 1 and len(out) == (nb - 1) * bs + (last or bs) == vals.nbytes
+    assert np.array_equal(np.frombuffer(out, dtype="<f8"), vals)
+    assert len(raw) < vals.nbytes and tail[o:].strip().endswith(b"</VTKFile>")
+
+
+@pytest.mark.parametrize("compress", [True, False])
+def test_mat_import(pkg, tmp_path, compress):
+    """MeshInformations (MeshInformations.jl:3-12) on MATLAB level-5 files written by scipy.io.savemat in the layout of
+    the reference's test data (test/*.mat: `rho` (nel,1) double, struct `msh` with X (3,nnp) double and IEN (8,nel)
+    uint16, 0-based) - with and without miCOMPRESSED elements"""
+    import scipy.io
+    X, IEN, rho = load_fixture("chapadlo")
+    p = str(tmp_path / "m.mat")
+    scipy.io.savemat(p, {"rho": rho.reshape(-1, 1), "msh": {"X": X.T.copy(), "IEN": (IEN - 1).T.astype(np.uint16)}},
+                     do_compression=compress)
+    X2, IEN2, rho2 = pkg.MeshInformations(p)
+    assert np.array_equal(X2, X) and np.array_equal(IEN2, IEN) and np.array_equal(rho2, rho)
+    # TET4 connectivity stored as doubles
+    from rho2sdf_jl_amd import synthetic
+    Xt, IT, _ = synthetic.tet_mesh(3)
+    scipy.io.savemat(p, {"msh": {"IEN": (IT - 1).T.astype(float), "X": Xt.T.copy()}, "rho": np.linspace(0, 1, len(IT))},
+                     do_compression=compress)
+    X2, IEN2, rho2 = pkg.MeshInformations(p)
+    assert np.array_equal(X2, Xt) and np.array_equal(IEN2, IT) and np.array_equal(rho2, np.linspace(0, 1, len(IT)))
+    scipy.io.savemat(p, {"rho": rho}, do_compression=compress)
+    with pytest.raises(pkg._lib.R2SError, match='struct "msh" not found'):
+        pkg.MeshInformations(p)
+    with pytest.raises(pkg._lib.R2SError, match="MAT file not found"):
+        pkg.MeshInformations(str(tmp_path / "none.mat"))
