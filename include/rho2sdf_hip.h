@@ -67,7 +67,13 @@ typedef struct {
      * fans out over (single process, one host thread per device 0..n_gpus-1, interleaved tile layers, every
      * device sends its layers straight to their place in the caller's array); <= 1 = the device named above */
     int32_t n_gpus;
-    int32_t reserved;
+    /* 0 = the reference's single-thread semantics (bit parity with a Julia run); 1 = order-independent "true
+     * minimum" (SURVEY 8(f)4): every valid candidate of a boundary triangle takes part in the minimum (no
+     * first-improving-edge break, sdfOnDensityField.jl:769-771; no vertex fall-back only after failures, :777),
+     * exact ties go to the lexicographically smaller projection point, and the HEX8 sign is +1 when ANY candidate
+     * element holding the point (max|xi| < 1.01) has rho >= rho_t (instead of SignDetection.jl:56-69's
+     * improving-sequence rule).  dist_true <= dist_ordered everywhere; see DESIGN.md for the measured deviation. */
+    int32_t true_min;
 } r2s_params;
 
 /* per-call counters (optional; pass NULL) */
@@ -138,7 +144,8 @@ typedef struct {
     int32_t device;                      /* -1 = current */
     int32_t n_gpus;                      /* > 1: raw SDF on devices 0..n_gpus-1 (tile layers gathered on device 0 over xGMI) */
     int32_t skip_rbf;                    /* 1: stop after artifact removal (fine_sdf_out may be NULL) */
-    int32_t reserved[5];
+    int32_t true_min;                    /* r2s_params.true_min for the raw SDF */
+    int32_t reserved[4];
 } r2s_options;
 
 typedef struct {

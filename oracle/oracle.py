@@ -209,6 +209,16 @@ def iso_project_hex8(x, Xe, rho_e, rho_t):
     return xi, it
 
 
+class true_min:
+    """context manager: order-independent "true minimum" semantics for the calls inside the block"""
+
+    def __enter__(self):
+        lib().orc_set_true_min(ctypes.c_int(1))
+
+    def __exit__(self, *a):
+        lib().orc_set_true_min(ctypes.c_int(0))
+
+
 def set_k_sampling(stride=1, phase=0):
     """bench.py cpu_baseline: evaluate only planes k % stride == phase"""
     lib().orc_set_k_sampling(ctypes.c_int64(stride), ctypes.c_int64(phase))

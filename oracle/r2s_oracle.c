@@ -853,8 +853,23 @@ static void mini_aabb(const orc_grid *g, const double (*P)[3], int np, double de
 }
 
 /* WriteValue (sdfOnDensityField.jl:44-57) / update_distance_parallel! (:121-136) */
+/* order-independent "true minimum" semantics (orc_set_true_min): every valid candidate of a
+ * triangle takes part in the minimum (no "first improving edge wins", sdfOnDensityField.jl:769-771, no vertex
+ * fall-back only after failures, :777), exact ties go to the lexicographically smaller projection point, and the
+ * HEX8 sign is +1 as soon as ANY candidate element that holds the point (max|xi| < 1.01) has rho >= rho_t
+ * (instead of the improving-sequence rule of SignDetection.jl:56-69).  Result: independent of element order and
+ * of the thread / GPU partition; dist_true <= dist_ordered everywhere. */
+static int g_true_min = 0;
+void orc_set_true_min(int on) { g_true_min = on; }
+
 static inline int write_value(dist_ctx *c, int64_t v, double d, const double xp[3])
 {
+    if (g_true_min && c->xp && fabs(d) == c->dist[v]) { /* symmetric tie rule */
+        double *q = c->xp + 3 * v;
+        int less = xp[0] < q[0] || (xp[0] == q[0] && (xp[1] < q[1] || (xp[1] == q[1] && xp[2] < q[2])));
+        if (less) { q[0] = xp[0]; q[1] = xp[1]; q[2] = xp[2]; }
+        return 0;
+    }
     if (fabs(d) < c->dist[v]) {
         c->dist[v] = d;
         if (c->xp) { c->xp[3 * v] = xp[0]; c->xp[3 * v + 1] = xp[1]; c->xp[3 * v + 2] = xp[2]; }
@@ -947,6 +962,36 @@ static void process_triangle(dist_ctx *c, const double Xt[3][3], int is_solid,
                 if (lam[1] < lmin || lam[1] != lam[1]) lmin = lam[1];
                 if (lam[2] < lmin || lam[2] != lam[2]) lmin = lam[2];
                 if (lam[0] != lam[0]) lmin = lam[0];
+                if (g_true_min) { /* every candidate: foot on the face, feet on the edges, the three vertices */
+                    if (lmin >= 0.0) {
+                        for (int i = 0; i < 3; ++i)
+                            xp[i] = lam[0] * Xt[0][i] + lam[1] * Xt[1][i] + lam[2] * Xt[2][i];
+                        for (int i = 0; i < 3; ++i) dv[i] = x[i] - xp[i];
+                        double d = norm3(dv);
+                        if (is_solid) write_value(c, v, d, xp);
+                        else projected_on_full_segment(c, Xe, re, rt, xp, x, v);
+                    }
+                    for (int j = 0; j < 3; ++j) {
+                        double L = norm3(Et[j]);
+                        double eh[3] = {Et[j][0] / L, Et[j][1] / L, Et[j][2] / L};
+                        double P = (x[0] - Xt[j][0]) * eh[0] + (x[1] - Xt[j][1]) * eh[1] +
+                                   (x[2] - Xt[j][2]) * eh[2];
+                        if (P >= 0 && P <= L) {
+                            for (int i = 0; i < 3; ++i) xp[i] = Xt[j][i] + eh[i] * P;
+                            for (int i = 0; i < 3; ++i) dv[i] = x[i] - xp[i];
+                            double d = norm3(dv);
+                            if (is_solid) write_value(c, v, d, xp);
+                            else projected_on_full_segment(c, Xe, re, rt, xp, x, v);
+                        }
+                    }
+                    for (int j = 0; j < 3; ++j) {
+                        for (int i = 0; i < 3; ++i) { dv[i] = x[i] - Xt[j][i]; xp[i] = Xt[j][i]; }
+                        double d = norm3(dv);
+                        if (is_solid) write_value(c, v, d, xp);
+                        else projected_on_full_segment(c, Xe, re, rt, xp, x, v);
+                    }
+                    continue;
+                }
                 if (lmin >= 0.0) {
                     for (int i = 0; i < 3; ++i)
                         xp[i] = lam[0] * Xt[0][i] + lam[1] * Xt[1][i] + lam[2] * Xt[2][i];
@@ -1186,6 +1231,15 @@ static inline void sign_visit(const double Xe[16][3], const double re[16], doubl
     double xi[3], N[8];
     inv_map_hex8(Xe, x, xi);
     double m = fmax(fabs(xi[0]), fmax(fabs(xi[1]), fabs(xi[2])));
+    if (g_true_min) { /* any element that holds the point decides for +1 (see write_value) */
+        if (m < 1.01) {
+            hex8_shape(xi, N);
+            double rho = 0.0;
+            for (int k = 0; k < 8; ++k) rho += N[k] * re[k];
+            if (rho >= rt) { *sign = 1.0; *done = 1; }
+        }
+        return;
+    }
     if (m < 1.01 && *max_local > m) {
         hex8_shape(xi, N);
         double rho = 0.0;

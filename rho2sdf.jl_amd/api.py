@@ -75,13 +75,14 @@ def _i(a):
     return a.ctypes.data_as(L.c_int64_p)
 
 
-def _params(mesh, band_factor, device, n_gpus=1):
+def _params(mesh, band_factor, device, n_gpus=1, true_min=False):
     p = L.R2SParams()
     L.lib().r2s_default_params(ctypes.byref(p))
     p.band_factor = float(band_factor)
     p.elem_type = mesh.element_type
     p.device = int(device)
     p.n_gpus = int(n_gpus)
+    p.true_min = int(bool(true_min))
     return p
 
 
@@ -115,14 +116,14 @@ def _rho(mesh, rho_n):
     return r
 
 
-def evalDistances(mesh, grid, rho_n, rho_t, *, band_factor=1.1, want_xp=True, device=-1, stats=None, n_gpus=1, out=None):
+def evalDistances(mesh, grid, rho_n, rho_t, *, band_factor=1.1, want_xp=True, device=-1, stats=None, n_gpus=1, out=None, true_min=False):
     """evalDistances(mesh, grid, points, rho_n, rho_t) -> (dist, xp)
     src/SignedDistances/sdfOnDensityField.jl:139-486 (`points` is implied by `grid`)."""
     r = _rho(mesh, rho_n)
     dist = _out(out, grid.ngp)
     xp = np.empty((grid.ngp, 3)) if want_xp else None
     st = L.R2SStats()
-    p = _params(mesh, band_factor, device, n_gpus)
+    p = _params(mesh, band_factor, device, n_gpus, true_min)
     L.check(L.lib().r2s_eval_distances(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(rho_t),
                                        ctypes.byref(grid.c), ctypes.byref(p), _d(dist),
                                        _d(xp) if want_xp else None, ctypes.byref(st)))
@@ -131,12 +132,12 @@ def evalDistances(mesh, grid, rho_n, rho_t, *, band_factor=1.1, want_xp=True, de
     return dist, xp
 
 
-def Sign_Detection(mesh, grid, rho_n, rho_t, *, device=-1, stats=None, n_gpus=1, out=None):
+def Sign_Detection(mesh, grid, rho_n, rho_t, *, device=-1, stats=None, n_gpus=1, out=None, true_min=False):
     """Sign_Detection(mesh, grid, points, rho_n, rho_t) -> signs  (SignDetection.jl:275-283)"""
     r = _rho(mesh, rho_n)
     s = _out(out, grid.ngp)
     st = L.R2SStats()
-    p = _params(mesh, 1.1, device, n_gpus)
+    p = _params(mesh, 1.1, device, n_gpus, true_min)
     L.check(L.lib().r2s_sign_detection(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(rho_t),
                                        ctypes.byref(grid.c), ctypes.byref(p), _d(s), ctypes.byref(st)))
     if stats is not None:
@@ -144,12 +145,12 @@ def Sign_Detection(mesh, grid, rho_n, rho_t, *, device=-1, stats=None, n_gpus=1,
     return s
 
 
-def sdf_fused(mesh, grid, rho_n, rho_t, *, band_factor=1.1, device=-1, stats=None, n_gpus=1, out=None):
+def sdf_fused(mesh, grid, rho_n, rho_t, *, band_factor=1.1, device=-1, stats=None, n_gpus=1, out=None, true_min=False):
     """`dists .* signs` in one pass (RhoToSDF.jl:169-171).  `out`: result array to fill (e.g. from host_array)."""
     r = _rho(mesh, rho_n)
     out = _out(out, grid.ngp)
     st = L.R2SStats()
-    p = _params(mesh, band_factor, device, n_gpus)
+    p = _params(mesh, band_factor, device, n_gpus, true_min)
     L.check(L.lib().r2s_sdf(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(rho_t),
                             ctypes.byref(grid.c), ctypes.byref(p), _d(out), ctypes.byref(st)))
     if stats is not None:
@@ -181,7 +182,7 @@ class DevicePlan:
             pass
 
     def run(self, dX, dIEN, d_rho_n, rho_t, grid, *, k_begin=0, k_end=None, band_factor=1.1,
-            elem_type=None, dist=None, sign=None, sdf=None, xp=None, stream=None, zstride=1, zphase=0):
+            elem_type=None, dist=None, sign=None, sdf=None, xp=None, stream=None, zstride=1, zphase=0, true_min=False):
         """one pass over planes [k_begin, k_end) (zstride <= 1) or over the interleaved tile layers
         t % zstride == zphase of the whole grid (see r2s_params in include/rho2sdf_hip.h)"""
         import torch
@@ -205,6 +206,7 @@ class DevicePlan:
         p.elem_type = int(elem_type)
         p.zstride = int(zstride)
         p.zphase = int(zphase)
+        p.true_min = int(bool(true_min))
         st = L.R2SStats()
         s = ctypes.c_void_p(stream.cuda_stream if stream is not None
                             else torch.cuda.current_stream().cuda_stream)

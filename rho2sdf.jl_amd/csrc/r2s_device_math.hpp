@@ -768,8 +768,14 @@ struct VoxState {
     double xp[3];  // projection point, starts at 0 (:174)
 };
 
-R2S_DEV bool write_value(VoxState& s, double d, const double xp[3])
+// sym (order-independent mode): an exact tie goes to the lexicographically smaller projection point
+R2S_DEV bool write_value(VoxState& s, double d, const double xp[3], bool sym = false)
 {
+    if (sym && fabs(d) == s.cur) {
+        const bool less = xp[0] < s.xp[0] || (xp[0] == s.xp[0] && (xp[1] < s.xp[1] || (xp[1] == s.xp[1] && xp[2] < s.xp[2])));
+        if (less) { s.xp[0] = xp[0]; s.xp[1] = xp[1]; s.xp[2] = xp[2]; }
+        return false;
+    }
     if (fabs(d) < s.cur) {
         s.cur = d;
         s.xp[0] = xp[0]; s.xp[1] = xp[1]; s.xp[2] = xp[2];
@@ -780,7 +786,7 @@ R2S_DEV bool write_value(VoxState& s, double d, const double xp[3])
 
 // IsProjectedOnFullSegment, HEX8 (sdfOnDensityField.jl:78-119)
 R2S_DEV bool projected_on_full_segment(VoxState& s, const ElemRec& E, double rt, const double xp[3],
-                                       const double x[3])
+                                       const double x[3], bool sym = false)
 {
     double xi[3], N[8];
     inv_map_hex8(E, xp, xi);
@@ -791,7 +797,7 @@ R2S_DEV bool projected_on_full_segment(VoxState& s, const ElemRec& E, double rt,
 #pragma unroll
         for (int k = 0; k < 8; ++k) rho += N[k] * E.r[k];
         if (rho >= rt) {
-            write_value(s, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), xp);
+            write_value(s, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), xp, sym);
             return true;
         }
     }
@@ -800,13 +806,43 @@ R2S_DEV bool projected_on_full_segment(VoxState& s, const ElemRec& E, double rt,
 
 template <class Rec>
 R2S_DEV bool tri_candidate(VoxState& s, bool solid, const Rec& E, double rt, const double xp[3],
-                           const double x[3], double d)
+                           const double x[3], double d, bool sym = false)
 {
-    return solid ? write_value(s, d, xp) : projected_on_full_segment(s, E, rt, xp, x);
+    return solid ? write_value(s, d, xp, sym) : projected_on_full_segment(s, E, rt, xp, x, sym);
+}
+
+// SURVEY 8(f)4, order-independent mode: every candidate of the triangle takes part in the minimum - the foot on
+// the face (if inside), the feet on the three edges (if on the segment) and the three vertices
+template <class Rec>
+R2S_DEV void process_triangle_sym(VoxState& s, const BandItem& T, const Rec& E, double rt, const double x[3],
+                                                  bool solid, bool inside, double l0, double l1, double l2)
+{
+    double xp[3];
+    if (inside) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xp[i] = l0 * T.tri[0][i] + l1 * T.tri[1][i] + l2 * T.tri[2][i];
+        tri_candidate(s, solid, E, rt, xp, x, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), true);
+    }
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+        const double L = T.L[j];
+        const double P = (x[0] - T.tri[j][0]) * T.eh[j][0] + (x[1] - T.tri[j][1]) * T.eh[j][1] +
+                         (x[2] - T.tri[j][2]) * T.eh[j][2];
+        if (P >= 0 && P <= L) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xp[i] = T.tri[j][i] + T.eh[j][i] * P;
+            tri_candidate(s, solid, E, rt, xp, x, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), true);
+        }
+    }
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+        xp[0] = T.tri[j][0]; xp[1] = T.tri[j][1]; xp[2] = T.tri[j][2];
+        tri_candidate(s, solid, E, rt, xp, x, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), true);
+    }
 }
 
 // process_triangle_projection! for one voxel (sdfOnDensityField.jl:675-813)
-template <class Rec>
+template <class Rec, bool SYM = false>
 R2S_DEV void process_triangle(VoxState& s, const BandItem& T, const Rec& E, double rt,
                               const double x[3])
 {
@@ -832,6 +868,10 @@ R2S_DEV void process_triangle(VoxState& s, const BandItem& T, const Rec& E, doub
     double xp[3];
     // minimum(lam) >= 0 with Julia's NaN-propagating minimum
     const bool inside = (l0 >= 0.0) && (l1 >= 0.0) && (l2 >= 0.0);
+    if constexpr (SYM) {   // order-independent mode: its own instantiation, the reference path keeps its registers
+        process_triangle_sym(s, T, E, rt, x, solid, inside, l0, l1, l2);
+        return;
+    }
     if (inside) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) xp[i] = l0 * T.tri[0][i] + l1 * T.tri[1][i] + l2 * T.tri[2][i];
@@ -928,7 +968,8 @@ R2S_DEV bool find_local_tet4(const TetRec& E, const double x[3], double loc[3])
 }
 
 // IsProjectedOnFullSegment, TET4 branch (sdfOnDensityField.jl:92-113)
-R2S_DEV bool projected_on_full_segment(VoxState& s, const TetRec& E, double rt, const double xp[3], const double x[3])
+R2S_DEV bool projected_on_full_segment(VoxState& s, const TetRec& E, double rt, const double xp[3], const double x[3],
+                                       bool sym = false)
 {
     double loc[3], N[4];
     find_local_tet4(E, xp, loc);
@@ -940,7 +981,7 @@ R2S_DEV bool projected_on_full_segment(VoxState& s, const TetRec& E, double rt, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) rho += N[k] * E.r[k];
         if (rho >= rt) {
-            write_value(s, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), xp);
+            write_value(s, norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]), xp, sym);
             return true;
         }
     }

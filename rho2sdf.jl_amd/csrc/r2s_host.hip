@@ -531,6 +531,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     r2s_default_params(&prm);
     prm.band_factor = o.band_factor;
     prm.elem_type = o.elem_type;
+    prm.true_min = o.true_min;
     prm.device = dev0;
     r2s_stats st;
     if (G == 1) {

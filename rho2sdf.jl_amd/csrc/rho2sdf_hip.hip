@@ -1415,6 +1415,7 @@ struct MainArgs {
     const uint32_t* s_store_off;
     const double* sres;
     const uint8_t* hot;        // per tile: some candidate reaches rho_t
+    int true_min;  // order-independent semantics (see write_value / process_triangle)
     int sdf_mode;  // 1: sdf = dist*sign in one kernel; 2: dist pass stores -dist; 3: sign pass flips;
                    // 4: dist pass after the sign pass (keeps the sign already stored)
 };
@@ -1422,7 +1423,8 @@ struct MainArgs {
 // TRI = false: instantiation for tiles whose band lists hold no boundary triangles (tile classification in
 // band_bin / active_tiles): without the triangle code the kernel needs half the registers and twice as many
 // wavefronts hide the dependent-load latency it is bound by
-template <class Rec, bool DO_DIST, bool DO_SIGN, bool TRI = true>
+// SYM = true: the order-independent instantiation of the triangle code (MainArgs::true_min is set with it)
+template <class Rec, bool DO_DIST, bool DO_SIGN, bool TRI = true, bool SYM = false>
 __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
 {
     const Rec* __restrict__ erec = static_cast<const Rec*>(A.erec);
@@ -1494,7 +1496,10 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                     if (in[u]) {
                         if (kind[u] == 0) {
                             // WriteValue of the pre-computed iso candidate (sdfOnDensityField.jl:617-621)
-                            if (fabs(d[u]) < st.cur) {
+                            if (A.true_min && A.iso_res_xp && fabs(d[u]) == st.cur) {
+                                const double q[3] = {A.iso_res_xp[3 * slot[u]], A.iso_res_xp[3 * slot[u] + 1], A.iso_res_xp[3 * slot[u] + 2]};
+                                write_value(st, d[u], q, true);   // symmetric tie rule
+                            } else if (fabs(d[u]) < st.cur) {
                                 st.cur = d[u];
                                 if (A.iso_res_xp) {
                                     st.xp[0] = A.iso_res_xp[3 * slot[u]];
@@ -1504,7 +1509,7 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                             }
                         } else if constexpr (TRI) {
                             const BandItem& T = A.items[__builtin_amdgcn_readlane(my_it, (int)(q0 + u))];
-                            process_triangle(st, T, erec[T.el], A.rho_t, x);
+                            process_triangle<Rec, SYM>(st, T, erec[T.el], A.rho_t, x);
                         }
                     }
                 }
@@ -1562,7 +1567,9 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                                 any = true;
                                 if (rmax[u] > cmax) cmax = rmax[u];
                                 const double m = fabs(v[u]);
-                                if (!done && m < 1.01 && max_local > m) {
+                                if (A.true_min) {   // any element that holds the point decides for +1
+                                    if (m < 1.01 && !__builtin_signbit(v[u])) sg = 1.0;
+                                } else if (!done && m < 1.01 && max_local > m) {
                                     if (!__builtin_signbit(v[u])) sg = 1.0;
                                     if (m < 0.95) done = true;
                                     else max_local = m;
@@ -2151,6 +2158,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     {
         MainArgs A;
         A.g = g; A.s = s; A.rho_t = rho_t;
+        A.true_min = prm.true_min ? 1 : 0;
         A.band_off = P->band_off.as<uint32_t>(); A.band_ent = P->band_ent.as<uint32_t>();
         A.sign_off = P->sign_off.as<uint32_t>(); A.sign_ent = P->sign_ent.as<uint32_t>();
         A.items = P->items.as<BandItem>(); A.erec = P->erec.as<typename ET::Rec>();
@@ -2216,15 +2224,18 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 }
                 if (n_tri) {
                     A.active = P->active_tri.as<uint32_t>(); A.n_active = n_tri;
-                    sdf_tiles_kernel<ElemRec, true, true, true><<<(n_tri + 3) / 4, 256, 0, st>>>(A);
+                    if (A.true_min) sdf_tiles_kernel<ElemRec, true, true, true, true><<<(n_tri + 3) / 4, 256, 0, st>>>(A);
+                    else sdf_tiles_kernel<ElemRec, true, true, true><<<(n_tri + 3) / 4, 256, 0, st>>>(A);
                 }
             } else if (want_dist && want_sign) {
                 const uint32_t n_any = P->h_pinned[8];
                 A.active = P->active_any.as<uint32_t>(); A.n_active = n_any;
-                if (n_any) sdf_tiles_kernel<ElemRec, true, true><<<(n_any + 3) / 4, 256, 0, st>>>(A);
+                if (n_any && A.true_min) sdf_tiles_kernel<ElemRec, true, true, true, true><<<(n_any + 3) / 4, 256, 0, st>>>(A);
+                else if (n_any) sdf_tiles_kernel<ElemRec, true, true><<<(n_any + 3) / 4, 256, 0, st>>>(A);
             } else if (want_dist) {
                 A.active = P->active.as<uint32_t>(); A.n_active = n_active;
-                if (n_active) sdf_tiles_kernel<ElemRec, true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+                if (n_active && A.true_min) sdf_tiles_kernel<ElemRec, true, false, true, true><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+                else if (n_active) sdf_tiles_kernel<ElemRec, true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
             } else if (want_sign) {
                 A.active = P->active_sign.as<uint32_t>(); A.n_active = n_active_sign;
                 if (n_active_sign) sdf_tiles_kernel<ElemRec, false, true><<<(n_active_sign + 3) / 4, 256, 0, st>>>(A);
@@ -2258,7 +2269,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 A.xp = (mode & R2S_OUT_XP) ? d_xp : nullptr;
                 A.sdf_mode = overlap ? 4 : 2;
                 if (overlap) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
-                sdf_tiles_kernel<typename ET::Rec, true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+                if (A.true_min) sdf_tiles_kernel<typename ET::Rec, true, false, true, true><<<(n_active + 3) / 4, 256, 0, st>>>(A);
+                else sdf_tiles_kernel<typename ET::Rec, true, false><<<(n_active + 3) / 4, 256, 0, st>>>(A);
             } else if (overlap) {
                 HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));
             }

@@ -45,7 +45,7 @@ struct R2SParams                      # mirrors r2s_params
     zstride::Int32                    # device-pointer plan API only: interleaved tile layers
     zphase::Int32
     n_gpus::Int32                     # host-pointer entry points: devices 0..n_gpus-1 share the call
-    reserved::Int32
+    true_min::Int32                   # 1 = order-independent semantics (SURVEY 8(f)4); 0 = the reference's
 end
 etype(::Type{HEX8}) = Int32(0)
 etype(::Type{TET4}) = Int32(1)
@@ -63,7 +63,8 @@ struct R2SOptions                     # mirrors r2s_options (= Rho2sdfOptions, R
     device::Int32
     n_gpus::Int32
     skip_rbf::Int32
-    reserved::NTuple{5,Int32}
+    true_min::Int32
+    reserved::NTuple{4,Int32}
 end
 
 struct R2SRunInfo                     # mirrors r2s_run_info
@@ -105,7 +106,7 @@ function rho2sdf_hip(taskName::String, X::Vector{Vector{Float64}}, IEN::Vector{V
     smooth = options.rbf_grid == :same ? 1 : 2                                     # :222
     o = R2SOptions(options.threshold_density === nothing ? NaN : Float64(options.threshold_density), 1.1,
                    options.artifact_min_component_ratio, 1e-3, etype(T), Int32(options.rbf_interp), Int32(smooth),
-                   Int32(options.remove_artifacts), Int32(-1), N_GPUS[], Int32(0), (0, 0, 0, 0, 0))
+                   Int32(options.remove_artifacts), Int32(-1), N_GPUS[], Int32(0), Int32(0), (0, 0, 0, 0))
     ρₙ = Vector{Float64}(undef, mesh.nnp)
     sdf_dists = pinned(Float64, sdf_grid.ngp)
     fine_sdf = pinned(Float32, ((sdf_grid.N .* smooth) .+ 1)...)
