@@ -378,3 +378,37 @@ def test_elements_much_larger_than_cells(pkg, oracle):
     rel = np.abs(got[real] - ref[real]) / np.maximum(np.abs(ref[real]), 1e-300)
     assert not ((rel > RTOL) & (np.abs(got[real] - ref[real]) > 1e-12 * og.cell)).any()
     print(f"large elements: {int(real.sum())} band voxels on the sampled planes, bit-equal {int((got == ref).sum())}/{got.size}")
+
+
+def test_speculated_sizes_fall_back_when_the_data_changes(pkg, oracle):
+    """a plan remembers the list / work-array sizes of its last call and launches the next call of the same shapes
+    without waiting for them (run_impl, read_back_kernel); when the data behind the same shapes changes (another
+    threshold, another density field, a connectivity error) the device-side check must stop the call before anything
+    is written outside its buffers and the call is repeated the slow way - results as from a fresh plan"""
+    import torch
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, rn = synthetic.hex_mesh(9)
+    pg = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(72), 3)
+    dev = torch.device("cuda:0")
+    dX, dI = torch.from_numpy(X).to(dev), torch.from_numpy(IEN).to(dev)
+    rng = np.random.default_rng(11)
+    fields = [rn, rn, np.clip(rn + rng.normal(0, 0.2, len(rn)), 0, 1), rn * 0.0, np.clip(rng.normal(0.5, 0.3, len(rn)), 0, 1), rn]
+    thresholds = [0.5, 0.5, 0.5, 0.5, 0.35, 0.62]
+    plan = pkg.DevicePlan(0)
+    out = torch.empty(pg.ngp, dtype=torch.float64, device=dev)
+    for f, rt in zip(fields, thresholds):
+        dR = torch.from_numpy(np.ascontiguousarray(f)).to(dev)
+        plan.run(dX, dI, dR, rt, pg, sdf=out)
+        fresh = pkg.DevicePlan(0)
+        want = torch.empty_like(out)
+        fresh.run(dX, dI, dR, rt, pg, sdf=want)
+        fresh.close()
+        assert torch.equal(out, want)
+    # a connectivity error behind remembered sizes is still reported, and the plan keeps working afterwards
+    bad = IEN.copy()
+    bad[5, 2] = 10 ** 7
+    with pytest.raises(pkg._lib.R2SError, match="outside 1..nnp"):
+        plan.run(dX, torch.from_numpy(bad).to(dev), torch.from_numpy(rn).to(dev), 0.62, pg, sdf=out)
+    plan.run(dX, dI, torch.from_numpy(rn).to(dev), 0.62, pg, sdf=out)
+    assert torch.equal(out, want)
+    plan.close()
