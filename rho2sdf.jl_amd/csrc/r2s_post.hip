@@ -550,6 +550,105 @@ __global__ void __launch_bounds__(256) rbf_matvec_k_kernel(RbfGeom G, RbfTaps T,
     y[t] = acc;
 }
 
+// ---- K x through a table of the DISTINCT matrix entries --------------------------------------------------------
+// An entry of K depends on its row and column only through the three Float32 coordinate differences
+// cx[i] - cx[i+di], cy[j] - cy[j+dj], cz[k] - cz[k+dk].  On the reference's Float32 `range` lattice each of them takes
+// only a handful of distinct values per offset (rounding patterns of the coordinates: <= 10 on a 512-point axis), so
+// the whole matrix holds at most (2R+1)^3 x NV^3 distinct numbers.  They are evaluated ONCE with the reference's
+// arithmetic (Float32 distance, Float64 exp, threshold test, rounding to Float32 - rbf_lut_build_kernel) and the
+// matvec looks them up: per axis and offset a byte per lattice index names the variant.  Same values, same order
+// of accumulation => bit-identical to rbf_matvec_kernel, without its 81 exp() per row and without the 43 GB
+// materialised matrix of rbf_matvec_k_kernel; the table (<= 2 MB for R = 2) lives in L2.
+#define RBF_NV 16   // variants per (axis, offset) the table has room for; more -> the materialised / on-the-fly paths
+struct RbfLutGeom {
+    int nx, ny, nz, R, tap_d2;
+    const uint8_t *vx, *vy, *vz;   // [2R+1][n_axis]: variant id of (index, offset), 255 = neighbour outside the lattice
+    const float* T;                // [(2R+1)^3][NV][NV][NV], x variant fastest; 0 = entry absent (val <= threshold)
+};
+struct RbfLutVals {
+    float v[3][7][RBF_NV];         // the variant values per axis and offset
+    int R;
+    double sigma, thr;
+};
+__global__ void __launch_bounds__(256) rbf_lut_build_kernel(RbfLutVals V, float* __restrict__ T)
+{
+    const int W = 2 * V.R + 1;
+    const int64_t n = (int64_t)W * W * W * RBF_NV * RBF_NV * RBF_NV;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int a = (int)(t % RBF_NV), b = (int)((t / RBF_NV) % RBF_NV), c = (int)((t / (RBF_NV * RBF_NV)) % RBF_NV);
+    const int tap = (int)(t / (RBF_NV * RBF_NV * RBF_NV));
+    const int di = tap % W, dj = (tap / W) % W, dk = tap / (W * W);
+    const float dx = V.v[0][di][a], dy = V.v[1][dj][b], dz = V.v[2][dk][c];
+    const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+    const double u = (double)r / V.sigma;
+    const double val = exp(-(u * u));
+    T[t] = (val > V.thr) ? (float)val : 0.0f;   // (unused variant slots hold NaN values -> comparisons false -> 0)
+}
+template <int R>
+__global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const float* __restrict__ x, float* __restrict__ y)
+{
+    constexpr int W = 2 * R + 1;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
+    if (t >= n) return;
+    const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
+    uint32_t ax[W], by[W], cz[W];
+#pragma unroll
+    for (int d = 0; d < W; ++d) {
+        ax[d] = G.vx[d * G.nx + i];
+        by[d] = G.vy[d * G.ny + j];
+        cz[d] = G.vz[d * G.nz + k];
+    }
+    float acc = 0.0f;
+    // the loop order of rbf_matvec_kernel (ck, cj, ci ascending): the row sum is formed from the same values in the same order
+#pragma unroll
+    for (int dk = 0; dk < W; ++dk) {
+        if (cz[dk] == 255u) continue;
+#pragma unroll
+        for (int dj = 0; dj < W; ++dj) {
+            if (by[dj] == 255u) continue;
+            if ((dk - R) * (dk - R) + (dj - R) * (dj - R) > G.tap_d2) continue;
+            const float* __restrict__ row = G.T + ((((size_t)((dk * W + dj) * W)) * RBF_NV + cz[dk]) * RBF_NV + by[dj]) * RBF_NV;
+            const int64_t base = t + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx - R;
+#pragma unroll
+            for (int di = 0; di < W; ++di) {
+                if ((dk - R) * (dk - R) + (dj - R) * (dj - R) + (di - R) * (di - R) > G.tap_d2) continue;
+                if (ax[di] == 255u) continue;
+                const float w = row[(size_t)di * RBF_NV * RBF_NV * RBF_NV + ax[di]];
+                if (w != 0.0f) acc += w * x[base + di];
+            }
+        }
+    }
+    y[t] = acc;
+}
+
+// host side of the table: distinct Float32 differences per axis and offset, variant ids per lattice index
+static bool rbf_lut_axis(const std::vector<float>& c, int R, float vals[7][RBF_NV], std::vector<uint8_t>& ids)
+{
+    const int n = (int)c.size(), W = 2 * R + 1;
+    ids.assign((size_t)W * n, 255);
+    for (int d = 0; d < W; ++d) {
+        std::vector<float> u;
+        for (int i = 0; i < n; ++i) {
+            const int ci = i + d - R;
+            if (ci < 0 || ci >= n) continue;
+            u.push_back(c[i] - c[ci]);   // px - G.cx[ci] of rbf_matvec_kernel (IEEE single subtraction on both sides)
+        }
+        std::sort(u.begin(), u.end());
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        if (u.size() > RBF_NV) return false;
+        for (int q = 0; q < RBF_NV; ++q) vals[d][q] = q < (int)u.size() ? u[q] : NAN;
+        for (int i = 0; i < n; ++i) {
+            const int ci = i + d - R;
+            if (ci < 0 || ci >= n) continue;
+            const float v = c[i] - c[ci];
+            ids[(size_t)d * n + i] = (uint8_t)(std::lower_bound(u.begin(), u.end(), v) - u.begin());
+        }
+    }
+    return true;
+}
+
 // process_vector (:15-22), pass 1: max |v| over |v| < 1e9 (as Float32 bits, all non-negative)
 __global__ void pv_max_kernel(const double* __restrict__ v, int64_t n, float* __restrict__ f, uint32_t* __restrict__ maxbits,
                               uint32_t* __restrict__ any)
@@ -678,10 +777,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     const int64_t nf = (int64_t)fx * fy * fz;
     hipStream_t st = nullptr;
     DevBuf d_sdf, d_f, d_w, d_lsf, d_fine, d_cx, d_cy, d_cz, d_tx, d_ty, d_tz, d_st, d_cnt, d_r, d_u, d_q, d_part, d_sum;
+    DevBuf d_lut, d_vx, d_vy, d_vz;
     VolumeWork vw;
     auto cleanup = [&]() {
         DevBuf* all[] = {&d_sdf, &d_f, &d_w, &d_lsf, &d_fine, &d_cx, &d_cy, &d_cz, &d_tx, &d_ty, &d_tz, &d_st, &d_cnt,
-                         &d_r, &d_u, &d_q, &d_part, &d_sum};
+                         &d_r, &d_u, &d_q, &d_part, &d_sum, &d_lut, &d_vx, &d_vy, &d_vz};
         for (DevBuf* b : all) b->release();
         vw.release();
     };
@@ -791,9 +891,34 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
                     taps.off[taps.n][0] = (signed char)di; taps.off[taps.n][1] = (signed char)dj; taps.off[taps.n][2] = (signed char)dk;
                     taps.n++;
                 }
-        bool use_k = false;
-        std::unique_lock<std::mutex> kv_lock(g_rbf_kv_mutex, std::try_to_lock);   // busy: fall back to on-the-fly
-        if (taps_ok && kv_lock.owns_lock()) {
+        // first choice: the table of distinct entries (exact, no matrix in memory); R2S_RBF_MATVEC=k|fly forces the others
+        bool use_lut = false, use_k = false;
+        const char* mv_env = getenv("R2S_RBF_MATVEC");   // (read per call: the tests switch between the three)
+        RbfLutGeom LG;
+        memset(&LG, 0, sizeof LG);
+        if (G.tap_r >= 1 && G.tap_r <= 3 && !(mv_env && (mv_env[0] == 'k' || mv_env[0] == 'f'))) {
+            RbfLutVals LV;
+            memset(&LV, 0, sizeof LV);
+            LV.R = G.tap_r; LV.sigma = G.sigma; LV.thr = G.thr;
+            std::vector<uint8_t> ix, iy, iz;
+            if (rbf_lut_axis(cx, G.tap_r, LV.v[0], ix) && rbf_lut_axis(cy, G.tap_r, LV.v[1], iy) && rbf_lut_axis(cz, G.tap_r, LV.v[2], iz)) {
+                const int W = 2 * G.tap_r + 1;
+                const size_t nT = (size_t)W * W * W * RBF_NV * RBF_NV * RBF_NV;
+                ENSURE_C(d_lut, sizeof(float) * nT);
+                ENSURE_C(d_vx, ix.size()); ENSURE_C(d_vy, iy.size()); ENSURE_C(d_vz, iz.size());
+                HIP_C(hipMemcpy(d_vx.p, ix.data(), ix.size(), hipMemcpyHostToDevice));
+                HIP_C(hipMemcpy(d_vy.p, iy.data(), iy.size(), hipMemcpyHostToDevice));
+                HIP_C(hipMemcpy(d_vz.p, iz.data(), iz.size(), hipMemcpyHostToDevice));
+                rbf_lut_build_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(LV, d_lut.as<float>());
+                LG.nx = nx; LG.ny = ny; LG.nz = nz; LG.R = G.tap_r; LG.tap_d2 = G.tap_d2;
+                LG.vx = d_vx.as<uint8_t>(); LG.vy = d_vy.as<uint8_t>(); LG.vz = d_vz.as<uint8_t>();
+                LG.T = d_lut.as<float>();
+                use_lut = true;
+            }
+        }
+        std::unique_lock<std::mutex> kv_lock(g_rbf_kv_mutex, std::defer_lock);
+        if (!use_lut && !(mv_env && mv_env[0] == 'f')) kv_lock.try_lock();   // busy: fall back to on-the-fly
+        if (!use_lut && taps_ok && kv_lock.owns_lock()) {
             size_t free_b = 0, total_b = 0;
             const size_t need = sizeof(float) * (size_t)n * (size_t)taps.n;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= total_b / 4 &&
@@ -812,7 +937,10 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         while (!(residual <= tol) && its < n) {
             const float beta = (residual * residual) / (prev * prev);
             cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
-            if (use_k) rbf_matvec_k_kernel<<<nb, 256, 0, st>>>(G, taps, g_rbf_kv.as<float>(), d_u.as<float>(), d_q.as<float>());
+            if (use_lut && G.tap_r == 1) rbf_matvec_lut_kernel<1><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
+            else if (use_lut && G.tap_r == 2) rbf_matvec_lut_kernel<2><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
+            else if (use_lut) rbf_matvec_lut_kernel<3><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
+            else if (use_k) rbf_matvec_k_kernel<<<nb, 256, 0, st>>>(G, taps, g_rbf_kv.as<float>(), d_u.as<float>(), d_q.as<float>());
             else rbf_matvec_kernel<<<nb, 256, 0, st>>>(G, d_u.as<float>(), d_q.as<float>());
             float uq;
             TRY_C(dot(d_u.as<float>(), d_q.as<float>(), &uq));

@@ -1449,13 +1449,16 @@ struct MainArgs {
 template <class Rec, bool DO_DIST, bool DO_SIGN, bool TRI = true, bool SYM = false>
 __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
 {
-    if (*A.abort_flag) return;
     const Rec* __restrict__ erec = static_cast<const Rec*>(A.erec);
     // wave-uniform tile id: everything derived from it lives in SGPRs / scalar loads
     const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (w >= A.n_active) return;
     const int lane = threadIdx.x & 63;
+    // (the abort flag travels with the tile id: two independent scalar loads, one wait - a dependent load of its own
+    // at the top of this latency-bound kernel cost 15 % of its run time)
+    const uint32_t ab = *A.abort_flag;
     const uint32_t t = A.active[w];
+    if (ab) return;
     const int tx = t % A.s.ntx, ty = (t / A.s.ntx) % A.s.nty, tz = t / (A.s.ntx * A.s.nty);
     const int i = tx * 4 + (lane & 3), j = ty * 4 + ((lane >> 2) & 3), kl = tz * 4 + (lane >> 4);
     const int k = slab_global_k(A.s, kl);

@@ -34,10 +34,14 @@ fine = timed("RBFs_smoothing(%s, smooth=%d)" % ("interp" if a.interp else "appro
 print(json.dumps({"grid": grid.dims, "elements": int(len(IEN)), "rho_t": rt, "flipped": nf, "th": info["th"],
                   "cg_iterations": info["cg_iterations"], "ms": T}))
 
-# whole rho2sdf() with the stages chained in HBM (api.rho2sdf)
+# whole rho2sdf() in ONE call (r2s_rho2sdf: every stage chained in HBM, results into pinned arrays)
 opts = pkg.Rho2sdfOptions(threshold_density=rt, sdf_grid_setup="automatic", rbf_interp=a.interp,
                           rbf_grid="same" if a.smooth == 1 else "fine")
 pkg.rho2sdf("bench", X, IEN, rho_e, options=opts, sdf_grid=grid)      # warm-up
-t = time.perf_counter()
-pkg.rho2sdf("bench", X, IEN, rho_e, options=opts, sdf_grid=grid)
-print(json.dumps({"rho2sdf_device_chain_ms": round((time.perf_counter() - t) * 1e3, 1)}))
+for pinned in (True, False):
+    info = {}
+    t = time.perf_counter()
+    pkg.rho2sdf("bench", X, IEN, rho_e, options=opts, sdf_grid=grid, info=info, pinned_results=pinned)
+    wall = (time.perf_counter() - t) * 1e3
+    print(json.dumps({"r2s_rho2sdf": "pinned results" if pinned else "pageable results", "wall_ms": round(wall, 1),
+                      **{k: round(v, 2) for k, v in info.items() if k.startswith("ms_")}, "cg_iters": info["cg_iters"]}))
