@@ -674,7 +674,6 @@ static bool rbf_lut_axis(const std::vector<float>& c, int R, float vals[7][RBF_N
 //   Float64 table (apply):      (dist <= max_distance) ? val : -1                 (:240-242)
 // Bit-identical to direct evaluation (an s outside its cluster's range is evaluated directly).
 #define RBF_CLUS 64
-#define RBF_SPAN 8   // groups of 256 outputs per workgroup of the table kernels
 struct RbfSTab {
     int off[RBF_CLUS];         // first entry of cluster c
     uint32_t base[RBF_CLUS];   // bit pattern of its smallest s
@@ -718,10 +717,8 @@ __global__ void __launch_bounds__(256) rbf_matvec_s_kernel(RbfGeom G, RbfSTab S,
     for (int e = threadIdx.x; e < S.total; e += blockDim.x) lt[e] = tab[e];
     __syncthreads();
     const int64_t n = (int64_t)G.nx * G.ny * G.nz;
-    // RBF_SPAN consecutive groups of 256 rows per workgroup: the table is staged once for all of them
-    for (int it = 0; it < RBF_SPAN; ++it) {
-    const int64_t t = ((int64_t)blockIdx.x * RBF_SPAN + it) * blockDim.x + threadIdx.x;
-    if (t >= n) break;
+    // persistent blocks (grid-stride): the table is staged once per workgroup, not once per 256 rows
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
     const float px = G.cx[i], py = G.cy[j], pz = G.cz[k];
     float sx[W], sy[W], sz[W];
@@ -752,11 +749,7 @@ __global__ void __launch_bounds__(256) rbf_matvec_s_kernel(RbfGeom G, RbfSTab S,
                 const uint32_t e = __float_as_uint(sv) - S.base[d2];
                 float wv;
                 if (e < S.n[d2]) wv = lt[S.off[d2] + (int)e];
-#ifdef R2S_RBF_NOFALLBACK
-                else wv = 0.0f;
-#else
                 else wv = rbf_weight_f32(sv, G.sigma, G.thr);               // outside the tabulated range: direct
-#endif
                 int64_t o = base + di;
                 o = o < 0 ? 0 : (o > last ? last : o);
                 xv[di] = x[o];
@@ -785,9 +778,7 @@ __global__ void __launch_bounds__(256) rbf_apply_s_kernel(RbfGeom G, RbfSTab S, 
     }
     const double* __restrict__ T = tab_in_lds ? ld : tab;
     const int64_t nt = (int64_t)tnx * tny * tnz;
-    for (int it = 0; it < RBF_SPAN; ++it) {
-    const int64_t t = ((int64_t)blockIdx.x * RBF_SPAN + it) * blockDim.x + threadIdx.x;
-    if (t >= nt) break;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(t % tnx), j = (int)((t / tnx) % tny), k = (int)(t / ((int64_t)tnx * tny));
     const Stencil& St = stencils[((k % s) * s + (j % s)) * s + (i % s)];
     const int bi = i / s, bj = j / s, bk = k / s;
@@ -802,11 +793,7 @@ __global__ void __launch_bounds__(256) rbf_apply_s_kernel(RbfGeom G, RbfSTab S, 
         double val;
         const uint32_t e = __float_as_uint(sv) - (c < RBF_CLUS ? S.base[c] : 0u);
         if (c < RBF_CLUS && e < S.n[c]) val = T[S.off[c] + (int)e];
-#ifdef R2S_RBF_NOFALLBACK
-        else val = -1.0;
-#else
         else val = rbf_value_f64(sv, G.sigma, G.max_distance);
-#endif
         if (val >= 0.0) acc = (float)((double)acc + (double)w[((int64_t)ck * G.ny + cj) * G.nx + ci] * val);
     }
     out[t] = acc + add;
@@ -1126,7 +1113,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     auto apply = [&](const RbfSTab& S, const DevBuf& tab, bool in_lds, int sm, int anx, int any_, int anz, const float* ax_, const float* ay_,
                      const float* az_, const Stencil* stn, float add, float* out) {
         const unsigned blocks = (unsigned)(((int64_t)anx * any_ * anz + 255) / 256);
-        const unsigned pblocks = (blocks + RBF_SPAN - 1) / RBF_SPAN;   // the LDS table is staged once per RBF_SPAN groups
+        const unsigned pblocks = std::min(blocks, 256u * 8u);   // persistent: the LDS table is staged once per workgroup
         if (stab_on && S.total)
             rbf_apply_s_kernel<<<pblocks, 256, in_lds ? sizeof(double) * (size_t)S.total : 0, st>>>(
                 G, S, (const double*)tab.p, in_lds ? 1 : 0, d_w.as<float>(), sm, anx, any_, anz, ax_, ay_, az_, stn, add, out);
@@ -1225,7 +1212,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             const float beta = (residual * residual) / (prev * prev);
             cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
             const size_t mv_lds = sizeof(float) * (size_t)SM.total;
-            const unsigned pnb = (nb + RBF_SPAN - 1) / RBF_SPAN;
+            const unsigned pnb = std::min(nb, 256u * 8u);
             if (use_s && G.tap_r == 1) rbf_matvec_s_kernel<1><<<pnb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
             else if (use_s && G.tap_r == 2) rbf_matvec_s_kernel<2><<<pnb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
             else if (use_s) rbf_matvec_s_kernel<3><<<pnb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
