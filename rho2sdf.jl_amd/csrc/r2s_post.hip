@@ -716,9 +716,9 @@ __global__ void __launch_bounds__(256) rbf_matvec_s_kernel(RbfGeom G, RbfSTab S,
     constexpr int W = 2 * R + 1;
     for (int e = threadIdx.x; e < S.total; e += blockDim.x) lt[e] = tab[e];
     __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = (int64_t)G.nx * G.ny * G.nz;
-    // persistent blocks (grid-stride): the table is staged once per workgroup, not once per 256 rows
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t >= n) return;
     const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
     const float px = G.cx[i], py = G.cy[j], pz = G.cz[k];
     float sx[W], sy[W], sz[W];
@@ -761,7 +761,6 @@ __global__ void __launch_bounds__(256) rbf_matvec_s_kernel(RbfGeom G, RbfSTab S,
         }
     }
     y[t] = acc;
-    }
 }
 
 // rbf_interpolation_kdtree (:219-248) with the Float64 table (LDS when it fits, else L2): 1 thread / target point
@@ -777,8 +776,9 @@ __global__ void __launch_bounds__(256) rbf_apply_s_kernel(RbfGeom G, RbfSTab S, 
         __syncthreads();
     }
     const double* __restrict__ T = tab_in_lds ? ld : tab;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nt = (int64_t)tnx * tny * tnz;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t >= nt) return;
     const int i = (int)(t % tnx), j = (int)((t / tnx) % tny), k = (int)(t / ((int64_t)tnx * tny));
     const Stencil& St = stencils[((k % s) * s + (j % s)) * s + (i % s)];
     const int bi = i / s, bj = j / s, bk = k / s;
@@ -797,7 +797,6 @@ __global__ void __launch_bounds__(256) rbf_apply_s_kernel(RbfGeom G, RbfSTab S, 
         if (val >= 0.0) acc = (float)((double)acc + (double)w[((int64_t)ck * G.ny + cj) * G.nx + ci] * val);
     }
     out[t] = acc + add;
-    }
 }
 
 // host side: range of s per cluster.  s = fl(fl(a + b) + c) is monotone in the three squared differences, so the
@@ -1113,9 +1112,8 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     auto apply = [&](const RbfSTab& S, const DevBuf& tab, bool in_lds, int sm, int anx, int any_, int anz, const float* ax_, const float* ay_,
                      const float* az_, const Stencil* stn, float add, float* out) {
         const unsigned blocks = (unsigned)(((int64_t)anx * any_ * anz + 255) / 256);
-        const unsigned pblocks = std::min(blocks, 256u * 8u);   // persistent: the LDS table is staged once per workgroup
         if (stab_on && S.total)
-            rbf_apply_s_kernel<<<pblocks, 256, in_lds ? sizeof(double) * (size_t)S.total : 0, st>>>(
+            rbf_apply_s_kernel<<<blocks, 256, in_lds ? sizeof(double) * (size_t)S.total : 0, st>>>(
                 G, S, (const double*)tab.p, in_lds ? 1 : 0, d_w.as<float>(), sm, anx, any_, anz, ax_, ay_, az_, stn, add, out);
         else
             rbf_apply_kernel<<<blocks, 256, 0, st>>>(G, d_w.as<float>(), sm, anx, any_, anz, ax_, ay_, az_, stn, add, out);
@@ -1212,10 +1210,9 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             const float beta = (residual * residual) / (prev * prev);
             cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
             const size_t mv_lds = sizeof(float) * (size_t)SM.total;
-            const unsigned pnb = std::min(nb, 256u * 8u);
-            if (use_s && G.tap_r == 1) rbf_matvec_s_kernel<1><<<pnb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
-            else if (use_s && G.tap_r == 2) rbf_matvec_s_kernel<2><<<pnb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
-            else if (use_s) rbf_matvec_s_kernel<3><<<pnb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
+            if (use_s && G.tap_r == 1) rbf_matvec_s_kernel<1><<<nb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
+            else if (use_s && G.tap_r == 2) rbf_matvec_s_kernel<2><<<nb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
+            else if (use_s) rbf_matvec_s_kernel<3><<<nb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
             else if (use_lut && G.tap_r == 1) rbf_matvec_lut_kernel<1><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
             else if (use_lut && G.tap_r == 2) rbf_matvec_lut_kernel<2><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
             else if (use_lut) rbf_matvec_lut_kernel<3><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
