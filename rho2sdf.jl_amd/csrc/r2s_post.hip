@@ -393,7 +393,6 @@ struct VolumeWork {
 struct Stencil {
     int n;
     signed char off[512][3];
-    unsigned char clus[512];   // cluster of the tap in the squared-distance table (RbfSTab), 255 = evaluate directly
 };
 
 static void build_stencil(int s, const int frac[3], Stencil* st, double R2)
@@ -423,7 +422,6 @@ static void build_stencil(int s, const int frac[3], Stencil* st, double R2)
         st->off[i][0] = (signed char)cand[idx[i]][3];
         st->off[i][1] = (signed char)cand[idx[i]][2];
         st->off[i][2] = (signed char)cand[idx[i]][1];
-        st->clus[i] = (unsigned char)(cand[idx[i]][0] < 255 ? cand[idx[i]][0] : 255);   // = lattice distance^2 in (cell/s)^2
     }
 }
 
@@ -663,197 +661,6 @@ static bool rbf_lut_axis(const std::vector<float>& c, int R, float vals[7][RBF_N
     return true;
 }
 
-// ---- kernel values as a function of the BIT PATTERN of the squared distance -----------------------------------------
-// Every kernel value of the reference is a function of one Float32 number, s = dx*dx + dy*dy + dz*dz (Float32, in
-// that order): dist = sqrt(s) (Float32), u = dist / sigma (Float64), exp(-(u*u)).  On a lattice s clusters around
-// d2 * (cell/smooth)^2 for the few integer d2 inside the support, and inside a cluster it only takes the couple of
-// hundred neighbouring Float32 values the rounding of the coordinates allows.  So the function is tabulated ONCE per
-// call for every representable s of every cluster - with the reference's arithmetic, by the device's own sqrt / exp -
-// and the kernels replace ~50 FP64 instructions per neighbour by two additions and a look-up in LDS:
-//   Float32 table (CG matvec):  (val > threshold) ? Float32(val) : 0             (RBFs4Smoothing.jl:163-168)
-//   Float64 table (apply):      (dist <= max_distance) ? val : -1                 (:240-242)
-// Bit-identical to direct evaluation (an s outside its cluster's range is evaluated directly).
-#define RBF_CLUS 64
-struct RbfSTab {
-    int off[RBF_CLUS];         // first entry of cluster c
-    uint32_t base[RBF_CLUS];   // bit pattern of its smallest s
-    uint32_t n[RBF_CLUS];      // entries (0 = not tabulated)
-    int total;
-};
-__device__ __forceinline__ float rbf_weight_f32(float s, double sigma, double thr)
-{
-    const float r = sqrtf(s);
-    const double u = (double)r / sigma;
-    const double val = exp(-(u * u));
-    return (val > thr) ? (float)val : 0.0f;
-}
-__device__ __forceinline__ double rbf_value_f64(float s, double sigma, float max_distance)
-{
-    const float dist = sqrtf(s);
-    if (!(dist <= max_distance)) return -1.0;
-    const double u = (double)dist / sigma;
-    return exp(-(u * u));
-}
-__global__ void __launch_bounds__(256) rbf_stab_build_kernel(RbfSTab S, double sigma, double thr, float max_distance,
-                                                            float* __restrict__ tf, double* __restrict__ td)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S.total) return;
-    int c = 0;
-    for (int q = 0; q < RBF_CLUS; ++q)
-        if (S.n[q] && e >= S.off[q] && e < S.off[q] + (int)S.n[q]) c = q;
-    const float sv = __uint_as_float(S.base[c] + (uint32_t)(e - S.off[c]));
-    if (tf) tf[e] = rbf_weight_f32(sv, sigma, thr);
-    if (td) td[e] = rbf_value_f64(sv, sigma, max_distance);
-}
-
-// y = K x with the Float32 table in LDS; loop and accumulation order of rbf_matvec_kernel
-template <int R>
-__global__ void __launch_bounds__(256) rbf_matvec_s_kernel(RbfGeom G, RbfSTab S, const float* __restrict__ tab,
-                                                          const float* __restrict__ x, float* __restrict__ y)
-{
-    extern __shared__ float lt[];
-    constexpr int W = 2 * R + 1;
-    for (int e = threadIdx.x; e < S.total; e += blockDim.x) lt[e] = tab[e];
-    __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
-    if (t >= n) return;
-    const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
-    const float px = G.cx[i], py = G.cy[j], pz = G.cz[k];
-    float sx[W], sy[W], sz[W];
-    bool okx[W], oky[W], okz[W];
-#pragma unroll
-    for (int d = 0; d < W; ++d) {
-        const int ci = i + d - R, cj = j + d - R, ck = k + d - R;
-        okx[d] = ci >= 0 && ci < G.nx; oky[d] = cj >= 0 && cj < G.ny; okz[d] = ck >= 0 && ck < G.nz;
-        const float dx = px - G.cx[okx[d] ? ci : i], dy = py - G.cy[oky[d] ? cj : j], dz = pz - G.cz[okz[d] ? ck : k];
-        sx[d] = dx * dx; sy[d] = dy * dy; sz[d] = dz * dz;
-    }
-    const int64_t last = n - 1;
-    float acc = 0.0f;
-#pragma unroll
-    for (int dk = 0; dk < W; ++dk) {
-#pragma unroll
-        for (int dj = 0; dj < W; ++dj) {
-            if ((dk - R) * (dk - R) + (dj - R) * (dj - R) > G.tap_d2) continue;
-            const int64_t base = t + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx - R;
-            float w[W], xv[W];
-#pragma unroll
-            for (int di = 0; di < W; ++di) {
-                const int d2 = (dk - R) * (dk - R) + (dj - R) * (dj - R) + (di - R) * (di - R);   // compile-time
-                w[di] = 0.0f;
-                xv[di] = 0.0f;
-                if (d2 > G.tap_d2) continue;
-                const float sv = (sx[di] + sy[dj]) + sz[dk];                // dx*dx + dy*dy + dz*dz
-                const uint32_t e = __float_as_uint(sv) - S.base[d2];
-                float wv;
-                if (e < S.n[d2]) wv = lt[S.off[d2] + (int)e];
-                else wv = rbf_weight_f32(sv, G.sigma, G.thr);               // outside the tabulated range: direct
-                int64_t o = base + di;
-                o = o < 0 ? 0 : (o > last ? last : o);
-                xv[di] = x[o];
-                w[di] = (okx[di] && oky[dj] && okz[dk]) ? wv : 0.0f;
-            }
-#pragma unroll
-            for (int di = 0; di < W; ++di)
-                if (w[di] != 0.0f) acc += w[di] * xv[di];
-        }
-    }
-    y[t] = acc;
-}
-
-// rbf_interpolation_kdtree (:219-248) with the Float64 table (LDS when it fits, else L2): 1 thread / target point
-__global__ void __launch_bounds__(256) rbf_apply_s_kernel(RbfGeom G, RbfSTab S, const double* __restrict__ tab, int tab_in_lds,
-                                                         const float* __restrict__ w, int s, int tnx, int tny, int tnz,
-                                                         const float* __restrict__ tx, const float* __restrict__ ty,
-                                                         const float* __restrict__ tz, const Stencil* __restrict__ stencils,
-                                                         float add, float* __restrict__ out)
-{
-    extern __shared__ double ld[];
-    if (tab_in_lds) {
-        for (int e = threadIdx.x; e < S.total; e += blockDim.x) ld[e] = tab[e];
-        __syncthreads();
-    }
-    const double* __restrict__ T = tab_in_lds ? ld : tab;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nt = (int64_t)tnx * tny * tnz;
-    if (t >= nt) return;
-    const int i = (int)(t % tnx), j = (int)((t / tnx) % tny), k = (int)(t / ((int64_t)tnx * tny));
-    const Stencil& St = stencils[((k % s) * s + (j % s)) * s + (i % s)];
-    const int bi = i / s, bj = j / s, bk = k / s;
-    const float px = tx[i], py = ty[j], pz = tz[k];
-    float acc = 0.0f;
-    for (int q = 0; q < St.n; ++q) {
-        const int ci = bi + St.off[q][0], cj = bj + St.off[q][1], ck = bk + St.off[q][2];
-        if (ci < 0 || cj < 0 || ck < 0 || ci >= G.nx || cj >= G.ny || ck >= G.nz) continue;
-        const float dx = px - G.cx[ci], dy = py - G.cy[cj], dz = pz - G.cz[ck];
-        const float sv = dx * dx + dy * dy + dz * dz;
-        const int c = St.clus[q];
-        double val;
-        const uint32_t e = __float_as_uint(sv) - (c < RBF_CLUS ? S.base[c] : 0u);
-        if (c < RBF_CLUS && e < S.n[c]) val = T[S.off[c] + (int)e];
-        else val = rbf_value_f64(sv, G.sigma, G.max_distance);
-        if (val >= 0.0) acc = (float)((double)acc + (double)w[((int64_t)ck * G.ny + cj) * G.nx + ci] * val);
-    }
-    out[t] = acc + add;
-}
-
-// host side: range of s per cluster.  s = fl(fl(a + b) + c) is monotone in the three squared differences, so the
-// extremes over the lattice are reached at the per-axis extremes of (t[i] - c[ci])^2.
-static void rbf_axis_sq_range(const std::vector<float>& t, const std::vector<float>& c, int s, int frac, int d, float& mn, float& mx)
-{
-    mn = INFINITY;
-    mx = -INFINITY;
-    for (int i = frac; i < (int)t.size(); i += s) {
-        const int ci = i / s + d;
-        if (ci < 0 || ci >= (int)c.size()) continue;
-        const float v = t[i] - c[ci];
-        const float q = v * v;
-        mn = std::min(mn, q);
-        mx = std::max(mx, q);
-    }
-}
-struct RbfSTabBuilder {
-    uint32_t lo[RBF_CLUS], hi[RBF_CLUS];
-    bool any[RBF_CLUS];
-    RbfSTabBuilder() { for (int c = 0; c < RBF_CLUS; ++c) { lo[c] = 0xFFFFFFFFu; hi[c] = 0; any[c] = false; } }
-    // taps of one stencil class (offsets in source cells; frac = target index mod s per axis)
-    void add(const std::vector<float> t[3], const std::vector<float> c[3], int s, const int frac[3], int n,
-             const signed char (*off)[3])
-    {
-        for (int q = 0; q < n; ++q) {
-            const int ex = off[q][0] * s - frac[0], ey = off[q][1] * s - frac[1], ez = off[q][2] * s - frac[2];
-            const int d2 = ex * ex + ey * ey + ez * ez;
-            if (d2 >= RBF_CLUS) continue;
-            float mn[3], mx[3];
-            for (int a = 0; a < 3; ++a) rbf_axis_sq_range(t[a], c[a], s, frac[a], off[q][a], mn[a], mx[a]);
-            if (!(mn[0] <= mx[0] && mn[1] <= mx[1] && mn[2] <= mx[2])) continue;   // no lattice point uses this tap
-            const float smin = (mn[0] + mn[1]) + mn[2], smax = (mx[0] + mx[1]) + mx[2];
-            uint32_t a, b;
-            memcpy(&a, &smin, 4);
-            memcpy(&b, &smax, 4);
-            lo[d2] = std::min(lo[d2], a);
-            hi[d2] = std::max(hi[d2], b);
-            any[d2] = true;
-        }
-    }
-    // clusters wider than `max_per_cluster` entries (coordinates far from the origin relative to the cell) stay untabulated
-    void finish(RbfSTab& S, uint32_t max_per_cluster, int max_total) const
-    {
-        memset(&S, 0, sizeof S);
-        int total = 0;
-        for (int c = 0; c < RBF_CLUS; ++c) {
-            if (!any[c] || hi[c] < lo[c]) continue;
-            const uint32_t n = hi[c] - lo[c] + 1u;
-            if (n > max_per_cluster || total + (int)n > max_total) continue;
-            S.off[c] = total; S.base[c] = lo[c]; S.n[c] = n;
-            total += (int)n;
-        }
-        S.total = total;
-    }
-};
-
 // process_vector (:15-22), pass 1: max |v| over |v| < 1e9 (as Float32 bits, all non-negative)
 __global__ void pv_max_kernel(const double* __restrict__ v, int64_t n, float* __restrict__ f, uint32_t* __restrict__ maxbits,
                               uint32_t* __restrict__ any)
@@ -990,11 +797,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     const int64_t nf = (int64_t)fx * fy * fz;
     hipStream_t st = nullptr;
     DevBuf d_sdf, d_f, d_w, d_lsf, d_fine, d_cx, d_cy, d_cz, d_tx, d_ty, d_tz, d_st, d_cnt, d_r, d_u, d_q, d_part, d_sum;
-    DevBuf d_lut, d_vx, d_vy, d_vz, d_tabf, d_tabd1, d_tabd2;
+    DevBuf d_lut, d_vx, d_vy, d_vz;
     VolumeWork vw;
     auto cleanup = [&]() {
         DevBuf* all[] = {&d_sdf, &d_f, &d_w, &d_lsf, &d_fine, &d_cx, &d_cy, &d_cz, &d_tx, &d_ty, &d_tz, &d_st, &d_cnt,
-                         &d_r, &d_u, &d_q, &d_part, &d_sum, &d_lut, &d_vx, &d_vy, &d_vz, &d_tabf, &d_tabd1, &d_tabd2};
+                         &d_r, &d_u, &d_q, &d_part, &d_sum, &d_lut, &d_vx, &d_vy, &d_vz};
         for (DevBuf* b : all) b->release();
         vw.release();
     };
@@ -1076,48 +883,6 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         G.tap_d2 = (int)std::floor(R2 * 1.05 + 0.25);      // 1e-3 -> 7 (i.e. 6: 7 is not a sum of three squares)
         G.tap_r = (int)std::floor(std::sqrt((double)G.tap_d2));
     }
-    // ---- kernel values tabulated by the bit pattern of the squared distance (RbfSTab) ----
-    const std::vector<float> csrc[3] = {cx, cy, cz}, tfine[3] = {tx, ty, tz};
-    const char* ap_env = getenv("R2S_RBF_APPLY");                 // "direct": the exp()-per-neighbour kernel
-    const bool stab_on = !(ap_env && ap_env[0] == 'd');
-    RbfSTab S1, S2;                                               // coarse-grid apply (:357), fine-grid apply (:363-366)
-    memset(&S1, 0, sizeof S1);
-    memset(&S2, 0, sizeof S2);
-    bool lds1 = false, lds2 = false;
-    auto build_tab = [&](const RbfSTab& S, DevBuf& buf, bool dbl) -> int {
-        if (buf.ensure((dbl ? sizeof(double) : sizeof(float)) * (size_t)std::max(S.total, 1))) return fail(R2S_ERR_NOMEM, "hipMalloc failed");
-        if (S.total)
-            rbf_stab_build_kernel<<<(S.total + 255) / 256, 256, 0, st>>>(S, G.sigma, G.thr, G.max_distance, dbl ? nullptr : buf.as<float>(),
-                                                                       dbl ? buf.as<double>() : nullptr);
-        return 0;
-    };
-    if (stab_on) {
-        const int fr0[3] = {0, 0, 0};
-        RbfSTabBuilder b1, b2;
-        b1.add(csrc, csrc, 1, fr0, sts[0].n, sts[0].off);
-        b1.finish(S1, 8192u, 1 << 20);
-        for (int a = 0; a < smooth; ++a)
-            for (int b = 0; b < smooth; ++b)
-                for (int c = 0; c < smooth; ++c) {
-                    const int fr[3] = {c, b, a};
-                    const Stencil& q = sts[1 + (a * smooth + b) * smooth + c];
-                    b2.add(tfine, csrc, smooth, fr, q.n, q.off);
-                }
-        b2.finish(S2, 8192u, 1 << 20);
-        TRY_C(build_tab(S1, d_tabd1, true));
-        TRY_C(build_tab(S2, d_tabd2, true));
-        lds1 = (size_t)S1.total * sizeof(double) <= 56u * 1024u;
-        lds2 = (size_t)S2.total * sizeof(double) <= 56u * 1024u;
-    }
-    auto apply = [&](const RbfSTab& S, const DevBuf& tab, bool in_lds, int sm, int anx, int any_, int anz, const float* ax_, const float* ay_,
-                     const float* az_, const Stencil* stn, float add, float* out) {
-        const unsigned blocks = (unsigned)(((int64_t)anx * any_ * anz + 255) / 256);
-        if (stab_on && S.total)
-            rbf_apply_s_kernel<<<blocks, 256, in_lds ? sizeof(double) * (size_t)S.total : 0, st>>>(
-                G, S, (const double*)tab.p, in_lds ? 1 : 0, d_w.as<float>(), sm, anx, any_, anz, ax_, ay_, az_, stn, add, out);
-        else
-            rbf_apply_kernel<<<blocks, 256, 0, st>>>(G, d_w.as<float>(), sm, anx, any_, anz, ax_, ay_, az_, stn, add, out);
-    };
     // ---- weights ----
     int its = 0;
     if (is_interp) {   // compute_rbf_weights (:191-202): cg(K, b), IterativeSolvers 0.9.4 defaults
@@ -1147,28 +912,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
                     taps.n++;
                 }
         // first choice: the table of distinct entries (exact, no matrix in memory); R2S_RBF_MATVEC=k|fly forces the others
-        bool use_lut = false, use_k = false, use_s = false;
-        const char* mv_env = getenv("R2S_RBF_MATVEC");   // (read per call: the tests switch between the four: s, lut, k, fly)
-        RbfSTab SM;
-        memset(&SM, 0, sizeof SM);
-        if (G.tap_r >= 1 && G.tap_r <= 3 && taps_ok && !(mv_env && mv_env[0] != 's')) {
-            const int fr0[3] = {0, 0, 0};
-            RbfSTabBuilder bm;
-            bm.add(csrc, csrc, 1, fr0, taps.n, taps.off);
-            bm.finish(SM, 8192u, 12 * 1024);   // Float32 entries in LDS: <= 48 KB
-            bool all = SM.total > 0;
-            for (int q = 0; q < taps.n && all; ++q) {
-                const int d2 = taps.off[q][0] * taps.off[q][0] + taps.off[q][1] * taps.off[q][1] + taps.off[q][2] * taps.off[q][2];
-                if (d2 >= RBF_CLUS || !SM.n[d2]) all = false;
-            }
-            if (all) {
-                TRY_C(build_tab(SM, d_tabf, false));
-                use_s = true;
-            }
-        }
+        bool use_lut = false, use_k = false;
+        const char* mv_env = getenv("R2S_RBF_MATVEC");   // (read per call: the tests switch between the three)
         RbfLutGeom LG;
         memset(&LG, 0, sizeof LG);
-        if (!use_s && G.tap_r >= 1 && G.tap_r <= 3 && !(mv_env && (mv_env[0] == 'k' || mv_env[0] == 'f'))) {
+        if (G.tap_r >= 1 && G.tap_r <= 3 && !(mv_env && (mv_env[0] == 'k' || mv_env[0] == 'f'))) {
             RbfLutVals LV;
             memset(&LV, 0, sizeof LV);
             LV.R = G.tap_r; LV.sigma = G.sigma; LV.thr = G.thr;
@@ -1189,8 +937,8 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             }
         }
         std::unique_lock<std::mutex> kv_lock(g_rbf_kv_mutex, std::defer_lock);
-        if (!use_s && !use_lut && !(mv_env && mv_env[0] == 'f')) kv_lock.try_lock();   // busy: fall back to on-the-fly
-        if (!use_s && !use_lut && taps_ok && kv_lock.owns_lock()) {
+        if (!use_lut && !(mv_env && mv_env[0] == 'f')) kv_lock.try_lock();   // busy: fall back to on-the-fly
+        if (!use_lut && taps_ok && kv_lock.owns_lock()) {
             size_t free_b = 0, total_b = 0;
             const size_t need = sizeof(float) * (size_t)n * (size_t)taps.n;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= total_b / 4 &&
@@ -1209,11 +957,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         while (!(residual <= tol) && its < n) {
             const float beta = (residual * residual) / (prev * prev);
             cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
-            const size_t mv_lds = sizeof(float) * (size_t)SM.total;
-            if (use_s && G.tap_r == 1) rbf_matvec_s_kernel<1><<<nb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
-            else if (use_s && G.tap_r == 2) rbf_matvec_s_kernel<2><<<nb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
-            else if (use_s) rbf_matvec_s_kernel<3><<<nb, 256, mv_lds, st>>>(G, SM, d_tabf.as<float>(), d_u.as<float>(), d_q.as<float>());
-            else if (use_lut && G.tap_r == 1) rbf_matvec_lut_kernel<1><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
+            if (use_lut && G.tap_r == 1) rbf_matvec_lut_kernel<1><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
             else if (use_lut && G.tap_r == 2) rbf_matvec_lut_kernel<2><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
             else if (use_lut) rbf_matvec_lut_kernel<3><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
             else if (use_k) rbf_matvec_k_kernel<<<nb, 256, 0, st>>>(G, taps, g_rbf_kv.as<float>(), d_u.as<float>(), d_q.as<float>());
@@ -1232,8 +976,8 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     }
     if (cg_iters) *cg_iters = its;
     // ---- LSF on the coarse grid (:357) and the volume-preserving level (:359, :265-300) ----
-    apply(S1, d_tabd1, lds1, 1, nx, ny, nz, d_cx.as<float>(), d_cy.as<float>(), d_cz.as<float>(), d_st.as<Stencil>(), 0.0f,
-          d_lsf.as<float>());
+    rbf_apply_kernel<<<nb, 256, 0, st>>>(G, d_w.as<float>(), 1, nx, ny, nz, d_cx.as<float>(), d_cy.as<float>(),
+                                        d_cz.as<float>(), d_st.as<Stencil>(), 0.0f, d_lsf.as<float>());
     if (lsf_out) HIP_C(hipMemcpy(lsf_out, d_lsf.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     int mmh[2] = {0x7FFFFFFF, (int)0x80000000};
     HIP_C(hipMemcpy(d_cnt.p, mmh, 8, hipMemcpyHostToDevice));
@@ -1257,8 +1001,9 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     th = -th;
     if (th_out) *th_out = th;
     // ---- fine grid (:363-366) ----
-    apply(S2, d_tabd2, lds2, smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(), d_tz.as<float>(), d_st.as<Stencil>() + 1, th,
-          dfine);
+    const unsigned nbf = (unsigned)((nf + 255) / 256);
+    rbf_apply_kernel<<<nbf, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
+                                         d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine);
     HIP_C(hipGetLastError());
     if (out_dev) HIP_C(hipDeviceSynchronize());
     else HIP_C(hipMemcpy(fine_out, d_fine.p, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost));
