@@ -111,7 +111,7 @@ struct HostSession {
     r2s_plan* plan = nullptr;
     DevBuf dX, dI, dR, dE;
     DevBuf out[4];   // dist, sign, sdf, xp
-    DevBuf fine, raw;
+    DevBuf fine, raw, slab;
     void* stage[2] = {nullptr, nullptr};
     hipStream_t cs = nullptr;   // copy stream
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -144,7 +144,7 @@ struct HostSession {
         (void)hipSetDevice(device);
         if (plan) r2s_plan_destroy(plan);
         plan = nullptr;
-        DevBuf* all[] = {&dX, &dI, &dR, &dE, &out[0], &out[1], &out[2], &out[3], &fine, &raw};
+        DevBuf* all[] = {&dX, &dI, &dR, &dE, &out[0], &out[1], &out[2], &out[3], &fine, &raw, &slab};
         for (DevBuf* b : all) b->release();
         for (int i = 0; i < 2; ++i) {
             if (stage[i]) (void)hipHostFree(stage[i]);
@@ -526,7 +526,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     double t2 = now_ms();
     ri.ms_pre = t2 - t;
     // ---- raw SDF = dists .* signs (:169-171) ----
-    if (S->out[2].ensure_exact(sizeof(double) * (size_t)ngp)) return fail(R2S_ERR_NOMEM, "hipMalloc of the SDF volume failed");
+    if (G == 1 && S->out[2].ensure_exact(sizeof(double) * (size_t)ngp)) return fail(R2S_ERR_NOMEM, "hipMalloc of the SDF volume failed");
     r2s_params prm;
     r2s_default_params(&prm);
     prm.band_factor = o.band_factor;
@@ -540,52 +540,130 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
                                    nullptr, &st)))
             return rc;
     } else {
-        // every device computes its interleaved tile layers from its own copy of (X, IEN, rho_n) and sends them to
-        // their place in device 0's volume over xGMI (peer copies; device 0 writes in place)
+        // ---- n_gpus > 1: nothing is ever gathered on one device --------------------------------------------------
+        // raw SDF: every device computes its interleaved 4-plane tile layers (balanced: the band is not uniform in z)
+        // from its own copy of (X, IEN, rho_n).  Post-processing works on contiguous Z-slabs with halos, so the layers
+        // then travel to the slab(s) that hold their planes (peer copies over xGMI), the components are labelled per
+        // slab and merged over the interface planes, the smoothing exchanges halos of its vectors, and every device
+        // sends its planes of the two results straight to the caller's arrays.
         std::vector<double> h_rn((size_t)nnp);
         HIP_TRY(hipMemcpy(h_rn.data(), S->dR.p, sizeof(double) * (size_t)nnp, hipMemcpyDeviceToHost));
-        double* d_full = S->out[2].as<double>();
+        const int64_t nz = grid->N[2] + 1, plane = (grid->N[0] + 1) * (grid->N[1] + 1), layers = (nz + 3) / 4;
+        const int H = 4;   // planes a smoothing stencil can reach beyond a slab (build_stencil: offsets -3..4)
+        std::vector<HostSession*> T((size_t)G, nullptr);
+        std::vector<r2s_int::Slab> slabs((size_t)G);
+        for (int r = 0; r < G; ++r)
+            if ((rc = get_session(r, &T[(size_t)r]))) return rc;
+        {
+            const int64_t per = (nz + G - 1) / G;
+            for (int r = 0; r < G; ++r) {
+                r2s_int::Slab& sl = slabs[(size_t)r];
+                sl.device = T[(size_t)r]->device;
+                sl.stream = T[(size_t)r]->cs;
+                sl.k0 = (int)std::min<int64_t>(nz, r * per);
+                sl.k1 = (int)std::min<int64_t>(nz, (r + 1) * per);
+                sl.h0 = std::max(0, sl.k0 - H);
+                sl.h1 = (int)std::min<int64_t>(nz, sl.k1 + H);
+                sl.d_sdf = nullptr;
+            }
+        }
         lock.unlock();   // device 0's own share takes the session lock again
         rc = fan_out(G, [&](int r) -> int {
-            HostSession* T = nullptr;
-            int rc2 = get_session(r, &T);
-            if (rc2) return rc2;
-            std::lock_guard<std::mutex> l2(T->mu);
-            HIP_TRY(hipSetDevice(T->device));
-            const int64_t nz = grid->N[2] + 1, plane = (grid->N[0] + 1) * (grid->N[1] + 1), layers = (nz + 3) / 4;
+            HostSession* Tr = T[(size_t)r];
+            int rc2 = 0;
+            std::lock_guard<std::mutex> l2(Tr->mu);
+            HIP_TRY(hipSetDevice(Tr->device));
+            const r2s_int::Slab& sl = slabs[(size_t)r];
+            if (sl.k1 > sl.k0 && Tr->slab.ensure_exact(sizeof(double) * (size_t)((sl.h1 - sl.h0) * plane)))
+                return fail(R2S_ERR_NOMEM, "hipMalloc of a slab failed");
             if (layers <= r) return 0;
             const int64_t owned = 4 * ((layers - r + G - 1) / G);
             if (r != 0) {
-                ENSURE(T->dX, sizeof(double) * 3 * (size_t)nnp);
-                ENSURE(T->dR, sizeof(double) * (size_t)nnp);
-                ENSURE(T->dI, sizeof(int64_t) * nen * (size_t)nel);
-                if ((rc2 = upload(T->dX.p, X, sizeof(double) * 3 * (size_t)nnp))) return rc2;
-                if ((rc2 = upload(T->dI.p, IEN, sizeof(int64_t) * nen * (size_t)nel))) return rc2;
-                if ((rc2 = upload(T->dR.p, h_rn.data(), sizeof(double) * (size_t)nnp))) return rc2;
+                ENSURE(Tr->dX, sizeof(double) * 3 * (size_t)nnp);
+                ENSURE(Tr->dR, sizeof(double) * (size_t)nnp);
+                ENSURE(Tr->dI, sizeof(int64_t) * nen * (size_t)nel);
+                if ((rc2 = upload(Tr->dX.p, X, sizeof(double) * 3 * (size_t)nnp))) return rc2;
+                if ((rc2 = upload(Tr->dI.p, IEN, sizeof(int64_t) * nen * (size_t)nel))) return rc2;
+                if ((rc2 = upload(Tr->dR.p, h_rn.data(), sizeof(double) * (size_t)nnp))) return rc2;
             }
-            if (T->raw.ensure_exact(sizeof(double) * (size_t)(owned * plane))) return fail(R2S_ERR_NOMEM, "hipMalloc failed");
+            if (Tr->raw.ensure_exact(sizeof(double) * (size_t)(owned * plane))) return fail(R2S_ERR_NOMEM, "hipMalloc failed");
             r2s_params p2 = prm;
-            p2.device = T->device;
+            p2.device = Tr->device;
             p2.zstride = G;
             p2.zphase = r;
             r2s_stats st2;
-            if ((rc2 = r2s_plan_run_dev(T->plan, T->dX.as<double>(), nnp, T->dI.as<int64_t>(), nel, T->dR.as<double>(), ri.rho_t,
-                                        grid, &p2, 0, nz, R2S_OUT_SDF, nullptr, nullptr, T->raw.as<double>(), nullptr, nullptr,
+            if ((rc2 = r2s_plan_run_dev(Tr->plan, Tr->dX.as<double>(), nnp, Tr->dI.as<int64_t>(), nel, Tr->dR.as<double>(), ri.rho_t,
+                                        grid, &p2, 0, nz, R2S_OUT_SDF, nullptr, nullptr, Tr->raw.as<double>(), nullptr, nullptr,
                                         &st2)))
                 return rc2;
             if (r == 0) st = st2;
-            int64_t li = 0;
-            for (int64_t tl = r; tl < layers; tl += G, ++li) {
-                const int64_t k0 = 4 * tl, k1 = std::min<int64_t>(nz, k0 + 4);
-                HIP_TRY(hipMemcpyPeerAsync(d_full + k0 * plane, S->device, T->raw.as<double>() + 4 * li * plane, T->device,
-                                           sizeof(double) * (size_t)((k1 - k0) * plane), T->cs));
-            }
-            HIP_TRY(hipStreamSynchronize(T->cs));
             return 0;
         });
         lock.lock();
-        HIP_TRY(hipSetDevice(dev0));
         if (rc) return rc;
+        std::vector<std::unique_lock<std::mutex>> others;   // the post-processing uses every device's session (always locked in this order)
+        for (int r = 1; r < G; ++r) others.emplace_back(T[(size_t)r]->mu);
+        for (int r = 0; r < G; ++r) slabs[(size_t)r].d_sdf = T[(size_t)r]->slab.as<double>();
+        // layers -> slabs: plane k of layer tl of device r goes to every slab that holds it (all-to-all over xGMI)
+        for (int r = 0; r < G; ++r) {
+            HostSession* Tr = T[(size_t)r];
+            HIP_TRY(hipSetDevice(Tr->device));
+            int64_t li = 0;
+            for (int64_t tl = r; tl < layers; tl += G, ++li)
+                for (int64_t k = 4 * tl; k < std::min<int64_t>(nz, 4 * tl + 4); ++k)
+                    for (int q = 0; q < G; ++q) {
+                        const r2s_int::Slab& sl = slabs[(size_t)q];
+                        if (sl.k1 <= sl.k0 || k < sl.h0 || k >= sl.h1) continue;
+                        HIP_TRY(hipMemcpyPeerAsync(sl.d_sdf + (k - sl.h0) * plane, sl.device,
+                                                   Tr->raw.as<double>() + (4 * li + (k - 4 * tl)) * plane, Tr->device,
+                                                   sizeof(double) * (size_t)plane, Tr->cs));
+                    }
+        }
+        for (int r = 0; r < G; ++r) {
+            HIP_TRY(hipSetDevice(T[(size_t)r]->device));
+            HIP_TRY(hipStreamSynchronize(T[(size_t)r]->cs));
+        }
+        const double t3m = now_ms();
+        ri.ms_sdf = t3m - t2;
+        ri.ms_sdf_kernels = st.ms_prep + st.ms_bins + st.ms_main + st.ms_gather;
+        // owned planes of a per-slab Float64 field -> their place in a host array
+        auto slabs_to_host = [&](double* host) -> int {
+            for (int r = 0; r < G; ++r) {
+                const r2s_int::Slab& sl = slabs[(size_t)r];
+                if (sl.k1 <= sl.k0) continue;
+                HIP_TRY(hipSetDevice(sl.device));
+                std::vector<Segment> segs{{(char*)(host + (int64_t)sl.k0 * plane), (const char*)(sl.d_sdf + (int64_t)(sl.k0 - sl.h0) * plane),
+                                           sizeof(double) * (size_t)((sl.k1 - sl.k0) * plane)}};
+                int rc2 = download(T[(size_t)r], segs, is_pinned(host));
+                if (rc2) return rc2;
+            }
+            return 0;
+        };
+        if (sdf_raw_out && (rc = slabs_to_host(sdf_raw_out))) return rc;
+        if (o.remove_artifacts) {
+            if ((rc = r2s_int::remove_artifacts_slabs(slabs, grid, 0.0, o.artifact_min_component_ratio, &ri.n_flipped))) return rc;
+            std::vector<void*> base((size_t)G);
+            for (int r = 0; r < G; ++r) base[(size_t)r] = slabs[(size_t)r].d_sdf;
+            if ((rc = r2s_int::exchange_halo_slabs(slabs, base, sizeof(double), plane, H))) return rc;   // flipped voxels reach the halos
+        }
+        const double t4m = now_ms();
+        ri.ms_artifacts = t4m - t3m;
+        if (sdf_dists_out && (rc = slabs_to_host(sdf_dists_out))) return rc;
+        const double t5m = now_ms();
+        if (!o.skip_rbf) {
+            int its = 0;
+            if ((rc = r2s_int::rbf_smooth_slabs(slabs, grid, o.rbf_interp, o.rbf_smooth, o.rbf_kernel_threshold, ri.V_frac * ri.V_domain,
+                                                fine_sdf_out, &ri.level_shift, &its)))
+                return rc;
+            ri.cg_iters = its;
+        }
+        const double t6m = now_ms();
+        ri.ms_rbf = t6m - t5m;
+        ri.ms_download = t5m - t4m;
+        ri.ms_total = t6m - t_start;
+        HIP_TRY(hipSetDevice(dev0));
+        if (info) *info = ri;
+        return 0;
     }
     double t3 = now_ms();
     ri.ms_sdf = t3 - t2;

@@ -3,6 +3,7 @@
 // chained r2s_rho2sdf() in r2s_host.hip.  All of them run on the CURRENT device and are synchronous on return.
 #pragma once
 #include <cstdint>
+#include <vector>
 
 #include "r2s_common.hpp"
 
@@ -33,6 +34,27 @@ int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, dou
 // RBFs_smoothing with device-resident input / output (RBFs4Smoothing.jl:321-377)
 int rbf_smooth_dev(const double* d_sdf, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
                    float* d_fine_out, float* th_out, int* cg_iters);
+
+// ---- Z-slab distributed post-processing (single process, one entry per device; SURVEY 8(e) second half) ----------
+// A slab OWNS the grid planes [k0, k1) and HOLDS [h0, h1) (its planes plus the halo the stencils reach into);
+// d_sdf is the Float64 field of the held planes on `device`, plane k at (k - h0) * plane.
+struct Slab {
+    int device;
+    hipStream_t stream;
+    int k0, k1, h0, h1;
+    double* d_sdf;
+};
+// copies every held-but-not-owned plane from the slab that owns it (peer copies over xGMI); base[q] = the array of
+// slab q (held planes), elem = bytes per value
+int exchange_halo_slabs(const std::vector<Slab>& S, const std::vector<void*>& base, size_t elem, int64_t plane, int radius);
+// remove_sdf_artifacts! with the components labelled per slab and merged across the slab interfaces on the host
+// (boundary-plane labels only); owned planes of d_sdf are modified, halos are NOT refreshed
+int remove_artifacts_slabs(const std::vector<Slab>& S, const r2s_grid* g, double threshold, double min_ratio, int64_t* n_flipped);
+// RBFs_smoothing on slabs: halo exchanges of the CG direction / weights / LSF, plane-wise dot products summed in k
+// order on the host, volume row sums reduced on slab 0 - bit-identical to rbf_smooth_dev on one device.
+// fine_out_host: the caller's (host) array of the whole fine grid, filled slab by slab.
+int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
+                     float* fine_out_host, float* th_out, int* cg_iters);
 
 // frees the cached per-device host sessions (r2s_host.hip); called by r2s_release_cache()
 void release_host_sessions();

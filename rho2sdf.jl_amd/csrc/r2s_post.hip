@@ -281,12 +281,14 @@ __global__ void __launch_bounds__(256) sum_f32_kernel(const float* __restrict__ 
 // do not stall 63 idle lanes for 729 iterations.  Every reduction has a fixed order (no float atomics).
 __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restrict__ sdf, int nx, int ny, int nz,
                                                          float shift, float iso, float elvol, float jac,
-                                                         QuadTab q, float* __restrict__ partial)
+                                                         QuadTab q, float* __restrict__ partial, int row0 = 0)
 {
+    // (row0: first cell row of this launch - a Z-slab of a multi-device run works on the rows of its planes, with
+    //  `sdf` and `partial` addressed as the whole grid's)
     __shared__ float red[256];
     __shared__ int s_cut[256];
     __shared__ int s_wcnt[4];
-    const int row = blockIdx.x;
+    const int row = row0 + blockIdx.x;
     const int j = row % (ny - 1), k = row / (ny - 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t sy = nx, sz = (int64_t)nx * ny;
@@ -439,10 +441,12 @@ __global__ void __launch_bounds__(256) rbf_apply_kernel(RbfGeom G, const float* 
                                                        int tnz, const float* __restrict__ tx,
                                                        const float* __restrict__ ty, const float* __restrict__ tz,
                                                        const Stencil* __restrict__ stencils, float add,
-                                                       float* __restrict__ out)
+                                                       float* __restrict__ out, int64_t t_begin = 0, int64_t t_end = -1)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nt = (int64_t)tnx * tny * tnz;
+    // [t_begin, t_end): the targets of this launch (a Z-slab of a multi-device run; `w` and `out` are addressed as
+    // the whole grids')
+    const int64_t t = t_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nt = t_end >= 0 ? t_end : (int64_t)tnx * tny * tnz;
     if (t >= nt) return;
     const int i = (int)(t % tnx), j = (int)((t / tnx) % tny), k = (int)(t / ((int64_t)tnx * tny));
     const Stencil& S = stencils[((k % s) * s + (j % s)) * s + (i % s)];
@@ -463,11 +467,12 @@ __global__ void __launch_bounds__(256) rbf_apply_kernel(RbfGeom G, const float* 
 }
 
 // y = K x, K = compute_sparse_kernel_matrix (:142-176); row accumulation in ascending linear index
-__global__ void __launch_bounds__(256) rbf_matvec_kernel(RbfGeom G, const float* __restrict__ x, float* __restrict__ y)
+__global__ void __launch_bounds__(256) rbf_matvec_kernel(RbfGeom G, const float* __restrict__ x, float* __restrict__ y,
+                                                        int64_t t_begin = 0, int64_t t_end = -1)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = t_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = (int64_t)G.nx * G.ny * G.nz;
-    if (t >= n) return;
+    if (t >= (t_end >= 0 ? t_end : n)) return;
     const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
     const float px = G.cx[i], py = G.cy[j], pz = G.cz[k];
     float acc = 0.0f;
@@ -588,12 +593,16 @@ __global__ void __launch_bounds__(256) rbf_lut_build_kernel(RbfLutVals V, float*
     T[t] = (val > V.thr) ? (float)val : 0.0f;   // (unused variant slots hold NaN values -> comparisons false -> 0)
 }
 template <int R>
-__global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const float* __restrict__ x, float* __restrict__ y)
+__global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const float* __restrict__ x, float* __restrict__ y,
+                                                            int64_t t_begin = 0, int64_t t_end = -1, int64_t x_lo = 0,
+                                                            int64_t x_hi = -1)
 {
+    // [t_begin, t_end): rows of this launch; [x_lo, x_hi]: the part of x that exists on this device (a Z-slab with its
+    // halo; x and y are addressed as the whole vectors) - the clamp of absent neighbours stays inside it
     constexpr int W = 2 * R + 1;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = t_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = (int64_t)G.nx * G.ny * G.nz;
-    if (t >= n) return;
+    if (t >= (t_end >= 0 ? t_end : n)) return;
     const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
     uint32_t ax[W], by[W], cz[W];
 #pragma unroll
@@ -606,7 +615,7 @@ __global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const
     // the loop order of rbf_matvec_kernel (ck, cj, ci ascending): the row sum is formed from the same values in the same
     // order.  The table and vector loads of a (dk, dj) row are unconditional and independent (clamped addresses, absent
     // entries read as weight 0), so the memory system sees 2 W loads in flight per row instead of a dependent chain.
-    const int64_t last = n - 1;
+    const int64_t first = x_lo, last = x_hi >= 0 ? x_hi : n - 1;
 #pragma unroll
     for (int dk = 0; dk < W; ++dk) {
 #pragma unroll
@@ -623,7 +632,7 @@ __global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const
                                 (dk - R) * (dk - R) + (dj - R) * (dj - R) + (di - R) * (di - R) <= G.tap_d2;
                 const float tv = row[(size_t)di * RBF_NV * RBF_NV * RBF_NV + (ax[di] != 255u ? ax[di] : 0u)];
                 int64_t o = base + di;
-                o = o < 0 ? 0 : (o > last ? last : o);
+                o = o < first ? first : (o > last ? last : o);
                 xv[di] = x[o];
                 w[di] = ok ? tv : 0.0f;
             }
@@ -717,6 +726,25 @@ __global__ void __launch_bounds__(256) dot_kernel(const float* __restrict__ a, c
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         acc += (double)a[i] * (double)b[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// Dot product as one Float64 partial sum per Z plane (fixed tree inside the plane); the planes are added in k order on
+// the host.  The result does not depend on how the planes are spread over devices: a Z-slab run of the CG follows the
+// single-device run bit for bit.
+__global__ void __launch_bounds__(256) dot_planes_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t plane,
+                                                        double* __restrict__ partial)
+{
+    __shared__ double red[256];
+    const float* __restrict__ pa = a + (int64_t)blockIdx.x * plane;
+    const float* __restrict__ pb = b + (int64_t)blockIdx.x * plane;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < plane; i += 256) acc += (double)pa[i] * (double)pb[i];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -889,13 +917,14 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         ENSURE_C(d_r, sizeof(float) * (size_t)n);
         ENSURE_C(d_u, sizeof(float) * (size_t)n);
         ENSURE_C(d_q, sizeof(float) * (size_t)n);
-        ENSURE_C(d_part, sizeof(double) * 1024);
+        ENSURE_C(d_part, sizeof(double) * (size_t)std::max(nz, 1024));
         ENSURE_C(d_sum, 64);
         auto dot = [&](const float* a, const float* b, float* out) -> int {
-            dot_kernel<<<1024, 256, 0, st>>>(a, b, n, d_part.as<double>());
-            sum_f64_kernel<<<1, 256, 0, st>>>(d_part.as<double>(), 1024, d_sum.as<double>());
-            double h;
-            HIP_TRY(hipMemcpy(&h, d_sum.p, 8, hipMemcpyDeviceToHost));
+            dot_planes_kernel<<<nz, 256, 0, st>>>(a, b, (int64_t)nx * ny, d_part.as<double>());
+            std::vector<double> hp((size_t)nz);
+            HIP_TRY(hipMemcpy(hp.data(), d_part.p, sizeof(double) * (size_t)nz, hipMemcpyDeviceToHost));
+            double h = 0.0;
+            for (int k = 0; k < nz; ++k) h += hp[(size_t)k];   // planes in k order (see dot_planes_kernel)
             *out = (float)h;
             return 0;
         };
@@ -1011,7 +1040,606 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     return 0;
 }
 
+// ====================================================================================
+// Z-slab distributed post-processing (single process, one slab per device)
+// ====================================================================================
+__global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+__global__ void scatter_u32_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = val[i];
+}
+
+namespace {
+#define SLAB_HIP(expr)                                                                                       \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) { rc = fail(R2S_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } \
+    } while (0)
+#define SLAB_TRY(expr)                                                                                       \
+    do {                                                                                                     \
+        rc = (expr);                                                                                         \
+        if (rc) goto done;                                                                                   \
+    } while (0)
+
+struct SlabBufs {   // per-slab device buffers, allocated / freed on their device
+    std::vector<DevBuf> b;
+    const std::vector<r2s_int::Slab>* S;
+    explicit SlabBufs(const std::vector<r2s_int::Slab>& s) : b(s.size()), S(&s) {}
+    int ensure(size_t q, size_t bytes)
+    {
+        if (hipSetDevice((*S)[q].device) != hipSuccess) return fail(R2S_ERR_HIP, "hipSetDevice failed");
+        if (b[q].ensure_exact(std::max<size_t>(bytes, 16))) return fail(R2S_ERR_NOMEM, "hipMalloc of %zu bytes failed on device %d", bytes, (*S)[q].device);
+        return 0;
+    }
+    template <class T>
+    T* at(size_t q) { return b[q].as<T>(); }
+    ~SlabBufs()
+    {
+        for (size_t q = 0; q < b.size(); ++q) {
+            (void)hipSetDevice((*S)[q].device);
+            b[q].release();
+        }
+    }
+};
+
+int sync_slabs(const std::vector<r2s_int::Slab>& S)
+{
+    for (const auto& sl : S) {
+        HIP_TRY(hipSetDevice(sl.device));
+        HIP_TRY(hipStreamSynchronize(sl.stream));
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+}  // namespace
+
 namespace r2s_int {
+
+int exchange_halo_slabs(const std::vector<Slab>& S, const std::vector<void*>& base, size_t elem, int64_t plane, int radius)
+{
+    const size_t pb = (size_t)plane * elem;
+    for (size_t q = 0; q < S.size(); ++q) {
+        const Slab& d = S[q];
+        if (d.k1 <= d.k0) continue;
+        HIP_TRY(hipSetDevice(d.device));
+        for (int k = std::max(d.h0, d.k0 - radius); k < std::min(d.h1, d.k1 + radius); ++k) {
+            if (k >= d.k0 && k < d.k1) continue;
+            for (size_t o = 0; o < S.size(); ++o) {
+                const Slab& src = S[o];
+                if (k < src.k0 || k >= src.k1) continue;
+                HIP_TRY(hipMemcpyPeerAsync((char*)base[q] + (size_t)(k - d.h0) * pb, d.device,
+                                           (const char*)base[o] + (size_t)(k - src.h0) * pb, src.device, pb, d.stream));
+            }
+        }
+    }
+    return sync_slabs(S);
+}
+
+int remove_artifacts_slabs(const std::vector<Slab>& S, const r2s_grid* g, double threshold, double min_ratio, int64_t* n_flipped)
+{
+    const int nx = (int)g->N[0] + 1, ny = (int)g->N[1] + 1;
+    const int64_t plane = (int64_t)nx * ny;
+    const size_t G = S.size();
+    int rc = 0;
+    SlabBufs L(S), root(S), size(S), cnt(S), idx(S), val(S);
+    std::vector<uint32_t> nvox(G, 0);
+    std::vector<std::vector<uint32_t>> broots(G);                    // roots of slab q that touch an interface
+    std::vector<std::vector<uint32_t>> top(G), bot(G);               // root labels of the last / first owned plane
+    struct Cls { uint64_t size = 0, min_gid = ~0ull; };
+    std::vector<std::pair<uint64_t, uint64_t>> parent;               // (key, parent key), sorted by key after collection
+    auto key_of = [](size_t q, uint32_t r) { return ((uint64_t)q << 32) | r; };
+    std::vector<uint64_t> keys;
+    std::vector<uint64_t> par;
+    auto find = [&](uint64_t k) -> size_t {
+        size_t i = (size_t)(std::lower_bound(keys.begin(), keys.end(), k) - keys.begin());
+        while (par[i] != i) { par[i] = par[par[i]]; i = (size_t)par[i]; }
+        return i;
+    };
+    uint64_t interior = 0, largest = 0, largest_gid = ~0ull;
+    size_t largest_cls = (size_t)-1;
+    bool largest_merged = false;
+    std::vector<uint32_t> largest_local(G, NOLABEL - 1u);
+    uint64_t min_size64 = 1;
+    int64_t flipped = 0;
+    std::vector<size_t> order;   // non-empty slabs in k order
+    for (size_t q = 0; q < G; ++q)
+        if (S[q].k1 > S[q].k0) order.push_back(q);
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return S[a].k0 < S[b].k0; });
+
+    // ---- per slab: labels, roots, sizes ----
+    for (size_t q : order) {
+        const Slab& d = S[q];
+        const int64_t n64 = (int64_t)(d.k1 - d.k0) * plane;
+        if (n64 >= 0xFFFFFFFFll) return fail(R2S_ERR_ARG, "slab too large for 32-bit labels");
+        nvox[q] = (uint32_t)n64;
+        SLAB_TRY(L.ensure(q, 4 * (size_t)n64)); SLAB_TRY(root.ensure(q, 4 * (size_t)n64)); SLAB_TRY(size.ensure(q, 4 * (size_t)n64));
+        SLAB_TRY(cnt.ensure(q, 64));
+        const unsigned nb = (unsigned)((n64 + 255) / 256);
+        double* sdf = d.d_sdf + (int64_t)(d.k0 - d.h0) * plane;
+        uint32_t h[4] = {0, NOLABEL, 0, 0};
+        SLAB_HIP(hipMemcpyAsync(cnt.at<uint32_t>(q), h, sizeof h, hipMemcpyHostToDevice, d.stream));
+        SLAB_HIP(hipMemsetAsync(size.at<uint32_t>(q), 0, 4 * (size_t)n64, d.stream));
+        ccl_init_kernel<<<nb, 256, 0, d.stream>>>(sdf, nvox[q], threshold, L.at<uint32_t>(q));
+        ccl_union_kernel<<<nb, 256, 0, d.stream>>>(L.at<uint32_t>(q), nx, ny, d.k1 - d.k0);
+        ccl_flatten_count_kernel<<<nb, 256, 0, d.stream>>>(L.at<uint32_t>(q), nvox[q], root.at<uint32_t>(q), size.at<uint32_t>(q));
+        ccl_max_kernel<<<nb, 256, 0, d.stream>>>(size.at<uint32_t>(q), nvox[q], cnt.at<uint32_t>(q));   // [3]: interior voxels
+    }
+    SLAB_TRY(sync_slabs(S));
+    for (size_t q : order) {
+        const Slab& d = S[q];
+        uint32_t h[4];
+        SLAB_HIP(hipSetDevice(d.device));
+        SLAB_HIP(hipMemcpy(h, cnt.at<uint32_t>(q), sizeof h, hipMemcpyDeviceToHost));
+        interior += h[3];
+        top[q].resize((size_t)plane); bot[q].resize((size_t)plane);
+        SLAB_HIP(hipMemcpy(bot[q].data(), root.at<uint32_t>(q), 4 * (size_t)plane, hipMemcpyDeviceToHost));
+        SLAB_HIP(hipMemcpy(top[q].data(), root.at<uint32_t>(q) + (size_t)(nvox[q] - plane), 4 * (size_t)plane, hipMemcpyDeviceToHost));
+    }
+    if (interior == 0) {   // SdfArtifactRemoval.jl:150-153
+        if (n_flipped) *n_flipped = 0;
+        return 0;
+    }
+    // ---- interface merge on the host: union-find over the roots that touch an interface ----
+    for (size_t a = 0; a + 1 < order.size(); ++a) {
+        const size_t q = order[a], p = order[a + 1];
+        for (int64_t c = 0; c < plane; ++c) {
+            if (top[q][(size_t)c] != NOLABEL) keys.push_back(key_of(q, top[q][(size_t)c]));
+            if (bot[p][(size_t)c] != NOLABEL) keys.push_back(key_of(p, bot[p][(size_t)c]));
+        }
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    par.resize(keys.size());
+    for (size_t i = 0; i < par.size(); ++i) par[i] = i;
+    for (size_t a = 0; a + 1 < order.size(); ++a) {
+        const size_t q = order[a], p = order[a + 1];
+        for (int64_t c = 0; c < plane; ++c) {
+            const uint32_t ra = top[q][(size_t)c], rb = bot[p][(size_t)c];
+            if (ra == NOLABEL || rb == NOLABEL) continue;
+            const size_t ia = find(key_of(q, ra)), ib = find(key_of(p, rb));
+            if (ia != ib) par[std::max(ia, ib)] = std::min(ia, ib);
+        }
+    }
+    {
+        // sizes of the interface roots from their devices, class sizes, and back
+        std::vector<Cls> cls(keys.size());
+        std::vector<std::vector<uint32_t>> bsz(G);
+        for (size_t i = 0; i < keys.size(); ++i) broots[(size_t)(keys[i] >> 32)].push_back((uint32_t)keys[i]);
+        for (size_t q : order) {
+            const uint32_t nbq = (uint32_t)broots[q].size();
+            bsz[q].resize(nbq);
+            if (!nbq) continue;
+            const Slab& d = S[q];
+            SLAB_TRY(idx.ensure(q, 4 * (size_t)nbq)); SLAB_TRY(val.ensure(q, 4 * (size_t)nbq));
+            SLAB_HIP(hipMemcpy(idx.at<uint32_t>(q), broots[q].data(), 4 * (size_t)nbq, hipMemcpyHostToDevice));
+            gather_u32_kernel<<<(nbq + 255) / 256, 256, 0, d.stream>>>(size.at<uint32_t>(q), idx.at<uint32_t>(q), nbq, val.at<uint32_t>(q));
+            SLAB_HIP(hipMemcpyAsync(bsz[q].data(), val.at<uint32_t>(q), 4 * (size_t)nbq, hipMemcpyDeviceToHost, d.stream));
+        }
+        SLAB_TRY(sync_slabs(S));
+        {
+            std::vector<size_t> pos(G, 0);
+            for (size_t i = 0; i < keys.size(); ++i) {
+                const size_t q = (size_t)(keys[i] >> 32);
+                const size_t c = find(keys[i]);
+                cls[c].size += bsz[q][pos[q]++];
+                const uint64_t gid = (uint64_t)S[q].k0 * (uint64_t)plane + (uint32_t)keys[i];   // the root's index in the whole grid
+                cls[c].min_gid = std::min(cls[c].min_gid, gid);
+            }
+        }
+        // every interface root now carries its class size (saturated): the keep test of a slab sees the whole component
+        for (size_t q : order) {
+            const uint32_t nbq = (uint32_t)broots[q].size();
+            if (!nbq) continue;
+            const Slab& d = S[q];
+            std::vector<uint32_t> v(nbq);
+            for (uint32_t i = 0; i < nbq; ++i) {
+                const uint64_t sz = cls[find(key_of(q, broots[q][i]))].size;
+                v[i] = sz > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)sz;
+            }
+            SLAB_HIP(hipSetDevice(d.device));
+            SLAB_HIP(hipMemcpy(val.at<uint32_t>(q), v.data(), 4 * (size_t)nbq, hipMemcpyHostToDevice));
+            scatter_u32_kernel<<<(nbq + 255) / 256, 256, 0, d.stream>>>(size.at<uint32_t>(q), idx.at<uint32_t>(q), val.at<uint32_t>(q), nbq);
+        }
+        // ---- the largest component: per slab (max size, smallest root having it), then the smallest grid index among ties ----
+        for (size_t q : order) {
+            const Slab& d = S[q];
+            const unsigned nb = (unsigned)((nvox[q] + 255u) / 256u);
+            uint32_t h[4] = {0, NOLABEL, 0, 0};
+            SLAB_HIP(hipSetDevice(d.device));
+            SLAB_HIP(hipMemcpyAsync(cnt.at<uint32_t>(q), h, sizeof h, hipMemcpyHostToDevice, d.stream));
+            ccl_max_kernel<<<nb, 256, 0, d.stream>>>(size.at<uint32_t>(q), nvox[q], cnt.at<uint32_t>(q));
+            ccl_argmax_kernel<<<nb, 256, 0, d.stream>>>(size.at<uint32_t>(q), nvox[q], cnt.at<uint32_t>(q));
+        }
+        SLAB_TRY(sync_slabs(S));
+        for (size_t q : order) {
+            uint32_t h[4];
+            SLAB_HIP(hipSetDevice(S[q].device));
+            SLAB_HIP(hipMemcpy(h, cnt.at<uint32_t>(q), sizeof h, hipMemcpyDeviceToHost));
+            if (h[1] == NOLABEL) continue;
+            uint64_t sz = h[0], gid = (uint64_t)S[q].k0 * (uint64_t)plane + h[1];
+            size_t c = (size_t)-1;
+            const uint64_t k = key_of(q, h[1]);
+            const auto it = std::lower_bound(keys.begin(), keys.end(), k);
+            if (it != keys.end() && *it == k) {   // an interface root: its class decides (true size, smallest member index)
+                c = find(k);
+                sz = cls[c].size;
+                gid = cls[c].min_gid;
+            }
+            if (sz > largest || (sz == largest && gid < largest_gid)) {
+                largest = sz; largest_gid = gid; largest_cls = c; largest_merged = (c != (size_t)-1);
+                std::fill(largest_local.begin(), largest_local.end(), NOLABEL - 1u);
+                if (!largest_merged) largest_local[q] = h[1];
+            }
+        }
+        // a saturated size hides the true maximum from the slabs: an interface class larger than any saturated value wins here
+        for (size_t i = 0; i < keys.size(); ++i)
+            if (par[i] == i && (cls[i].size > largest || (cls[i].size == largest && cls[i].min_gid < largest_gid))) {
+                largest = cls[i].size; largest_gid = cls[i].min_gid; largest_cls = i; largest_merged = true;
+                std::fill(largest_local.begin(), largest_local.end(), NOLABEL - 1u);
+            }
+        {
+            // min_component_size = max(1, round(Int, ratio * largest)), ties to even (SdfArtifactRemoval.jl:206)
+            const double ms = std::nearbyint(min_ratio * (double)largest);
+            min_size64 = ms < 1.0 ? 1 : (ms > 1.8e19 ? ~0ull : (uint64_t)ms);
+        }
+        if (largest_merged) {
+            // its members are kept whatever the ratio (root == largest, :220): mark them with a size no threshold exceeds
+            for (size_t q : order) {
+                std::vector<uint32_t> ids;
+                for (uint32_t r : broots[q])
+                    if (find(key_of(q, r)) == largest_cls) ids.push_back(r);
+                if (ids.empty()) continue;
+                const Slab& d = S[q];
+                std::vector<uint32_t> v(ids.size(), 0xFFFFFFFFu);
+                SLAB_HIP(hipSetDevice(d.device));
+                SLAB_HIP(hipMemcpy(idx.at<uint32_t>(q), ids.data(), 4 * ids.size(), hipMemcpyHostToDevice));
+                SLAB_HIP(hipMemcpy(val.at<uint32_t>(q), v.data(), 4 * v.size(), hipMemcpyHostToDevice));
+                scatter_u32_kernel<<<(unsigned)((ids.size() + 255) / 256), 256, 0, d.stream>>>(size.at<uint32_t>(q), idx.at<uint32_t>(q),
+                                                                                             val.at<uint32_t>(q), (uint32_t)ids.size());
+            }
+        }
+    }
+    // ---- flip ----
+    for (size_t q : order) {
+        const Slab& d = S[q];
+        const unsigned nb = (unsigned)((nvox[q] + 255u) / 256u);
+        const uint32_t min_size = min_size64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)min_size64;
+        uint32_t h[4] = {0, NOLABEL, 0, 0};
+        SLAB_HIP(hipSetDevice(d.device));
+        SLAB_HIP(hipMemcpyAsync(cnt.at<uint32_t>(q), h, sizeof h, hipMemcpyHostToDevice, d.stream));
+        ccl_flip_kernel<<<nb, 256, 0, d.stream>>>(d.d_sdf + (int64_t)(d.k0 - d.h0) * plane, root.at<uint32_t>(q), size.at<uint32_t>(q), nvox[q],
+                                                largest_local[q], min_size, cnt.at<uint32_t>(q));
+    }
+    SLAB_TRY(sync_slabs(S));
+    for (size_t q : order) {
+        uint32_t h[4];
+        SLAB_HIP(hipSetDevice(S[q].device));
+        SLAB_HIP(hipMemcpy(h, cnt.at<uint32_t>(q), sizeof h, hipMemcpyDeviceToHost));
+        flipped += h[2];
+    }
+    if (n_flipped) *n_flipped = flipped;
+done:
+    return rc;
+}
+
+}  // namespace r2s_int
+
+namespace r2s_int {
+// RBFs_smoothing over Z-slabs (see r2s_internal.hpp).  Every step is the single-device step restricted to the
+// slab's planes; the vectors are addressed as the whole grid's (base pointer shifted by the first held plane).
+int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
+                     float* fine_out_host, float* th_out, int* cg_iters)
+{
+    if (!g || !fine_out_host) return fail(R2S_ERR_ARG, "null argument");
+    if (smooth < 1 || smooth > 4) return fail(R2S_ERR_ARG, "smooth must be 1..4");
+    if (!(kthr > 0.0 && kthr < 1.0)) return fail(R2S_ERR_ARG, "kernel threshold must be in (0,1)");
+    const int nx = (int)g->N[0] + 1, ny = (int)g->N[1] + 1, nz = (int)g->N[2] + 1;
+    const int64_t plane = (int64_t)nx * ny;
+    const int fx = (int)g->N[0] * smooth + 1, fy = (int)g->N[1] * smooth + 1, fz = (int)g->N[2] * smooth + 1;
+    const int64_t fplane = (int64_t)fx * fy;
+    const size_t G = S.size();
+    int rc = 0;
+    std::vector<size_t> order;
+    for (size_t q = 0; q < G; ++q)
+        if (S[q].k1 > S[q].k0) order.push_back(q);
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return S[a].k0 < S[b].k0; });
+    if (order.empty()) return fail(R2S_ERR_ARG, "no slab owns a plane");
+    // ---- host-side geometry (as rbf_smooth_host) ----
+    std::vector<float> cx, cy, cz, tx(fx), ty(fy), tz(fz);
+    coarse_coords(g->aabb_min[0], g->aabb_max[0], nx, cx);
+    coarse_coords(g->aabb_min[1], g->aabb_max[1], ny, cy);
+    coarse_coords(g->aabb_min[2], g->aabb_max[2], nz, cz);
+    {
+        const float xmin = (float)g->aabb_min[0], xmax = (float)g->aabb_max[0], ymin = (float)g->aabb_min[1], zmin = (float)g->aabb_min[2];
+        const float dx = (xmax - xmin) / (float)(fx - 1);
+        for (int i = 0; i < fx; ++i) tx[i] = xmin + (float)i * dx;
+        for (int i = 0; i < fy; ++i) ty[i] = ymin + (float)i * dx;
+        for (int i = 0; i < fz; ++i) tz[i] = zmin + (float)i * dx;
+    }
+    std::vector<Stencil> sts(1 + (size_t)smooth * smooth * smooth);
+    {
+        int fr0[3] = {0, 0, 0};
+        build_stencil(1, fr0, &sts[0], -std::log(kthr));
+        for (int a = 0; a < smooth; ++a)
+            for (int b = 0; b < smooth; ++b)
+                for (int c = 0; c < smooth; ++c) {
+                    int fr[3] = {c, b, a};
+                    build_stencil(smooth, fr, &sts[1 + (a * smooth + b) * smooth + c], -std::log(kthr));
+                }
+    }
+    RbfGeom G0;
+    memset(&G0, 0, sizeof G0);
+    G0.nx = nx; G0.ny = ny; G0.nz = nz;
+    G0.sigma = g->cell_size;
+    G0.thr = kthr;
+    G0.max_distance = (float)std::sqrt(-std::log(kthr) * G0.sigma * G0.sigma);
+    {
+        const double R2 = -std::log(kthr);
+        G0.tap_d2 = (int)std::floor(R2 * 1.05 + 0.25);
+        G0.tap_r = (int)std::floor(std::sqrt((double)G0.tap_d2));
+    }
+    int halo = G0.tap_r;   // planes a stencil reaches beyond the slab
+    for (const Stencil& st : sts)
+        for (int q = 0; q < st.n; ++q) halo = std::max(halo, std::max((int)st.off[q][2], -(int)st.off[q][2]));
+    for (size_t q : order)
+        if (S[q].h0 > std::max(0, S[q].k0 - halo) || S[q].h1 < std::min(nz, S[q].k1 + halo))
+            return fail(R2S_ERR_ARG, "slab [%d,%d) holds [%d,%d): the smoothing stencils need a halo of %d planes", S[q].k0, S[q].k1,
+                        S[q].h0, S[q].h1, halo);
+    // matvec through the table of distinct matrix entries when the lattice allows it (else on the fly)
+    RbfLutVals LV;
+    memset(&LV, 0, sizeof LV);
+    std::vector<uint8_t> ix, iy, iz;
+    bool use_lut = false;
+    if (is_interp && G0.tap_r >= 1 && G0.tap_r <= 3) {
+        LV.R = G0.tap_r; LV.sigma = G0.sigma; LV.thr = G0.thr;
+        use_lut = rbf_lut_axis(cx, G0.tap_r, LV.v[0], ix) && rbf_lut_axis(cy, G0.tap_r, LV.v[1], iy) && rbf_lut_axis(cz, G0.tap_r, LV.v[2], iz);
+    }
+    SlabBufs bf(S), bw(S), br(S), bu(S), bq(S), blsf(S), bfine(S), bcx(S), bcy(S), bcz(S), btx(S), bty(S), btz(S), bst(S), bcnt(S),
+        bpart(S), blut(S), bvx(S), bvy(S), bvz(S), brows(S);
+    std::vector<RbfGeom> Gq(G, G0);
+    std::vector<RbfLutGeom> LG(G);
+    std::vector<VolumeWork> vw(G);
+    std::vector<void*> base(G, nullptr);
+    auto nheld = [&](size_t q) { return (size_t)(S[q].h1 - S[q].h0) * (size_t)plane; };
+    auto vptr = [&](float* p, size_t q) { return p - (int64_t)S[q].h0 * plane; };   // whole-grid addressing of a held array
+    auto owned = [&](float* p, size_t q) { return p + (int64_t)(S[q].k0 - S[q].h0) * plane; };
+    auto nowned = [&](size_t q) { return (int64_t)(S[q].k1 - S[q].k0) * plane; };
+    auto halo_xchg = [&](SlabBufs& B, int radius) -> int {
+        for (size_t q = 0; q < G; ++q) base[q] = B.b[q].p;
+        return exchange_halo_slabs(S, base, sizeof(float), plane, radius);
+    };
+    // plane-wise dot product over all slabs, summed in k order on the host (dot_planes_kernel)
+    std::vector<std::vector<double>> hp(G);
+    auto dot = [&](SlabBufs& A, SlabBufs& B, float* out) -> int {
+        for (size_t q : order) {
+            const Slab& d = S[q];
+            HIP_TRY(hipSetDevice(d.device));
+            hp[q].resize((size_t)(d.k1 - d.k0));
+            dot_planes_kernel<<<d.k1 - d.k0, 256, 0, d.stream>>>(owned(A.at<float>(q), q), owned(B.at<float>(q), q), plane, bpart.at<double>(q));
+            HIP_TRY(hipMemcpyAsync(hp[q].data(), bpart.at<double>(q), sizeof(double) * hp[q].size(), hipMemcpyDeviceToHost, d.stream));
+        }
+        int r2 = sync_slabs(S);
+        if (r2) return r2;
+        double h = 0.0;
+        for (size_t q : order)
+            for (double v : hp[q]) h += v;
+        *out = (float)h;
+        return 0;
+    };
+    int its = 0;
+    float th = 0.0f;
+    uint32_t gmax_bits = 0;
+    bool any_real = false;
+    // ---- per-slab set-up: buffers, coordinates, stencils, tables, process_vector pass 1 ----
+    for (size_t q : order) {
+        const Slab& d = S[q];
+        const size_t nh = nheld(q);
+        SLAB_TRY(bf.ensure(q, 4 * nh)); SLAB_TRY(bw.ensure(q, 4 * nh)); SLAB_TRY(blsf.ensure(q, 4 * nh));
+        SLAB_TRY(bcnt.ensure(q, 64)); SLAB_TRY(bpart.ensure(q, sizeof(double) * (size_t)std::max(nz, 1024)));
+        if (is_interp) { SLAB_TRY(br.ensure(q, 4 * nh)); SLAB_TRY(bu.ensure(q, 4 * nh)); SLAB_TRY(bq.ensure(q, 4 * nh)); }
+        auto up = [&](SlabBufs& B, const void* src, size_t bytes) -> int {
+            int r2 = B.ensure(q, bytes);
+            if (r2) return r2;
+            HIP_TRY(hipMemcpyAsync(B.b[q].p, src, bytes, hipMemcpyHostToDevice, d.stream));
+            return 0;
+        };
+        SLAB_TRY(up(bcx, cx.data(), 4 * cx.size())); SLAB_TRY(up(bcy, cy.data(), 4 * cy.size())); SLAB_TRY(up(bcz, cz.data(), 4 * cz.size()));
+        SLAB_TRY(up(btx, tx.data(), 4 * tx.size())); SLAB_TRY(up(bty, ty.data(), 4 * ty.size())); SLAB_TRY(up(btz, tz.data(), 4 * tz.size()));
+        SLAB_TRY(up(bst, sts.data(), sizeof(Stencil) * sts.size()));
+        Gq[q].cx = bcx.at<float>(q); Gq[q].cy = bcy.at<float>(q); Gq[q].cz = bcz.at<float>(q);
+        if (use_lut) {
+            const int W = 2 * G0.tap_r + 1;
+            const size_t nT = (size_t)W * W * W * RBF_NV * RBF_NV * RBF_NV;
+            SLAB_TRY(blut.ensure(q, sizeof(float) * nT));
+            SLAB_TRY(up(bvx, ix.data(), ix.size())); SLAB_TRY(up(bvy, iy.data(), iy.size())); SLAB_TRY(up(bvz, iz.data(), iz.size()));
+            rbf_lut_build_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, d.stream>>>(LV, blut.at<float>(q));
+            memset(&LG[q], 0, sizeof(RbfLutGeom));
+            LG[q].nx = nx; LG[q].ny = ny; LG[q].nz = nz; LG[q].R = G0.tap_r; LG[q].tap_d2 = G0.tap_d2;
+            LG[q].vx = bvx.at<uint8_t>(q); LG[q].vy = bvy.at<uint8_t>(q); LG[q].vz = bvz.at<uint8_t>(q);
+            LG[q].T = blut.at<float>(q);
+        }
+        // process_vector pass 1 on the OWNED planes (every plane counts once for the maximum)
+        SLAB_HIP(hipMemsetAsync(bcnt.b[q].p, 0, 64, d.stream));
+        const int64_t no = nowned(q);
+        const unsigned nbo = (unsigned)((no + 255) / 256);
+        pv_max_kernel<<<(nbo < 2048u ? nbo : 2048u), 256, 0, d.stream>>>(d.d_sdf + (int64_t)(d.k0 - d.h0) * plane, no, owned(bf.at<float>(q), q),
+                                                                         bcnt.at<uint32_t>(q), bcnt.at<uint32_t>(q) + 1);
+    }
+    SLAB_TRY(sync_slabs(S));
+    for (size_t q : order) {
+        uint32_t hc[2];
+        SLAB_HIP(hipSetDevice(S[q].device));
+        SLAB_HIP(hipMemcpy(hc, bcnt.b[q].p, 8, hipMemcpyDeviceToHost));
+        if (hc[1]) { any_real = true; gmax_bits = std::max(gmax_bits, hc[0]); }   // non-negative floats order like their bits
+    }
+    if (!any_real) { rc = fail(R2S_ERR_ARG, "every SDF value is a sentinel: nothing to smooth"); goto done; }
+    for (size_t q : order) {
+        const Slab& d = S[q];
+        const int64_t no = nowned(q);
+        SLAB_HIP(hipSetDevice(d.device));
+        SLAB_HIP(hipMemcpyAsync(bcnt.b[q].p, &gmax_bits, 4, hipMemcpyHostToDevice, d.stream));
+        pv_replace_kernel<<<(unsigned)((no + 255) / 256), 256, 0, d.stream>>>(owned(bf.at<float>(q), q), no, bcnt.at<uint32_t>(q));
+    }
+    SLAB_TRY(sync_slabs(S));
+    // ---- weights ----
+    if (is_interp) {   // compute_rbf_weights (:191-202), the CG of rbf_smooth_host slab by slab
+        for (size_t q : order) {
+            const Slab& d = S[q];
+            SLAB_HIP(hipSetDevice(d.device));
+            SLAB_HIP(hipMemcpyAsync(owned(br.at<float>(q), q), owned(bf.at<float>(q), q), 4 * (size_t)nowned(q), hipMemcpyDeviceToDevice, d.stream));
+            SLAB_HIP(hipMemsetAsync(bu.b[q].p, 0, 4 * nheld(q), d.stream));
+            SLAB_HIP(hipMemsetAsync(bw.b[q].p, 0, 4 * nheld(q), d.stream));
+        }
+        float rr;
+        SLAB_TRY(dot(br, br, &rr));
+        float residual = std::sqrt(rr), prev = 1.0f;
+        const float tol = 3.4526698e-4f * residual;
+        const int64_t ntot = (int64_t)nz * plane;
+        while (!(residual <= tol) && its < ntot) {
+            const float beta = (residual * residual) / (prev * prev);
+            for (size_t q : order) {
+                const Slab& d = S[q];
+                const int64_t no = nowned(q);
+                SLAB_HIP(hipSetDevice(d.device));
+                cg_update_u_kernel<<<(unsigned)((no + 255) / 256), 256, 0, d.stream>>>(owned(bu.at<float>(q), q), owned(br.at<float>(q), q), beta, no);
+            }
+            SLAB_TRY(sync_slabs(S));
+            SLAB_TRY(halo_xchg(bu, G0.tap_r));
+            for (size_t q : order) {
+                const Slab& d = S[q];
+                const int64_t t0 = (int64_t)d.k0 * plane, t1 = (int64_t)d.k1 * plane;
+                const unsigned nb = (unsigned)((t1 - t0 + 255) / 256);
+                SLAB_HIP(hipSetDevice(d.device));
+                float* xv = vptr(bu.at<float>(q), q);
+                float* yv = vptr(bq.at<float>(q), q);
+                const int64_t xlo = (int64_t)d.h0 * plane, xhi = (int64_t)d.h1 * plane - 1;
+                if (use_lut && G0.tap_r == 1) rbf_matvec_lut_kernel<1><<<nb, 256, 0, d.stream>>>(LG[q], xv, yv, t0, t1, xlo, xhi);
+                else if (use_lut && G0.tap_r == 2) rbf_matvec_lut_kernel<2><<<nb, 256, 0, d.stream>>>(LG[q], xv, yv, t0, t1, xlo, xhi);
+                else if (use_lut) rbf_matvec_lut_kernel<3><<<nb, 256, 0, d.stream>>>(LG[q], xv, yv, t0, t1, xlo, xhi);
+                else rbf_matvec_kernel<<<nb, 256, 0, d.stream>>>(Gq[q], xv, yv, t0, t1);
+            }
+            float uq;
+            SLAB_TRY(dot(bu, bq, &uq));
+            const float alpha = (residual * residual) / uq;
+            for (size_t q : order) {
+                const Slab& d = S[q];
+                const int64_t no = nowned(q);
+                SLAB_HIP(hipSetDevice(d.device));
+                cg_update_xr_kernel<<<(unsigned)((no + 255) / 256), 256, 0, d.stream>>>(owned(bw.at<float>(q), q), owned(br.at<float>(q), q),
+                                                                                        owned(bu.at<float>(q), q), owned(bq.at<float>(q), q), alpha, no);
+            }
+            prev = residual;
+            SLAB_TRY(dot(br, br, &rr));
+            residual = std::sqrt(rr);
+            its++;
+        }
+    } else {
+        for (size_t q : order) {
+            SLAB_HIP(hipSetDevice(S[q].device));
+            SLAB_HIP(hipMemcpyAsync(owned(bw.at<float>(q), q), owned(bf.at<float>(q), q), 4 * (size_t)nowned(q), hipMemcpyDeviceToDevice, S[q].stream));
+        }
+        SLAB_TRY(sync_slabs(S));
+    }
+    if (cg_iters) *cg_iters = its;
+    // ---- LSF on the coarse grid (:357) ----
+    SLAB_TRY(halo_xchg(bw, halo));
+    for (size_t q : order) {
+        const Slab& d = S[q];
+        const int64_t t0 = (int64_t)d.k0 * plane, t1 = (int64_t)d.k1 * plane;
+        SLAB_HIP(hipSetDevice(d.device));
+        rbf_apply_kernel<<<(unsigned)((t1 - t0 + 255) / 256), 256, 0, d.stream>>>(Gq[q], vptr(bw.at<float>(q), q), 1, nx, ny, nz, bcx.at<float>(q),
+                                                                                bcy.at<float>(q), bcz.at<float>(q), bst.at<Stencil>(q), 0.0f,
+                                                                                vptr(blsf.at<float>(q), q), t0, t1);
+    }
+    SLAB_TRY(sync_slabs(S));
+    SLAB_TRY(halo_xchg(blsf, 1));   // the cells of the last owned plane reach into the next one
+    // ---- volume-preserving level (:359, :265-300): bisection on the summed row volumes ----
+    {
+        int lo_i = 0x7FFFFFFF, hi_i = (int)0x80000000;
+        for (size_t q : order) {
+            const Slab& d = S[q];
+            const int64_t no = nowned(q);
+            const unsigned nbo = (unsigned)((no + 255) / 256);
+            int mmh[2] = {0x7FFFFFFF, (int)0x80000000};
+            SLAB_HIP(hipSetDevice(d.device));
+            SLAB_HIP(hipMemcpyAsync(bcnt.b[q].p, mmh, 8, hipMemcpyHostToDevice, d.stream));
+            minmax_kernel<<<(nbo < 2048u ? nbo : 2048u), 256, 0, d.stream>>>(owned(blsf.at<float>(q), q), no, bcnt.at<int>(q));
+        }
+        SLAB_TRY(sync_slabs(S));
+        for (size_t q : order) {
+            int mmh[2];
+            SLAB_HIP(hipSetDevice(S[q].device));
+            SLAB_HIP(hipMemcpy(mmh, bcnt.b[q].p, 8, hipMemcpyDeviceToHost));
+            lo_i = std::min(lo_i, mmh[0]);
+            hi_i = std::max(hi_i, mmh[1]);
+        }
+        auto dec = [](int b) { b = b >= 0 ? b : (b ^ 0x7FFFFFFF); float f; memcpy(&f, &b, 4); return f; };
+        float lo = dec(lo_i), hi = dec(hi_i);
+        const size_t q0 = order[0];
+        const int nrows = (ny - 1) * (nz - 1);
+        for (size_t q : order) {
+            SLAB_HIP(hipSetDevice(S[q].device));
+            SLAB_TRY(vw[q].init(9));
+            SLAB_TRY(brows.ensure(q, sizeof(float) * (size_t)std::max(nrows, 1)));
+        }
+        const float edge = std::sqrt((cx[1] - cx[0]) * (cx[1] - cx[0]));
+        const float elvol = edge * edge * edge, jac = elvol / 8.0f;
+        double eps = 1.0;
+        int it = 0;
+        while (it < 40 && eps > 1.0e-4) {
+            th = (lo + hi) / 2;
+            for (size_t q : order) {   // rows of the cells between the slab's planes, written at their place in the whole row array
+                const Slab& d = S[q];
+                const int kc1 = std::min(d.k1, nz - 1);
+                if (kc1 <= d.k0) continue;
+                const int row0 = d.k0 * (ny - 1), nr = (kc1 - d.k0) * (ny - 1);
+                SLAB_HIP(hipSetDevice(d.device));
+                volume_rows_kernel<<<nr, 256, 0, d.stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, th, 0.0f, elvol, jac, vw[q].q,
+                                                            brows.at<float>(q), row0);
+                if (q != q0)
+                    SLAB_HIP(hipMemcpyPeerAsync(brows.at<float>(q0) + row0, S[q0].device, brows.at<float>(q) + row0, d.device,
+                                                sizeof(float) * (size_t)nr, d.stream));
+            }
+            SLAB_TRY(sync_slabs(S));
+            float vol;
+            SLAB_HIP(hipSetDevice(S[q0].device));
+            sum_f32_kernel<<<1, 256, 0, S[q0].stream>>>(brows.at<float>(q0), nrows, vw[q0].result.as<float>());
+            SLAB_HIP(hipMemcpyAsync(&vol, vw[q0].result.p, sizeof(float), hipMemcpyDeviceToHost, S[q0].stream));
+            SLAB_HIP(hipStreamSynchronize(S[q0].stream));
+            eps = std::fabs(target_volume - (double)vol);
+            if ((double)vol > target_volume) lo = th; else hi = th;
+            it++;
+        }
+        th = -th;
+        if (th_out) *th_out = th;
+    }
+    // ---- fine grid (:363-366): every slab evaluates the fine planes of its coarse planes and sends them to the caller ----
+    for (size_t q : order) {
+        const Slab& d = S[q];
+        const int f0 = d.k0 * smooth, f1 = std::min(fz, (d.k1 == nz) ? fz : d.k1 * smooth);
+        if (f1 <= f0) continue;
+        const int64_t t0 = (int64_t)f0 * fplane, t1 = (int64_t)f1 * fplane;
+        SLAB_HIP(hipSetDevice(d.device));
+        SLAB_TRY(bfine.ensure(q, 4 * (size_t)(t1 - t0)));
+        rbf_apply_kernel<<<(unsigned)((t1 - t0 + 255) / 256), 256, 0, d.stream>>>(Gq[q], vptr(bw.at<float>(q), q), smooth, fx, fy, fz, btx.at<float>(q),
+                                                                                bty.at<float>(q), btz.at<float>(q), bst.at<Stencil>(q) + 1, th,
+                                                                                bfine.at<float>(q) - t0, t0, t1);
+        SLAB_HIP(hipMemcpyAsync(fine_out_host + t0, bfine.at<float>(q), 4 * (size_t)(t1 - t0), hipMemcpyDeviceToHost, d.stream));
+    }
+    SLAB_TRY(sync_slabs(S));
+done:
+    for (size_t q = 0; q < G; ++q) {
+        (void)hipSetDevice(S[q].device);
+        vw[q].release();
+    }
+    return rc;
+}
+
 int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, double min_ratio, hipStream_t st,
                          int64_t* n_flipped)
 {

@@ -214,10 +214,18 @@ def test_single_process_fan_out(pkg, oracle, G, monkeypatch):
     d, xp = pkg.evalDistances(mesh, pg, rn, 0.5, n_gpus=G)
     d1, xp1 = pkg.evalDistances(mesh, pg, rn, 0.5)
     assert np.array_equal(d, wd) and np.array_equal(xp, xp1)
-    # the chained call with the raw SDF spread over G devices
-    rho = np.clip(rn[IEN - 1].mean(axis=1), 0, 1)
-    opts = pkg.Rho2sdfOptions(rbf_interp=False)
-    a = pkg.rho2sdf("t", X, IEN, rho, options=opts, sdf_grid=pg)
-    b = pkg.rho2sdf("t", X, IEN, rho, options=opts, sdf_grid=pg, n_gpus=G)
-    assert np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0])
+    # the chained call: raw SDF on interleaved tile layers, then connected components (labels merged over the slab
+    # interfaces), CG / RBF evaluation with halo exchanges and the level bisection on Z-slabs over the G devices.
+    # A noisy density field gives dozens of small components (some of them cut by slab interfaces) to remove.
+    rng = np.random.default_rng(17)
+    rho = np.clip(rn[IEN - 1].mean(axis=1) + rng.normal(0, 0.35, len(IEN)), 0, 1)
+    for interp, smooth in ((False, 1), (True, 1), (True, 2)):
+        opts = pkg.Rho2sdfOptions(threshold_density=0.5, rbf_interp=interp, rbf_grid="same" if smooth == 1 else "fine",
+                                  artifact_min_component_ratio=0.05)
+        ia, ib = {}, {}
+        a = pkg.rho2sdf("t", X, IEN, rho, options=opts, sdf_grid=pg, info=ia)
+        b = pkg.rho2sdf("t", X, IEN, rho, options=opts, sdf_grid=pg, n_gpus=G, info=ib)
+        assert ia["n_flipped"] == ib["n_flipped"] > 0 and ia["cg_iters"] == ib["cg_iters"] and ia["level_shift"] == ib["level_shift"]
+        assert np.array_equal(a[3], b[3]), (G, interp, smooth, "sdf_dists")
+        assert np.array_equal(a[0], b[0]), (G, interp, smooth, "fine_sdf")
     pkg._lib.lib().r2s_release_cache()
