@@ -91,6 +91,19 @@ def e2e_leg(pkg, X, IEN, rho_n, rho_t, grid, dev_index, sg):
         res[kind]["equals_device_path"] = bool(same)
         del out
     res["note"] = "r2s_sdf(host pointers): H2D mesh + kernels + D2H of 8 B/voxel; never `value`"
+    # the whole rho2sdf() with the reference's default options (rbf_interp = true, rbf_grid = :same, artifact removal) in
+    # ONE call (r2s_rho2sdf): element densities = mean of the nodal field, threshold 0.5, same grid
+    rho_e = np.ascontiguousarray(rho_n[IEN - 1].mean(axis=1))
+    opts = pkg.Rho2sdfOptions(threshold_density=float(rho_t))
+    info = {}
+    pkg.rho2sdf("bench", X, IEN, rho_e, options=opts, sdf_grid=grid, device=dev_index, pinned_results=False)     # warm-up
+    t0 = time.perf_counter()
+    pkg.rho2sdf("bench", X, IEN, rho_e, options=opts, sdf_grid=grid, device=dev_index, info=info, pinned_results=False)
+    wall = time.perf_counter() - t0
+    res["rho2sdf_default_options"] = {"ms_wall": wall * 1e3, "Mvoxels_per_s": grid.ngp / wall / 1e6, "cg_iters": info["cg_iters"],
+                                      "n_flipped": info["n_flipped"],
+                                      "stages_ms": {k[3:]: round(v, 2) for k, v in info.items() if k.startswith("ms_")}}
+    pkg._lib.lib().r2s_release_cache()
     return res
 
 
@@ -247,6 +260,7 @@ def main():
         pack2 = staticmethod(lambda local, payload, ids, masks, mids: plan.pack_tiles2(local, payload, ids, masks, mids))
         unpack = staticmethod(lambda payload, ids, n, vol: plan.unpack_tiles(payload, ids, n, grid, vol))
         unpack_masks = staticmethod(lambda masks, mids, n, vol: plan.unpack_masks(masks, mids, n, grid, vol))
+        unpack_all = staticmethod(lambda buf, world_, seglen, mf, mm, vol: plan.unpack_segments(buf, world_, seglen, mf, mm, grid, vol))
         fill = staticmethod(lambda t, v: plan.fill(t, v))
 
     sg = slabs.SlabGather((nx, ny, nz), rank, world, dev,

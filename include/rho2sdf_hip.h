@@ -217,6 +217,13 @@ int r2s_plan_pack_tiles2_dev(r2s_plan *plan, const double *d_local_sdf, double *
 int r2s_unpack_masks_dev(const uint64_t *d_masks, const uint32_t *d_mask_ids, int64_t n_tiles, const r2s_grid *grid,
                          double magnitude, double *d_volume, void *stream);
 
+/* The whole exchange buffer of the compressed stitching at once: `world` segments of `seglen` doubles, each
+ * [n_full, n_mask as two int64 | cap_full x 64 doubles | cap_full ids (uint32, padded to 8 B) | cap_mask masks |
+ * cap_mask mask ids (uint32, padded)].  The counts are read from the segment headers on the device (no host round
+ * trip, two launches for all ranks); a segment whose counts exceed the capacities is skipped. */
+int r2s_unpack_segments_dev(const double *d_buf, int32_t world, int64_t seglen, int64_t cap_full, int64_t cap_mask,
+                            const r2s_grid *grid, double magnitude, double *d_volume, void *stream);
+
 /* ---- pre-stage: mesh volume, nodal densities, volume-preserving threshold ------------- */
 
 /* calculate_mesh_volume(X, IEN, rho, HEX8) -> (V_domain, V_frac)     src/MeshGrid/MeshVolume.jl:4-42 */

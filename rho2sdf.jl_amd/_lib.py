@@ -95,6 +95,8 @@ SYMBOLS = [
     ("r2s_plan_pack_tiles2_dev", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, _P, _P, ctypes.c_int64, c_int64_p,
                                                 c_int64_p, _P]),
     ("r2s_unpack_masks_dev", ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.POINTER(R2SGrid), ctypes.c_double, _P, _P]),
+    ("r2s_unpack_segments_dev", ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                               ctypes.POINTER(R2SGrid), ctypes.c_double, _P, _P]),
     ("r2s_mesh_volume", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_int32, c_double_p, c_double_p]),
     ("r2s_dense_in_nodes", ctypes.c_int, _MESH + [ctypes.c_int32, c_double_p, ctypes.c_int32, c_double_p]),
     ("r2s_find_threshold", ctypes.c_int, _MESH + [c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int32,

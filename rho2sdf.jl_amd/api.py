@@ -255,6 +255,14 @@ class DevicePlan:
                                              DevicePlan._stream(stream)))
 
     @staticmethod
+    def unpack_segments(buf, world, seglen, cap_full, cap_mask, grid, volume, magnitude=1.0e10, stream=None):
+        """scatter every rank's segment of the exchange buffer in two launches; the tile counts are read from the segment
+        headers on the device (see r2s_unpack_segments_dev)"""
+        L.check(L.lib().r2s_unpack_segments_dev(ctypes.c_void_p(buf.data_ptr()), int(world), int(seglen), int(cap_full), int(cap_mask),
+                                                ctypes.byref(grid.c), float(magnitude), ctypes.c_void_p(volume.data_ptr()),
+                                                DevicePlan._stream(stream)))
+
+    @staticmethod
     def fill(t, value, stream=None):
         L.check(L.lib().r2s_fill_dev(ctypes.c_void_p(t.data_ptr()), int(t.numel()), float(value), DevicePlan._stream(stream)))
 
@@ -451,11 +459,12 @@ class Rho2sdfOptions:
 
 
 def rho2sdf(taskName, X, IEN, rho, *, options=None, sdf_grid=None, device=-1, export_results=False, n_gpus=1,
-            info=None, pinned_results=True):
+            info=None, pinned_results=False):
     """rho2sdf(taskName, X, IEN, rho; options) -> (fine_sdf, fine_grid, sdf_grid, sdf_dists)
     src/RhoToSDF.jl:116-242.  ONE call into the library (r2s_rho2sdf): the mesh goes up once, mesh volume ->
     nodal densities -> threshold -> raw SDF -> artifact removal -> RBF smoothing run on HBM-resident data, the two
-    result arrays come down once (into pinned arrays from r2s_host_alloc unless pinned_results=False).
+    result arrays come down once (pinned_results=True: into arrays from r2s_host_alloc - plain DMA, but pinning 1.6 GB
+    costs ~0.2 s, so it only pays when the arrays are reused; the default staged path runs within 5 % of it).
     `sdf_grid` replaces the interactive prompt of sdf_grid_setup = :manual (Grid_setup.jl:111-154 is out of scope).
     fine_grid is returned as (origin, spacing, dims) instead of one heap vector per voxel.  export_results=True
     writes the final `.vti` like RhoToSDF.jl:230-238 (the .jld2 dumps stay in the Julia package).  `info` (a dict)

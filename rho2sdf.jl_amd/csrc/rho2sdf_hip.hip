@@ -1726,6 +1726,44 @@ __global__ void __launch_bounds__(256) unpack_masks_kernel(const uint64_t* __res
     if (i < nx && j < ny && k < nz) volume[((int64_t)k * ny + j) * nx + i] = ((m >> lane) & 1ull) ? magnitude : -magnitude;
 }
 
+// The whole exchange buffer of the sparse stitching in two launches: every rank's segment is
+// [n_full, n_mask (two int64) | n_cap_full x 64 doubles | ids | masks | mask ids] (slabs.py: SlabGather), the counts
+// are read from the segment headers ON THE DEVICE, so the host neither waits for them nor launches per rank.
+// A count beyond the capacity marks a segment that was not packed (the step is repeated with larger segments).
+__global__ void __launch_bounds__(256) unpack_segments_tiles_kernel(const double* __restrict__ buf, int64_t seglen, uint32_t cap_full,
+                                                                   int nx, int ny, int nz, double* __restrict__ volume)
+{
+    const double* __restrict__ seg = buf + (int64_t)blockIdx.y * seglen;
+    const int64_t nf = reinterpret_cast<const int64_t*>(seg)[0];
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (nf < 0 || nf > (int64_t)cap_full || (int64_t)w >= nf) return;
+    const double* __restrict__ payload = seg + 2;
+    const uint32_t* __restrict__ ids = reinterpret_cast<const uint32_t*>(seg + 2 + (int64_t)cap_full * 64);
+    const int lane = threadIdx.x & 63;
+    const int ntx = (nx + 3) / 4, nty = (ny + 3) / 4;
+    const uint32_t t = ids[w];
+    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+    const int i = tx * 4 + (lane & 3), j = ty * 4 + ((lane >> 2) & 3), k = tz * 4 + (lane >> 4);
+    if (i < nx && j < ny && k < nz) volume[((int64_t)k * ny + j) * nx + i] = payload[(size_t)w * 64 + lane];
+}
+__global__ void __launch_bounds__(256) unpack_segments_masks_kernel(const double* __restrict__ buf, int64_t seglen, uint32_t cap_full,
+                                                                   uint32_t cap_mask, int nx, int ny, int nz, double magnitude,
+                                                                   double* __restrict__ volume)
+{
+    const double* __restrict__ seg = buf + (int64_t)blockIdx.y * seglen;
+    const int64_t nf = reinterpret_cast<const int64_t*>(seg)[0], nm = reinterpret_cast<const int64_t*>(seg)[1];
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (nf < 0 || nf > (int64_t)cap_full || nm < 0 || nm > (int64_t)cap_mask || (int64_t)w >= nm) return;
+    const uint64_t* __restrict__ masks = reinterpret_cast<const uint64_t*>(seg + 2 + (int64_t)cap_full * 64 + (cap_full + 1) / 2);
+    const uint32_t* __restrict__ ids = reinterpret_cast<const uint32_t*>(masks + cap_mask);
+    const int lane = threadIdx.x & 63;
+    const int ntx = (nx + 3) / 4, nty = (ny + 3) / 4;
+    const uint32_t t = ids[w];
+    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+    const int i = tx * 4 + (lane & 3), j = ty * 4 + ((lane >> 2) & 3), k = tz * 4 + (lane >> 4);
+    if (i < nx && j < ny && k < nz) volume[((int64_t)k * ny + j) * nx + i] = ((masks[w] >> lane) & 1ull) ? magnitude : -magnitude;
+}
+
 // ------------------------------------------------------------------------------------
 // plan: device workspace that survives across calls
 // ------------------------------------------------------------------------------------
@@ -2476,6 +2514,26 @@ int r2s_unpack_masks_dev(const uint64_t* d_masks, const uint32_t* d_mask_ids, in
         unpack_masks_kernel<<<(unsigned)((n_tiles + 3) / 4), 256, 0, (hipStream_t)stream>>>(
             d_masks, d_mask_ids, (uint32_t)n_tiles, (int)grid->N[0] + 1, (int)grid->N[1] + 1, (int)grid->N[2] + 1, magnitude,
             d_volume);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int r2s_unpack_segments_dev(const double* d_buf, int32_t world, int64_t seglen, int64_t cap_full, int64_t cap_mask,
+                            const r2s_grid* grid, double magnitude, double* d_volume, void* stream)
+{
+    if (!d_buf || !grid || !d_volume || world < 1 || world > 65535 || cap_full < 0 || cap_mask < 0 ||
+        cap_full >= ((int64_t)1 << 31) || cap_mask >= ((int64_t)1 << 31))
+        return fail(R2S_ERR_ARG, "r2s_unpack_segments_dev: bad argument");
+    const int64_t need = 2 + cap_full * 64 + (cap_full + 1) / 2 + cap_mask + (cap_mask + 1) / 2;
+    if (seglen < need) return fail(R2S_ERR_ARG, "segment length %lld < %lld for capacities (%lld, %lld)", (long long)seglen, (long long)need,
+                                   (long long)cap_full, (long long)cap_mask);
+    const int nx = (int)grid->N[0] + 1, ny = (int)grid->N[1] + 1, nz = (int)grid->N[2] + 1;
+    if (cap_full)
+        unpack_segments_tiles_kernel<<<dim3((unsigned)((cap_full + 3) / 4), (unsigned)world), 256, 0, (hipStream_t)stream>>>(
+            d_buf, seglen, (uint32_t)cap_full, nx, ny, nz, d_volume);
+    if (cap_mask)
+        unpack_segments_masks_kernel<<<dim3((unsigned)((cap_mask + 3) / 4), (unsigned)world), 256, 0, (hipStream_t)stream>>>(
+            d_buf, seglen, (uint32_t)cap_full, (uint32_t)cap_mask, nx, ny, nz, magnitude, d_volume);
     HIP_TRY(hipGetLastError());
     return 0;
 }

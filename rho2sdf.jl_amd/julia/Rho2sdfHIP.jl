@@ -4,8 +4,7 @@
 # Two levels:
 #   * `rho2sdf(taskName, X, IEN, rho; options)` itself (src/RhoToSDF.jl:116-242) is overridden: ONE ccall
 #     (r2s_rho2sdf) uploads the mesh once, runs mesh volume -> DenseInNodes -> threshold -> raw SDF -> artifact
-#     removal -> RBF smoothing on HBM-resident data and brings `sdf_dists` and `fine_sdf` down once, into pinned
-#     arrays.  `generateGridPoints` (3.2 GB at 512^3, :166) and the projection points `xp` (:169, discarded by the
+#     removal -> RBF smoothing on HBM-resident data and brings `sdf_dists` and `fine_sdf` down once.  `generateGridPoints` (3.2 GB at 512^3, :166) and the projection points `xp` (:169, discarded by the
 #     reference) are never materialised.  All file exports stay Julia code and run on the returned arrays.
 #   * every function `rho2sdf` and the reference's tests call directly keeps a ccall-backed method with the
 #     reference's signature (leaf overrides), for callers that use the stages one by one.
@@ -81,9 +80,13 @@ function check(rc::Cint)
     error("rho2sdf_hip: $msg")          # same behaviour as the reference's error(...)
 end
 
-# Result arrays on pinned host memory (r2s_host_alloc): the device -> host copy is then one DMA at PCIe rate.
-# The array owns nothing; a finalizer returns the block to the library.
+# Result arrays.  Ordinary Julia arrays by default: the library brings results down through pinned staging buffers
+# with a multi-threaded copy, within 5 % of a plain DMA (24.9 vs 24.1 ms for 1 GB).  PINNED[] = true allocates them
+# with r2s_host_alloc instead (the copy is then one DMA) - pinning 1.6 GB costs ~0.2 s per call, so that only pays
+# for callers that keep and reuse the arrays.  The array owns nothing; a finalizer returns the block to the library.
+const PINNED = Ref(false)
 function pinned(::Type{T}, dims::Int...) where {T}
+    PINNED[] || return Array{T}(undef, dims...)
     n = prod(dims)
     p = ccall((:r2s_host_alloc, LIB[]), Ptr{Cvoid}, (Csize_t,), max(n, 1) * sizeof(T))
     p == C_NULL && error("rho2sdf_hip: " * unsafe_string(ccall((:r2s_last_error, LIB[]), Cstring, ())))

@@ -69,6 +69,7 @@ class SlabGather:
             self.my_planes = self.k1 - self.k0
         self._ordered = None
         self._cap = None          # sparse stitching: agreed segment capacities (band tiles, sign-only tiles)
+        self._buf = self._hdr = self._mine_hdr = None
         self.n_collectives = 0
         self.last_counts = None
         if self.sparse:
@@ -126,9 +127,15 @@ class SlabGather:
         while True:
             mf, mm = self._cap
             seglen = 2 + mf * 64 + (mf + 1) // 2 + mm + (mm + 1) // 2
-            buf = torch.empty(self.world * seglen, dtype=self.dtype, device=self.device)
+            if self._buf is None or self._buf.numel() != self.world * seglen:
+                # the exchange buffer lives as long as the capacities: no allocation per step
+                self._buf = torch.empty(self.world * seglen, dtype=self.dtype, device=self.device)
+                self._hdr = torch.empty((self.world, 2), dtype=torch.int64, pin_memory=(self.device.type == "cuda"))
+                self._mine_hdr = torch.empty(2, dtype=torch.int64, pin_memory=(self.device.type == "cuda"))
+            buf = self._buf
             seg = buf[self.rank * seglen:(self.rank + 1) * seglen]
-            seg[:2].view(torch.int64).copy_(torch.tensor([nf_mine, nm_mine], dtype=torch.int64))
+            self._mine_hdr[0], self._mine_hdr[1] = nf_mine, nm_mine
+            seg[:2].view(torch.int64).copy_(self._mine_hdr, non_blocking=True)
             if nf_mine <= mf and nm_mine <= mm and (nf_mine or nm_mine):
                 payload, ids, masks, mids = self._segment_views(seg[2:], mf, mm)
                 got = self.ops.pack2(self.my_slab, payload, ids, masks, mids)
@@ -141,18 +148,32 @@ class SlabGather:
                 self.ops.fill(self.full, SENTINEL)
                 filled = True
             work.wait()
-            allc = buf.view(self.world, seglen)[:, :2].contiguous().view(torch.int64).tolist()
-            if all(int(c[0]) <= mf and int(c[1]) <= mm for c in allc):
+            hdr_view = buf.view(self.world, seglen)[:, :2]
+            if hasattr(self.ops, "unpack_all"):
+                # device-side counts: the scatter of every rank's segment is queued (two launches) before the host has
+                # seen a single count; the headers come back beside it and are only needed for the overflow decision
+                self._hdr.copy_(hdr_view.contiguous().view(torch.int64), non_blocking=True)
+                self.ops.unpack_all(buf, self.world, seglen, mf, mm, self.full)
+                if self.device.type == "cuda":
+                    torch.cuda.current_stream(self.device).synchronize()
+                allc = self._hdr.tolist()
+                done = all(int(c[0]) <= mf and int(c[1]) <= mm for c in allc)
+            else:
+                allc = hdr_view.contiguous().view(torch.int64).tolist()
+                done = all(int(c[0]) <= mf and int(c[1]) <= mm for c in allc)
+                if done:
+                    for r, (cf, cm) in enumerate(allc):
+                        payload, ids, masks, mids = self._segment_views(buf[r * seglen + 2:(r + 1) * seglen], mf, mm)
+                        if cf:
+                            self.ops.unpack(payload[:int(cf) * 64], ids[:int(cf)], int(cf), self.full)
+                        if cm:
+                            self.ops.unpack_masks(masks[:int(cm)], mids[:int(cm)], int(cm), self.full)
+            if done:
                 break
             self._cap = (grow(max(int(c[0]) for c in allc)), grow(max(int(c[1]) for c in allc)))
+            filled = False       # (segments that did fit were scattered already: start the volume again)
         self.last_counts = allc
         self.last_bytes = buf.numel() * buf.element_size()
-        for r, (cf, cm) in enumerate(allc):
-            payload, ids, masks, mids = self._segment_views(buf[r * seglen + 2:(r + 1) * seglen], mf, mm)
-            if cf:
-                self.ops.unpack(payload[:int(cf) * 64], ids[:int(cf)], int(cf), self.full)
-            if cm:
-                self.ops.unpack_masks(masks[:int(cm)], mids[:int(cm)], int(cm), self.full)
 
     def volume(self):
         """the stitched (nz, ny, nx) volume (padding trimmed, tile layers back in lattice order)"""

@@ -249,9 +249,11 @@ def test_compressed_tile_stitching_equals_full_volume(pkg, oracle, tets):
             vol = torch.empty_like(full)
             plan.fill(vol, -1.0e10)
             n_full = n_mask = 0
+            segs = []
             for r in range(world):
                 owned, _ = slabs.interleaved_layers(nz, world, r)
                 if not owned:
+                    segs.append((0, 0, None, None, None, None))
                     continue
                 local = torch.empty(4 * owned * ny * nx, dtype=torch.float64, device=dev)
                 st = plan.run(dX, dI, dR, 0.5, pg, sdf=local, zstride=world, zphase=r)
@@ -264,11 +266,29 @@ def test_compressed_tile_stitching_equals_full_volume(pkg, oracle, tets):
                 assert plan.pack_tiles2(local, payload, ids, masks, mids) == (nf, nm)
                 plan.unpack_tiles(payload, ids, nf, pg, vol)
                 plan.unpack_masks(masks, mids, nm, pg, vol)
+                segs.append((nf, nm, payload, ids, masks, mids))
                 n_full += nf
                 n_mask += nm
             torch.cuda.synchronize()
             assert torch.equal(vol, full), f"{world} ranks, {npts}^3: compressed stitching differs"
             assert n_mask > 0 or npts < 100     # the finer grid has tiles deep inside the solid
+            # the same exchange as ONE buffer of `world` segments scattered by r2s_unpack_segments_dev (counts read from
+            # the segment headers on the device), laid out exactly as slabs.SlabGather lays it out
+            mf, mm = max(segs, key=lambda c: c[0])[0] + 3, max(segs, key=lambda c: c[1])[1] + 2
+            seglen = 2 + mf * 64 + (mf + 1) // 2 + mm + (mm + 1) // 2
+            buf = torch.zeros(world * seglen, dtype=torch.float64, device=dev)
+            for r, (nf, nm, payload, ids, masks, mids) in enumerate(segs):
+                seg = buf[r * seglen:(r + 1) * seglen]
+                seg[:2].view(torch.int64).copy_(torch.tensor([nf, nm]))
+                if payload is None:
+                    continue
+                p2, i2, m2, mi2 = slabs.SlabGather._segment_views(seg[2:], mf, mm)
+                p2[:nf * 64].copy_(payload[:nf * 64]); i2[:nf].copy_(ids[:nf]); m2[:nm].copy_(masks[:nm]); mi2[:nm].copy_(mids[:nm])
+            vol2 = torch.empty_like(full)
+            plan.fill(vol2, -1.0e10)
+            plan.unpack_segments(buf, world, seglen, mf, mm, pg, vol2)
+            torch.cuda.synchronize()
+            assert torch.equal(vol2, full), f"{world} ranks, {npts}^3: segment-wide scatter differs"
     plan.close()
 
 

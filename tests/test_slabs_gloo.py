@@ -87,7 +87,23 @@ class NumpyTileOps:
         t.fill_(value)
 
 
-def _worker(rank, world, port, ref_path, dims, interleaved, sparse=False):
+class NumpyTileOpsAll(NumpyTileOps):
+    """+ the stand-in of r2s_unpack_segments_dev: every rank's segment in one call, counts read from the segment headers
+    (a segment whose counts exceed the capacities is skipped, as on the device)"""
+
+    def unpack_all(self, buf, world, seglen, mf, mm, vol):
+        from rho2sdf_jl_amd import slabs
+        for r in range(world):
+            seg = buf[r * seglen:(r + 1) * seglen]
+            cf, cm = (int(c) for c in seg[:2].view(torch.int64))
+            if cf > mf or cm > mm:
+                continue
+            payload, ids, masks, mids = slabs.SlabGather._segment_views(seg[2:], mf, mm)
+            self.unpack(payload, ids, cf, vol)
+            self.unpack_masks(masks, mids, cm, vol)
+
+
+def _worker(rank, world, port, ref_path, dims, interleaved, sparse=False, device_counts=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -96,7 +112,7 @@ def _worker(rank, world, port, ref_path, dims, interleaved, sparse=False):
     graft.load_package()
     from rho2sdf_jl_amd import slabs
     ref = torch.from_numpy(np.load(ref_path))
-    ops = NumpyTileOps(dims, world, rank)
+    ops = (NumpyTileOpsAll if device_counts else NumpyTileOps)(dims, world, rank)
     sg = slabs.SlabGather(dims, rank, world, torch.device("cpu"), interleaved=interleaved, sparse=sparse, ops=ops)
     plane = dims[0] * dims[1]
     nz = dims[2]
@@ -171,10 +187,12 @@ def test_slab_bounds():
     assert slabs.interleaved_layers(17, 8, 5) == (0, 1)
 
 
+@pytest.mark.parametrize("device_counts", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sparse_tile_allgather(oracle, tmp_path, world):
+def test_sparse_tile_allgather(oracle, tmp_path, world, device_counts):
     """sparse stitching: only non-sentinel 4x4x4 tiles travel, sign-only tiles as 64-bit masks (counts + ONE padded
-    all-gather + scatter)"""
+    all-gather + scatter); device_counts: the scatter reads the counts from the segment headers itself
+    (r2s_unpack_segments_dev on the GPU, NumpyTileOpsAll here) instead of waiting for the host to read them"""
     X, IEN, rho = load_fixture("sphere")
     rn = oracle.dense_in_nodes(X, IEN, rho)
     g = oracle.grid_make(X.min(0), X.max(0), 10)
@@ -183,5 +201,5 @@ def test_sparse_tile_allgather(oracle, tmp_path, world):
     assert (sdf == -1.0e10).sum() > 1000          # the case has plenty of sentinel tiles to skip
     ref_path = str(tmp_path / "ref.npy")
     np.save(ref_path, sdf)
-    port = 29700 + (os.getpid() % 200) + world
-    mp.spawn(_worker, args=(world, port, ref_path, g.dims, True, True), nprocs=world, join=True)
+    port = 29700 + (os.getpid() % 200) + world + (20 if device_counts else 0)
+    mp.spawn(_worker, args=(world, port, ref_path, g.dims, True, True, device_counts), nprocs=world, join=True)
