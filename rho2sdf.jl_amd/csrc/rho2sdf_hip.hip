@@ -1197,7 +1197,7 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
                                                           SlabInfo sl, double rho_t, const uint8_t* __restrict__ hot,
                                                           double* __restrict__ res, const uint32_t* __restrict__ abort_flag)
 {
-    if (*abort_flag) return;   // speculated sizes of this call did not hold (run_impl)
+    const uint32_t ab = *abort_flag;   // (tested after the search below: its loads do not wait for this one)
     __shared__ uint32_t queue[128];
     const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     uint32_t c = w * cpw;
@@ -1208,6 +1208,7 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
         const uint32_t mid = (lo + hi) >> 1;
         if (chunk_off[mid] <= c) lo = mid; else hi = mid;
     }
+    if (ab) return;   // speculated sizes of this call did not hold (run_impl)
     const uint32_t lane = threadIdx.x & 63;
     while (c < c_end) {
         lo = __builtin_amdgcn_readfirstlane(lo);

@@ -25,5 +25,12 @@ echo "sq1 done"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --output-format csv -d $OUT/prof_$TAG/sq2 -- python3 $ROOT/tools/profile_modes.py --modes sdf --reps 2 > /dev/null
 echo "sq2 done"
 python3 $ROOT/tools/pmc_summary.py $OUT/prof_$TAG/sq1 $OUT/prof_$TAG/sq2 --out $OUT/${TAG}_valu_counters.json > $OUT/${TAG}_valu_counters.txt
+# post-processing kernels (RBF smoothing with the CG, 512^3): kernel-trace stats + HBM traffic of the CG matvec
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/rbf -- python3 $ROOT/tools/rbf_bench.py --interp --reps 2 > $OUT/${TAG}_rbf_bench.json
+cp $(ls $OUT/prof_$TAG/rbf/*/*kernel_stats.csv | head -1) $OUT/${TAG}_rbf_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_$TAG/rbf_fetch -- python3 $ROOT/tools/rbf_bench.py --interp --reps 1 > /dev/null
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_$TAG/rbf_write -- python3 $ROOT/tools/rbf_bench.py --interp --reps 1 > /dev/null
+python3 $ROOT/tools/collect_traffic.py $OUT/prof_$TAG/rbf_fetch $OUT/prof_$TAG/rbf_write $OUT/${TAG}_rbf_traffic.json
+echo "rbf done"
 rm -rf $OUT/prof_$TAG
 echo "profile_round $TAG complete"
