@@ -734,17 +734,20 @@ __global__ void __launch_bounds__(256) dot_kernel(const float* __restrict__ a, c
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-// Dot product as one Float64 partial sum per Z plane (fixed tree inside the plane); the planes are added in k order on
-// the host.  The result does not depend on how the planes are spread over devices: a Z-slab run of the CG follows the
-// single-device run bit for bit.
+// Dot product as DOT_PARTS Float64 partial sums per Z plane (fixed tree inside each part); the parts are added in
+// (k, part) order on the host.  The result does not depend on how the planes are spread over devices: a Z-slab run of
+// the CG follows the single-device run bit for bit.
+#define DOT_PARTS 4
 __global__ void __launch_bounds__(256) dot_planes_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t plane,
                                                         double* __restrict__ partial)
 {
     __shared__ double red[256];
-    const float* __restrict__ pa = a + (int64_t)blockIdx.x * plane;
-    const float* __restrict__ pb = b + (int64_t)blockIdx.x * plane;
+    const int64_t k = blockIdx.x / DOT_PARTS, part = blockIdx.x % DOT_PARTS;
+    const int64_t chunk = (plane + DOT_PARTS - 1) / DOT_PARTS, lo = part * chunk, hi = (lo + chunk < plane) ? lo + chunk : plane;
+    const float* __restrict__ pa = a + k * plane;
+    const float* __restrict__ pb = b + k * plane;
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < plane; i += 256) acc += (double)pa[i] * (double)pb[i];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += (double)pa[i] * (double)pb[i];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -917,14 +920,14 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         ENSURE_C(d_r, sizeof(float) * (size_t)n);
         ENSURE_C(d_u, sizeof(float) * (size_t)n);
         ENSURE_C(d_q, sizeof(float) * (size_t)n);
-        ENSURE_C(d_part, sizeof(double) * (size_t)std::max(nz, 1024));
+        ENSURE_C(d_part, sizeof(double) * (size_t)std::max(nz * DOT_PARTS, 1024));
         ENSURE_C(d_sum, 64);
         auto dot = [&](const float* a, const float* b, float* out) -> int {
-            dot_planes_kernel<<<nz, 256, 0, st>>>(a, b, (int64_t)nx * ny, d_part.as<double>());
-            std::vector<double> hp((size_t)nz);
-            HIP_TRY(hipMemcpy(hp.data(), d_part.p, sizeof(double) * (size_t)nz, hipMemcpyDeviceToHost));
+            dot_planes_kernel<<<nz * DOT_PARTS, 256, 0, st>>>(a, b, (int64_t)nx * ny, d_part.as<double>());
+            std::vector<double> hp((size_t)nz * DOT_PARTS);
+            HIP_TRY(hipMemcpy(hp.data(), d_part.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
             double h = 0.0;
-            for (int k = 0; k < nz; ++k) h += hp[(size_t)k];   // planes in k order (see dot_planes_kernel)
+            for (double v : hp) h += v;   // parts in (k, part) order (see dot_planes_kernel)
             *out = (float)h;
             return 0;
         };
@@ -1419,8 +1422,8 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         for (size_t q : order) {
             const Slab& d = S[q];
             HIP_TRY(hipSetDevice(d.device));
-            hp[q].resize((size_t)(d.k1 - d.k0));
-            dot_planes_kernel<<<d.k1 - d.k0, 256, 0, d.stream>>>(owned(A.at<float>(q), q), owned(B.at<float>(q), q), plane, bpart.at<double>(q));
+            hp[q].resize((size_t)(d.k1 - d.k0) * DOT_PARTS);
+            dot_planes_kernel<<<(d.k1 - d.k0) * DOT_PARTS, 256, 0, d.stream>>>(owned(A.at<float>(q), q), owned(B.at<float>(q), q), plane, bpart.at<double>(q));
             HIP_TRY(hipMemcpyAsync(hp[q].data(), bpart.at<double>(q), sizeof(double) * hp[q].size(), hipMemcpyDeviceToHost, d.stream));
         }
         int r2 = sync_slabs(S);
@@ -1440,7 +1443,7 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         const Slab& d = S[q];
         const size_t nh = nheld(q);
         SLAB_TRY(bf.ensure(q, 4 * nh)); SLAB_TRY(bw.ensure(q, 4 * nh)); SLAB_TRY(blsf.ensure(q, 4 * nh));
-        SLAB_TRY(bcnt.ensure(q, 64)); SLAB_TRY(bpart.ensure(q, sizeof(double) * (size_t)std::max(nz, 1024)));
+        SLAB_TRY(bcnt.ensure(q, 64)); SLAB_TRY(bpart.ensure(q, sizeof(double) * (size_t)std::max(nz * DOT_PARTS, 1024)));
         if (is_interp) { SLAB_TRY(br.ensure(q, 4 * nh)); SLAB_TRY(bu.ensure(q, 4 * nh)); SLAB_TRY(bq.ensure(q, 4 * nh)); }
         auto up = [&](SlabBufs& B, const void* src, size_t bytes) -> int {
             int r2 = B.ensure(q, bytes);
