@@ -31,6 +31,12 @@ struct alignas(16) ElemRec {
     // Sign_Detection's candidate test cannot accept it and the Newton solve is skipped (exact pruning)
     double pn[6][3];
     double po[6];
+    // the same six normals with INNER offsets: pn[f].x <= pi[f] for all f describes a convex region that lies inside the
+    // element (every bilinear face patch lies in the hull of its four corners, i.e. beyond its inner plane; the region
+    // holds the image of xi = 0 and cannot cross a face).  A lattice point in it has local coordinates with
+    // max|xi| <= 1 without any Newton solve (sign_project_kernel uses it for elements whose nodal densities all exceed
+    // rho_t).  -inf: no inner region (degenerate / inverted element).
+    double pi[6];
     // first Newton step of the inverse map (xi = 0): rows of the adjugate of J(0) = [C1 C2 C3] and 1/det
     double nw[10];
 };
@@ -143,7 +149,7 @@ R2S_DEV void hex8_monomials(ElemRec& R)
 // product of the two in-face tangents at the face centre, oriented along s * dX/dxi_a; offset = max of
 // n.X over the 8 corners of the cube |xi| = 1.011 (a trilinear map takes the cube into the convex hull of
 // the corner images) plus a rounding margin.  Degenerate faces give n = 0 and never reject.
-R2S_DEV void hex8_plane(const ElemRec& R, int a, int sg, double n[3], double& po)
+R2S_DEV void hex8_plane(const ElemRec& R, int a, int sg, double n[3], double& po, double& pin)
 {
     const double lamb = 1.011;
     double ext = 0.0;
@@ -178,6 +184,44 @@ R2S_DEV void hex8_plane(const ElemRec& R, int a, int sg, double n[3], double& po
     }
     const double nn = fabs(n[0]) + fabs(n[1]) + fabs(n[2]);
     po = off + 1e-9 * nn * ext;
+    // inner offset: min of n.X over the four corners of the face xi_a = s, minus the rounding margin; valid only when the
+    // element is not inverted anywhere (Jacobian determinant of one sign at the centre and the eight corners) and its
+    // centre lies strictly inside this half-space
+    double inner = INFINITY;
+    for (int k = 0; k < 4; ++k) {
+        double c[3];
+        c[a] = s;
+        c[(a + 1) % 3] = (k & 1) ? 1.0 : -1.0;
+        c[(a + 2) % 3] = (k & 2) ? 1.0 : -1.0;
+        double v = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const double Xi = R.C[0][i] + c[0] * R.C[1][i] + c[1] * R.C[2][i] + c[2] * R.C[3][i] + c[0] * c[1] * R.C[4][i] +
+                              c[0] * c[2] * R.C[5][i] + c[1] * c[2] * R.C[6][i] + c[0] * c[1] * c[2] * R.C[7][i];
+            v += n[i] * Xi;
+        }
+        inner = fmin(inner, v);
+    }
+    inner -= 1e-9 * nn * ext;
+    bool ok = along != 0.0 && nn > 0.0;
+    double sgn = 0.0;
+    for (int k = 0; k < 9 && ok; ++k) {   // k = 8: the centre
+        const double c0 = k == 8 ? 0.0 : ((k & 1) ? 1.0 : -1.0), c1 = k == 8 ? 0.0 : ((k & 2) ? 1.0 : -1.0),
+                     c2 = k == 8 ? 0.0 : ((k & 4) ? 1.0 : -1.0);
+        double Jc[3][3];
+        for (int i = 0; i < 3; ++i) {
+            Jc[i][0] = R.C[1][i] + c1 * R.C[4][i] + c2 * R.C[5][i] + c1 * c2 * R.C[7][i];
+            Jc[i][1] = R.C[2][i] + c0 * R.C[4][i] + c2 * R.C[6][i] + c0 * c2 * R.C[7][i];
+            Jc[i][2] = R.C[3][i] + c0 * R.C[5][i] + c1 * R.C[6][i] + c0 * c1 * R.C[7][i];
+        }
+        const double det = Jc[0][0] * (Jc[1][1] * Jc[2][2] - Jc[1][2] * Jc[2][1]) - Jc[0][1] * (Jc[1][0] * Jc[2][2] - Jc[1][2] * Jc[2][0]) +
+                           Jc[0][2] * (Jc[1][0] * Jc[2][1] - Jc[1][1] * Jc[2][0]);
+        if (!(det != 0.0)) ok = false;
+        else if (sgn == 0.0) sgn = det;
+        else if ((det > 0.0) != (sgn > 0.0)) ok = false;
+    }
+    const double centre = n[0] * R.C[0][0] + n[1] * R.C[0][1] + n[2] * R.C[0][2];
+    if (!(centre < inner)) ok = false;
+    pin = ok ? inner : -INFINITY;
 }
 
 // constants of the inverse map's first Newton step (see inv_map_hex8): the cofactor / det / reciprocal
@@ -212,6 +256,17 @@ R2S_DEV bool hex8_outside(const ER& E, const double x[3])
     for (int f = 0; f < 6; ++f)
         out = out || (E.pn[f][0] * x[0] + E.pn[f][1] * x[1] + E.pn[f][2] * x[2] > E.po[f]);
     return out;
+}
+
+// true when x lies in the inner region (ElemRec::pi): inside the element, max|xi| <= 1, no Newton solve needed
+template <class ER>
+R2S_DEV bool hex8_inner(const ER& E, const double x[3])
+{
+    bool in = true;
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+        in = in && (E.pn[f][0] * x[0] + E.pn[f][1] * x[1] + E.pn[f][2] * x[2] <= E.pi[f]);
+    return in;
 }
 
 // value, gradient and mixed second derivatives of one scalar trilinear field (12 FMAs)

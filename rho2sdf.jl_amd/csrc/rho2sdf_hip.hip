@@ -367,10 +367,11 @@ __global__ void hex_planes_kernel(ElemRec* __restrict__ erec, int64_t nel)
     const int64_t el = gid / 6;
     const int f = (int)(gid % 6);
     if (el >= nel) return;
-    double n[3], po;
-    hex8_plane(erec[el], f >> 1, f & 1, n, po);
+    double n[3], po, pin;
+    hex8_plane(erec[el], f >> 1, f & 1, n, po, pin);
     erec[el].pn[f][0] = n[0]; erec[el].pn[f][1] = n[1]; erec[el].pn[f][2] = n[2];
     erec[el].po[f] = po;
+    erec[el].pi[f] = pin;
 }
 
 // boundary faces (sdfOnDensityField.jl:511-519): a face is on the boundary when exactly one element (this one)
@@ -594,14 +595,18 @@ __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, con
             // SQP needs tens of iterations - they go first in the work order (work_order_kernel)
             double dmin = INFINITY;
             for (int k = 0; k < 8; ++k) dmin = fmin(dmin, fabs(E.r[k] - rho_t));
-            hard[w] = dmin < 0.1 * (E.rmax - E.rmin) ? 1 : 0;
+            // rank 0 (hardest) .. 15: distance of the nearest nodal density from the threshold in 1/32 of the element's
+            // density range (round 2: the dozen wavefronts that used to end the kernel 0.3-0.7 ms after the work ran dry
+            // each held ONE voxel of an element with a ratio of 0.10-0.17, just beyond the former yes/no limit of 0.1)
+            const double ratio = dmin / (E.rmax - E.rmin);
+            hard[w] = (uint8_t)(ratio < 15.0 / 32.0 ? (int)(ratio * 32.0) : 15);
         }
         items[w++] = T;
     }
 }
 
 // Work order of the persistent projection kernel (HEX8): items whose iso-surface passes close to a node come
-// first.  Those are the elements the surface only clips near a corner or follows along a face, and that is where
+// first (16 ranks, see item_build_kernel).  Those are the elements the surface only clips near a corner or follows along a face, and that is where
 // the SQP needs tens of iterations (degenerate or nearly infeasible sub-problems) instead of four.  A lane works
 // through such a voxel alone, so when one of them is handed out near the end of the kernel everything waits for
 // it (the drain phase used to be a quarter of the kernel's run time); handed out first, it finishes in the
@@ -611,16 +616,20 @@ __global__ void __launch_bounds__(1024) work_order_kernel(const uint8_t* __restr
                                                           uint32_t nitems, uint32_t* __restrict__ perm,
                                                           uint32_t* __restrict__ wchunks)
 {
-    __shared__ uint32_t n_hard, c_hard, c_easy;
-    if (threadIdx.x == 0) { n_hard = 0; c_hard = 0; c_easy = 0; }
+    // counting sort over the 16 hardness ranks (rank 0 first); items that are not iso items carry rank 0 and no chunks
+    __shared__ uint32_t cnt[16], base[16], cur[16];
+    if (threadIdx.x < 16) { cnt[threadIdx.x] = 0; cur[threadIdx.x] = 0; }
     __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t it = threadIdx.x; it < nitems; it += blockDim.x) mine += hard[it] ? 1u : 0u;
-    if (mine) atomicAdd(&n_hard, mine);
+    for (uint32_t it = threadIdx.x; it < nitems; it += blockDim.x) atomicAdd(&cnt[hard[it] & 15], 1u);
     __syncthreads();
-    const uint32_t nh = n_hard;
+    if (threadIdx.x == 0) {
+        uint32_t b = 0;
+        for (int q = 0; q < 16; ++q) { base[q] = b; b += cnt[q]; }
+    }
+    __syncthreads();
     for (uint32_t it = threadIdx.x; it < nitems; it += blockDim.x) {
-        const uint32_t pos = hard[it] ? atomicAdd(&c_hard, 1u) : nh + atomicAdd(&c_easy, 1u);
+        const uint32_t r = hard[it] & 15;
+        const uint32_t pos = base[r] + atomicAdd(&cur[r], 1u);
         perm[pos] = it;
         wchunks[pos] = nchunks[it];
     }
@@ -897,9 +906,14 @@ struct IsoElemLds {
 #endif
 #ifdef R2S_ISO_WAVE_END   // diagnostic build only (tools/iso_phase_stats.py): when the wavefronts of the kernel leave
 __device__ unsigned long long g_iso_wave_end[4096];   // wall_clock64 at the exit of every wavefront; [4094]: a start
+__device__ unsigned long long g_iso_wave_info[4096 * 4];   // per wavefront: time the work ran dry for it, last item, trips and busy lanes at that time
 extern "C" int r2s_debug_iso_wave_end(unsigned long long* out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iso_wave_end), sizeof(unsigned long long) * 4096) != hipSuccess;
+}
+extern "C" int r2s_debug_iso_wave_info(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iso_wave_info), sizeof(unsigned long long) * 4096 * 4) != hipSuccess;
 }
 #endif
 #ifdef R2S_ISO_STATS   // diagnostic build only (tools/iso_phase_stats.py): visits and active lanes per phase
@@ -1018,7 +1032,17 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
                         uint32_t cc = 0;
                         if (lane == 0) cc = atomicAdd(counter, group);
                         c = __builtin_amdgcn_readfirstlane(cc);
-                        if (c >= nchunks) { exhausted = true; break; }
+                        if (c >= nchunks) {
+#ifdef R2S_ISO_WAVE_END
+                            if (!exhausted && lane == 0 && blockIdx.x < 4094) {
+                                g_iso_wave_info[4 * blockIdx.x] = wall_clock64();
+                                g_iso_wave_info[4 * blockIdx.x + 1] = it;
+                                g_iso_wave_info[4 * blockIdx.x + 2] = (unsigned long long)__popcll(__ballot(s.phase != ISO_IDLE && s.phase != ISO_DONE));
+                            }
+#endif
+                            exhausted = true;
+                            break;
+                        }
                         c_end = (c + group < nchunks) ? c + group : nchunks;
                     }
                     if (!(have_item && c >= co && c < cn)) {
@@ -1223,6 +1247,9 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
         const int lo0 = B.lo[0], lo1 = B.lo[1], lo2 = B.lo[2];
         const uint32_t st_off = store_off[lo];
         const TileBox tb = tile_box(B.lo, B.dim);
+        // (margin: sum N_k r_k of the reference is a rounded convex combination; with r_min strictly above rho_t by more
+        //  than its rounding it is >= rho_t for every xi in the cube)
+        const bool solid = E.rmin > rho_t + 1e-9 * fmax(1.0, fabs(rho_t));
         uint32_t qn = 0;   // wave-uniform queue length
         for (uint32_t v0 = v_begin; v0 < v_end || qn > 0; v0 += 64u) {
             if (v0 < v_end) {
@@ -1239,6 +1266,13 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
                     const uint32_t t = ((uint32_t)(kl >> 2) * sl.nty + (uint32_t)(j >> 2)) * sl.ntx + (uint32_t)(i >> 2);
                     pass = hot[t] && !hex8_outside(E, x);
                     if (!pass) res[tile_slot(st_off, tb, i, j, kl)] = INFINITY;
+                    else if (solid && hex8_inner(E, x)) {
+                        // inside an element whose densities all exceed rho_t: max|xi| <= 1 and rho(xi) >= rho_t whatever xi
+                        // is; the state machine of the gather only needs "holds the point, counts as +1, ends the walk"
+                        // (in a conforming mesh no earlier candidate can hold a point this deep inside another element)
+                        res[tile_slot(st_off, tb, i, j, kl)] = 0.0;
+                        pass = false;
+                    }
                 }
                 const uint64_t m = __ballot(pass);
                 if (pass) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = v;

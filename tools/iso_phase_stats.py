@@ -38,4 +38,7 @@ print("pairs with >= 256 trips:", lng[0])
 for k in range(min(int(lng[0]), 63)):
     w = lng[8 * (k + 1): 8 * (k + 2)]
     xyz = [struct.unpack("d", struct.pack("Q", v))[0] for v in w[1:4]]
-    print("LONG el %d x %.17g %.17g %.17g its %d trips %d qp %d ls %d" % (w[0], xyz[0], xyz[1], xyz[2], w[4], w[5], w[6], w[7]))
+    re = rn[IEN[w[0]] - 1]
+    dmin = abs(re - 0.5).min()
+    print("LONG el %d x %.6g %.6g %.6g its %d trips %d qp %d ls %d | hard-flag %s dmin/range %.3f" % (
+        w[0], xyz[0], xyz[1], xyz[2], w[4], w[5], w[6], w[7], dmin < 0.1 * (re.max() - re.min()), dmin / (re.max() - re.min())))

@@ -28,5 +28,16 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,8").split(",")]:
     ends = np.sort(t[:3072][t[:3072] > 0]) - t[4094]
     ends *= 1e-2   # 100 MHz counter -> microseconds
     q = lambda f: ends[min(len(ends) - 1, int(len(ends) * f))]
+    if hasattr(L, "r2s_debug_iso_wave_info"):
+        wi = (ctypes.c_ulonglong * (4096 * 4))()
+        L.r2s_debug_iso_wave_info(wi)
+        info = np.array(wi[:], dtype=np.float64).reshape(4096, 4)[:3072]
+        tt = t[:3072] - t[4094]
+        last = np.argsort(tt)[-12:]
+        dry = (info[:, 0] - t[4094]) * 1e-2
+        print("work ran dry for the wavefronts (us after the start): first %.0f, median %.0f, last %.0f" % (dry[dry > 0].min(), np.median(dry[dry > 0]), dry.max()))
+        for w in last:
+            el = None
+            print("  wave %4d exits at %.0f us; work dry for it at %.0f us with %d lanes busy, last item %d" % (w, tt[w] * 1e-2, dry[w], info[w, 2], info[w, 1]))
     print("world %d: kernel %.0f us by events; wavefront exits after the start (us): first %.0f, 10%% %.0f, 50%% %.0f, "
           "90%% %.0f, 99%% %.0f, last %.0f" % (world, st["ms_main"] * 1e3, ends[0], q(0.1), q(0.5), q(0.9), q(0.99), ends[-1]))
