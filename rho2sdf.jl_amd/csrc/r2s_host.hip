@@ -681,24 +681,42 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     }
     double t4 = now_ms();
     ri.ms_artifacts = t4 - t3;
-    // the cleaned field starts its way to the host while the smoothing runs (pinned destination: one DMA)
+    // the cleaned field travels to the host while the smoothing runs: one DMA into a pinned destination, else the staged
+    // copy on a helper thread (copy stream + staging buffers of the session; the smoothing uses the default stream)
     bool dists_in_flight = false;
+    std::thread dl_thread;
+    int dl_rc = 0;
+    std::string dl_err;
     if (sdf_dists_out && pin_d) {
         HIP_TRY(hipMemcpyAsync(sdf_dists_out, S->out[2].p, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost, S->cs));
         dists_in_flight = true;
+    } else if (sdf_dists_out && !o.skip_rbf) {
+        dl_thread = std::thread([&]() {
+            if (hipSetDevice(dev0) != hipSuccess) { dl_rc = R2S_ERR_HIP; dl_err = "hipSetDevice failed"; return; }
+            std::vector<Segment> segs{{(char*)sdf_dists_out, (const char*)S->out[2].p, sizeof(double) * (size_t)ngp}};
+            dl_rc = download(S, segs, false);
+            if (dl_rc) dl_err = g_err;
+        });
+        dists_in_flight = true;
     }
+    auto join_dl = [&]() -> int {
+        if (dl_thread.joinable()) dl_thread.join();
+        return dl_rc ? fail(dl_rc, "%s", dl_err.c_str()) : 0;
+    };
     // ---- RBF smoothing (:222-224) ----
     size_t nfine = 0;
     if (!o.skip_rbf) {
         nfine = 1;
         for (int i = 0; i < 3; ++i) nfine *= (size_t)(grid->N[i] * o.rbf_smooth + 1);
-        if (S->fine.ensure_exact(sizeof(float) * nfine)) return fail(R2S_ERR_NOMEM, "hipMalloc of the fine grid failed");
+        if (S->fine.ensure_exact(sizeof(float) * nfine)) { (void)join_dl(); return fail(R2S_ERR_NOMEM, "hipMalloc of the fine grid failed"); }
         int its = 0;
-        if ((rc = r2s_int::rbf_smooth_dev(S->out[2].as<double>(), grid, o.rbf_interp, o.rbf_smooth, o.rbf_kernel_threshold,
-                                          ri.V_frac * ri.V_domain, S->fine.as<float>(), &ri.level_shift, &its)))
-            return rc;
+        if (S->fine.p == nullptr) { (void)join_dl(); return fail(R2S_ERR_NOMEM, "hipMalloc of the fine grid failed"); }
+        rc = r2s_int::rbf_smooth_dev(S->out[2].as<double>(), grid, o.rbf_interp, o.rbf_smooth, o.rbf_kernel_threshold,
+                                     ri.V_frac * ri.V_domain, S->fine.as<float>(), &ri.level_shift, &its);
+        if (rc) { (void)join_dl(); return rc; }
         ri.cg_iters = its;
     }
+    if ((rc = join_dl())) return rc;
     double t5 = now_ms();
     ri.ms_rbf = t5 - t4;
     // ---- results to the caller ----
