@@ -1249,7 +1249,8 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
         const TileBox tb = tile_box(B.lo, B.dim);
         // (margin: sum N_k r_k of the reference is a rounded convex combination; with r_min strictly above rho_t by more
         //  than its rounding it is >= rho_t for every xi in the cube)
-        const bool solid = E.rmin > rho_t + 1e-9 * fmax(1.0, fabs(rho_t));
+        const double margin = 1e-9 * fmax(1.0, fabs(rho_t));
+        const double uniform_sign = (E.rmin > rho_t + margin) ? 1.0 : ((E.rmax < rho_t - margin) ? -1.0 : 0.0);
         uint32_t qn = 0;   // wave-uniform queue length
         for (uint32_t v0 = v_begin; v0 < v_end || qn > 0; v0 += 64u) {
             if (v0 < v_end) {
@@ -1266,11 +1267,13 @@ __global__ void __launch_bounds__(64) sign_project_kernel(const SignBox* __restr
                     const uint32_t t = ((uint32_t)(kl >> 2) * sl.nty + (uint32_t)(j >> 2)) * sl.ntx + (uint32_t)(i >> 2);
                     pass = hot[t] && !hex8_outside(E, x);
                     if (!pass) res[tile_slot(st_off, tb, i, j, kl)] = INFINITY;
-                    else if (solid && hex8_inner(E, x)) {
-                        // inside an element whose densities all exceed rho_t: max|xi| <= 1 and rho(xi) >= rho_t whatever xi
-                        // is; the state machine of the gather only needs "holds the point, counts as +1, ends the walk"
-                        // (in a conforming mesh no earlier candidate can hold a point this deep inside another element)
-                        res[tile_slot(st_off, tb, i, j, kl)] = 0.0;
+                    else if (uniform_sign != 0.0 && hex8_inner(E, x)) {
+                        // inside an element whose nodal densities lie all above (or all below) rho_t: max|xi| <= 1 and the
+                        // comparison rho(xi) >= rho_t comes out the same whatever xi is.  The state machine of the gather only
+                        // needs "holds the point, counts as +1 (or leaves the sign alone), ends the walk": in a conforming mesh
+                        // no other candidate holds a point this deep inside the element with a smaller max|xi|, so nothing
+                        // after it can change the outcome and the order of what came before it is untouched.
+                        res[tile_slot(st_off, tb, i, j, kl)] = uniform_sign > 0.0 ? 0.0 : -0.0;
                         pass = false;
                     }
                 }
