@@ -22,6 +22,7 @@ using Rho2sdf.MeshGrid
 using Rho2sdf.SignedDistances
 using Rho2sdf.SdfSmoothing
 using Rho2sdf.ElementTypes
+using Rho2sdf.ShapeFunctions
 using Rho2sdf.DataExport
 
 const LIB = Ref{String}("librho2sdf_hip.so")
