@@ -2326,7 +2326,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             if (want_dist && n_chunks) {
                 static const int wps_env = getenv("R2S_ISO_WPS") ? atoi(getenv("R2S_ISO_WPS")) : 0;   // tuning knob
                 const uint32_t wps = (wps_env >= 1 && wps_env <= 3) ? (uint32_t)wps_env : 3u;
-                const uint32_t resident = (uint32_t)P->n_cu * 4u * wps;   // CUs x SIMDs x waves/SIMD of this kernel
+                static const int free_env = getenv("R2S_ISO_FREE") ? atoi(getenv("R2S_ISO_FREE")) : 0;   // tuning knob: wave slots left to the second stream
+                const uint32_t resident = (uint32_t)P->n_cu * 4u * wps - (uint32_t)std::min(std::max(free_env, 0), (int)P->n_cu * 4);   // CUs x SIMDs x waves/SIMD of this kernel
                 // (2 waves/SIMD, or 3 on only part of the SIMDs so that sign_project finds room beside them from the
                 // start: measured, no gain - the two kernels together are bound by their FP64 work either way)
                 // chunks per fetch: 4 when every wavefront gets dozens of them (1-8: +-2 %), fewer for a small share of
