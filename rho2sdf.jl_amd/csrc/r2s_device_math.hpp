@@ -990,6 +990,14 @@ struct alignas(16) TetRec {
     double sab[4][3];
     double sab2[4];
     int32_t segok[4];
+    // unit outward face normals fn[f] with two offsets each (tet4_face_planes): fn[f].x > fo[f] => the barycentric
+    // coordinate of face f is below -1e-6, so is_point_in_tetrahedron (tolerance 1e-10, SignDetection.jl:220-242)
+    // rejects the point; fn[f].x < fi[f] for all four faces => every coordinate is above +1e-6 and it accepts it.
+    // Only the points in between (a 2e-6 shell around the faces) need the 4x4 solve.  fo = +inf, fi = -inf for
+    // degenerate or flat elements (height / longest edge < 1e-3), which always take the solve.
+    double fn[4][3];
+    double fo[4];
+    double fi[4];
 };
 
 __device__ const int c_tet_isn[4][3] = {{0, 2, 1}, {0, 1, 3}, {1, 2, 3}, {0, 3, 2}};
@@ -1172,6 +1180,53 @@ R2S_DEV double iso_candidate(const TetRec& E, double rt, const double x[3], doub
         xp[i] = t;
     }
     return norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]);
+}
+
+// unit outward normals and the two offsets of the four faces (TetRec::fn, fo, fi)
+R2S_DEV void tet4_face_planes(TetRec& E)
+{
+    double scale = 0.0, edge2 = 0.0;
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 3; ++i) scale = fmax(scale, fabs(E.X[k][i]));
+    for (int a = 0; a < 4; ++a)
+        for (int b = a + 1; b < 4; ++b) {
+            const double d[3] = {E.X[b][0] - E.X[a][0], E.X[b][1] - E.X[a][1], E.X[b][2] - E.X[a][2]};
+            edge2 = fmax(edge2, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        }
+    const double edge = sqrt(edge2);
+    bool good = edge > 0.0 && !E.sing3 && !E.sing4;
+    for (int f = 0; f < 4; ++f) {   // face f = the three vertices other than f
+        const int a = (f + 1) & 3, b = (f + 2) & 3, c = (f + 3) & 3;
+        const double u[3] = {E.X[b][0] - E.X[a][0], E.X[b][1] - E.X[a][1], E.X[b][2] - E.X[a][2]};
+        const double v[3] = {E.X[c][0] - E.X[a][0], E.X[c][1] - E.X[a][1], E.X[c][2] - E.X[a][2]};
+        double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+        const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (!(nn > 0.0)) { good = false; E.fn[f][0] = E.fn[f][1] = E.fn[f][2] = 0.0; continue; }
+        n[0] /= nn; n[1] /= nn; n[2] /= nn;
+        const double d = n[0] * E.X[a][0] + n[1] * E.X[a][1] + n[2] * E.X[a][2];
+        double h = d - (n[0] * E.X[f][0] + n[1] * E.X[f][1] + n[2] * E.X[f][2]);   // height of vertex f over the face (signed)
+        double ds = d;
+        if (h < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; h = -h; ds = -d; }   // outward = away from vertex f
+        if (!(h > 1e-3 * edge)) good = false;
+        const double m = 1e-6 * h + 1e-11 * scale;   // 1e-6 of the coordinate + the rounding of fn.x itself
+        E.fn[f][0] = n[0]; E.fn[f][1] = n[1]; E.fn[f][2] = n[2];
+        E.fo[f] = ds + m;
+        E.fi[f] = ds - m;
+    }
+    if (!good)
+        for (int f = 0; f < 4; ++f) { E.fo[f] = INFINITY; E.fi[f] = -INFINITY; }
+}
+// position of p against the face planes: outside = beyond some face by the margin, inside = within all four by it
+R2S_DEV void tet4_classify(const TetRec& E, const double p[3], bool& outside, bool& inside)
+{
+    outside = false;
+    inside = true;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const double t = E.fn[f][0] * p[0] + E.fn[f][1] * p[1] + E.fn[f][2] * p[2];
+        outside = outside || (t > E.fo[f]);
+        inside = inside && (t < E.fi[f]);
+    }
 }
 
 // is_point_in_tetrahedron (SignDetection.jl:220-242), tolerance 1e-10

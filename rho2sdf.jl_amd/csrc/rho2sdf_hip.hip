@@ -291,6 +291,7 @@ struct TetT {
         }
         R.pad = 0;
         tet4_iso_constants(R, rho_t);
+        tet4_face_planes(R);
     }
 };
 
@@ -659,11 +660,17 @@ __global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __rest
                                                          const uint32_t* __restrict__ chunk_off,
                                                          uint32_t nchunks, const Rec* __restrict__ erec,
                                                          GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
-                                                         double* __restrict__ res_xp, const uint32_t* __restrict__ abort_flag)
+                                                         double* __restrict__ res_xp, const uint32_t* __restrict__ abort_flag,
+                                                         uint32_t cpw)
 {
-    if (*abort_flag) return;   // speculated sizes of this call did not hold (run_impl)
-    const uint32_t c = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    // `cpw` consecutive chunks per wavefront: the search for the item of a chunk (a chain of dependent scalar loads,
+    // ~10 us of latency for 30 000 items - four times what the projection of the chunk's 64 voxels takes) and the
+    // element record are paid once per run of chunks instead of once per chunk
+    const uint32_t ab = *abort_flag;
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    uint32_t c = w * cpw;
     if (c >= nchunks) return;
+    const uint32_t c_end = (c + cpw < nchunks) ? c + cpw : nchunks;
     const int lane = threadIdx.x & 63;
     // last item with chunk_off[it] <= c  (chunk_off has nitems+1 entries, non-decreasing)
     uint32_t lo = 0, hi = nitems;
@@ -671,29 +678,33 @@ __global__ void __launch_bounds__(256) iso_project_kernel(const BandItem* __rest
         const uint32_t mid = (lo + hi) >> 1;
         if (chunk_off[mid] <= c) lo = mid; else hi = mid;
     }
-    const BandItem& T = items[lo];
-    const Rec& E = erec[T.el];
-    const uint32_t local = (c - chunk_off[lo]) * 64u + lane;
-    const uint32_t bx = T.dim[0], by = T.dim[1], bz = T.dim[2];
-    if (local >= bx * by * bz) return;
-    const int li = local % bx, lj = (local / bx) % by, lk = local / (bx * by);
-    double x[3];
-    x[0] = grid_coord(g, 0, T.lo[0] + li);
-    x[1] = grid_coord(g, 1, T.lo[1] + lj);
-    x[2] = grid_coord(g, 2, slab_global_k(sl, T.lo[2] + lk));   // T.lo[2] is a local plane
-    const int ci = (int)cell_of(g, 0, x[0]), cj = (int)cell_of(g, 1, x[1]), ck = (int)cell_of(g, 2, x[2]);
-    const bool in = ci >= T.imin[0] && ci <= T.imax[0] && cj >= T.imin[1] && cj <= T.imax[1] &&
-                    ck >= T.imin[2] && ck <= T.imax[2];
-    if (!in) return;
-    double xp[3];
-    const double d = iso_candidate(E, rho_t, x, xp);
-    const TileBox tb = tile_box(T.lo, T.dim);
-    const size_t slot = tile_slot(T.store_off, tb, T.lo[0] + li, T.lo[1] + lj, T.lo[2] + lk);
-    res[slot] = d;
-    if (res_xp) {
-        res_xp[3 * slot] = xp[0];
-        res_xp[3 * slot + 1] = xp[1];
-        res_xp[3 * slot + 2] = xp[2];
+    if (ab) return;   // speculated sizes of this call did not hold (run_impl)
+    for (; c < c_end; ++c) {
+        while (lo + 1 < nitems && chunk_off[lo + 1] <= c) ++lo;   // (items without chunks are stepped over)
+        const BandItem& T = items[lo];
+        const Rec& E = erec[T.el];
+        const uint32_t local = (c - chunk_off[lo]) * 64u + lane;
+        const uint32_t bx = T.dim[0], by = T.dim[1], bz = T.dim[2];
+        if (local >= bx * by * bz) continue;
+        const int li = local % bx, lj = (local / bx) % by, lk = local / (bx * by);
+        double x[3];
+        x[0] = grid_coord(g, 0, T.lo[0] + li);
+        x[1] = grid_coord(g, 1, T.lo[1] + lj);
+        x[2] = grid_coord(g, 2, slab_global_k(sl, T.lo[2] + lk));   // T.lo[2] is a local plane
+        const int ci = (int)cell_of(g, 0, x[0]), cj = (int)cell_of(g, 1, x[1]), ck = (int)cell_of(g, 2, x[2]);
+        const bool in = ci >= T.imin[0] && ci <= T.imax[0] && cj >= T.imin[1] && cj <= T.imax[1] &&
+                        ck >= T.imin[2] && ck <= T.imax[2];
+        if (!in) continue;
+        double xp[3];
+        const double d = iso_candidate(E, rho_t, x, xp);
+        const TileBox tb = tile_box(T.lo, T.dim);
+        const size_t slot = tile_slot(T.store_off, tb, T.lo[0] + li, T.lo[1] + lj, T.lo[2] + lk);
+        res[slot] = d;
+        if (res_xp) {
+            res_xp[3 * slot] = xp[0];
+            res_xp[3 * slot + 1] = xp[1];
+            res_xp[3 * slot + 2] = xp[2];
+        }
     }
 }
 
@@ -853,6 +864,33 @@ __global__ void band_bin_kernel(const BandItem* __restrict__ items, uint32_t nit
     }
 }
 
+// TET4: is every voxel of the (local) tile beyond one face plane of the element by the margin of TetRec::fo?  Then
+// is_point_in_tetrahedron rejects all 64 of them and the element need not be in the tile's list (its bounding box
+// holds 3-6 times the tiles the element itself touches).  HEX8 lists are tested by the inverse maps instead.
+__device__ __forceinline__ bool tile_clear_of(const ElemRec&, const GridDev&, const SlabInfo&, int, int, int) { return false; }
+__device__ __forceinline__ bool tile_clear_of(const TetRec& E, const GridDev& g, const SlabInfo& s, int tx, int ty, int tz)
+{
+    const double half = 1.5 * g.cell;
+    const double c[3] = {grid_coord(g, 0, 4 * tx) + half, grid_coord(g, 1, 4 * ty) + half,
+                         grid_coord(g, 2, slab_global_k(s, 4 * tz)) + half};
+    bool clear = false;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const double t = E.fn[f][0] * c[0] + E.fn[f][1] * c[1] + E.fn[f][2] * c[2];
+        const double r = (fabs(E.fn[f][0]) + fabs(E.fn[f][1]) + fabs(E.fn[f][2])) * half;
+        clear = clear || (t - r > E.fo[f]);
+    }
+    return clear;
+}
+__device__ __forceinline__ void tile_xyz(const int lo[3], const int hi[3], uint32_t q, int& tx, int& ty, int& tz)
+{
+    const uint32_t n0 = (uint32_t)(hi[0] - lo[0] + 1), n1 = (uint32_t)(hi[1] - lo[1] + 1);
+    const uint32_t z = q / (n0 * n1), r = q - z * (n0 * n1), y = r / n0;
+    tx = lo[0] + (int)(r - y * n0);
+    ty = lo[1] + (int)y;
+    tz = lo[2] + (int)z;
+}
+
 // a voxel is only examined when some candidate reaches rho_t (SignDetection.jl:36): tiles whose lists
 // would hold no such element keep sign = -1 without any work ("hot" = the others).  Pass 1 marks them.
 template <class Rec>
@@ -866,7 +904,12 @@ __global__ void sign_hot_kernel(const Rec* __restrict__ erec, uint32_t nel, Grid
     int lo[3], hi[3];
     if (!sign_tile_range(erec[el], g, s, lo, hi)) return;
     const uint32_t n = tile_count(lo, hi);
-    for (uint32_t q = sub; q < n; q += BIN_LANES) hot[tile_of(lo, hi, q, s)] = 1;
+    for (uint32_t q = sub; q < n; q += BIN_LANES) {
+        int tx, ty, tz;
+        tile_xyz(lo, hi, q, tx, ty, tz);
+        if (tile_clear_of(erec[el], g, s, tx, ty, tz)) continue;
+        hot[((uint32_t)tz * s.nty + (uint32_t)ty) * s.ntx + (uint32_t)tx] = 1;
+    }
 }
 
 // candidate lists of the hot tiles only (count pass, then fill pass)
@@ -874,18 +917,24 @@ template <class Rec, bool FILL>
 __global__ void sign_bin_kernel(const Rec* __restrict__ erec, uint32_t nel, GridDev g, SlabInfo s,
                                 uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                 uint32_t* __restrict__ entries, const uint8_t* __restrict__ hot,
-                                const uint32_t* __restrict__ abort_flag)
+                                const uint32_t* __restrict__ abort_flag, double rmax_needed)
 {
     if (FILL && *abort_flag) return;   // speculated sizes of this call did not hold (run_impl)
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t el = gid / BIN_LANES, sub = gid % BIN_LANES;
     if (el >= nel) return;
+    // TET4: only a hit with rho >= rho_t counts (SignDetection.jl:143-146) and rho <= max nodal density of the
+    // element (validated shape functions are >= 0 and sum to <= 1), so elements below rho_t are no candidates.
+    // (HEX8 passes -inf: there every candidate takes part in the cmax test, SignDetection.jl:36)
+    if (erec[el].rmax < rmax_needed) return;
     int lo[3], hi[3];
     if (!sign_tile_range(erec[el], g, s, lo, hi)) return;
     const uint32_t n = tile_count(lo, hi);
     for (uint32_t q = sub; q < n; q += BIN_LANES) {
-        const uint32_t t = tile_of(lo, hi, q, s);
-        if (!hot[t]) continue;
+        int tx, ty, tz;
+        tile_xyz(lo, hi, q, tx, ty, tz);
+        const uint32_t t = ((uint32_t)tz * s.nty + (uint32_t)ty) * s.ntx + (uint32_t)tx;
+        if (!hot[t] || tile_clear_of(erec[el], g, s, tx, ty, tz)) continue;
         const uint32_t pos = atomicAdd(&cnt[t], 1u);
         if (FILL) entries[off[t] + pos] = el;
     }
@@ -1645,8 +1694,9 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
                 if (!(any && !(cmax < A.rho_t))) sg = -1.0;   // SignDetection.jl:36
             }
         } else {
-            // Sign_Detection_TET4 (SignDetection.jl:116-151): bin index of the point (:258-268),
-            // candidates of that bin in ascending element order, first hit with rho >= rho_t wins
+            // Sign_Detection_TET4 (SignDetection.jl:116-151): bin index of the point (:258-268), candidates of
+            // that bin, +1 when one of them holds the point with rho >= rho_t (the reference stops at the first
+            // such element of its ascending list - which one it is does not change the sign)
             const int dims[3] = {A.g.nx, A.g.ny, A.g.nz};
             int gi[3];
 #pragma unroll
@@ -1658,10 +1708,15 @@ __global__ void __launch_bounds__(256) sdf_tiles_kernel(MainArgs A)
             }
             bool done = false;
             for (uint32_t p = b; p < e; ++p) {
+                if (!__any(valid && !done)) break;   // every voxel of the tile has its first hit
                 const TetRec& E = erec[A.sign_ent[p]];
                 const bool in = valid && !done && gi[0] >= E.blo[0] && gi[0] <= E.bhi[0] && gi[1] >= E.blo[1] &&
                                 gi[1] <= E.bhi[1] && gi[2] >= E.blo[2] && gi[2] <= E.bhi[2];
-                if (in && point_in_tet(E, x)) {
+                // the 4x4 solve of is_point_in_tetrahedron only for the points the face planes leave undecided
+                bool outside, pit;
+                tet4_classify(E, x, outside, pit);
+                if (in && !outside && !pit) pit = point_in_tet(E, x);
+                if (in && pit) {
                     double loc[3], N[4];
                     if (find_local_tet4(E, x, loc)) {
                         tet4_shape(loc, N);
@@ -2176,6 +2231,9 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipEventRecord(P->ev[1], st));
 
     // ---- tile bins ----
+    // (TET4 sign lists leave out the elements that cannot reach rho_t, see sign_bin_kernel; 1e-12: the rounding of
+    // the interpolated density, 8 eps, with room to spare)
+    const double rmax_needed = std::is_same<typename ET::Rec, ElemRec>::value ? -INFINITY : rho_t - 1e-12 * (fabs(rho_t) + 1.0);
     zero_many(st, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)},
                    {P->hot.p, (size_t)ntiles + 1}, {P->tri.p, (size_t)ntiles + 1}});
     if (n_items)
@@ -2183,7 +2241,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     if (want_sign)
     {
         sign_hot_kernel<typename ET::Rec><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
-        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>(), abort_flag);
+        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>(), abort_flag, rmax_needed);
     }
     {
         int rc = scan_exclusive2(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->sign_cnt.as<uint32_t>(),
@@ -2236,14 +2294,16 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     if (n_items)
         band_bin_kernel<true><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), nullptr, abort_flag);
     if (want_sign)
-        sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->hot.as<uint8_t>(), abort_flag);
+        sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), HEX ? P->sign_raw.as<uint32_t>() : P->sign_ent.as<uint32_t>(), P->hot.as<uint8_t>(), abort_flag, rmax_needed);
+    // (TET4: a voxel is +1 when ANY candidate holds it with rho >= rho_t - "the first one" of SignDetection.jl:128-147
+    // only ends the search - so the order of a list does not matter and the lists are used as filled)
     // lists longer than 64 entries only occur when the grid is coarse relative to the mesh (few tiles)
     if (n_active) {
         bin_sort_small_kernel<<<(n_active * SORT_LANES + 255) / 256, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>(), abort_flag);
         if (cnt[6] > 64u)
             bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>(), abort_flag);
     }
-    if (n_active_sign) {
+    if (n_active_sign && HEX) {
         bin_sort_small_kernel<<<(n_active_sign * SORT_LANES + 255) / 256, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>(), abort_flag);
         if (cnt[7] > 64u)
             bin_sort_kernel<<<(n_active_sign + 3) / 4, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>(), abort_flag);
@@ -2390,9 +2450,14 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             A.iso_res = P->iso_res.as<double>();
             A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
             if (want_dist && n_chunks)
-                iso_project_kernel<typename ET::Rec><<<(n_chunks + 3) / 4, 256, 0, st>>>(
+            {
+                static const int cpw_env = getenv("R2S_ISO_CPW") ? atoi(getenv("R2S_ISO_CPW")) : 0;   // tuning knob
+                const uint32_t cpw = cpw_env > 0 ? (uint32_t)cpw_env : 8u;
+                const uint32_t nwaves = (n_chunks + cpw - 1) / cpw;
+                iso_project_kernel<typename ET::Rec><<<(nwaves + 3) / 4, 256, 0, st>>>(
                     P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
-                    s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, abort_flag);
+                    s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, abort_flag, cpw);
+            }
             HIP_TRY(hipEventRecord(P->ev[6], st));
             if (want_dist && n_active) {
                 A.active = P->active.as<uint32_t>(); A.n_active = n_active;
