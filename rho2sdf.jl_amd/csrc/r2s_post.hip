@@ -474,6 +474,10 @@ __device__ __forceinline__ double exp_neg_fast(double t, const double* __restric
     return ldexp(tab[k & 63] * p, -(k >> 6));
 }
 
+__device__ __forceinline__ float rbf_apply_point(const RbfGeom& G, const float* __restrict__ w, int s, int tnx, int tny,
+                                                 const float* __restrict__ tx, const float* __restrict__ ty,
+                                                 const float* __restrict__ tz, const Stencil* __restrict__ stencils,
+                                                 const double* __restrict__ etab, int64_t t);
 // rbf_interpolation_kdtree (:219-248): 1 thread / target point
 __global__ void __launch_bounds__(256) rbf_apply_kernel(RbfGeom G, const float* __restrict__ w, int s, int tnx, int tny,
                                                        int tnz, const float* __restrict__ tx,
@@ -486,10 +490,17 @@ __global__ void __launch_bounds__(256) rbf_apply_kernel(RbfGeom G, const float* 
     __shared__ double etab[64];
     if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_neg_64[threadIdx.x];
     __syncthreads();
-    const double inv_sigma = 1.0 / G.sigma;
     const int64_t t = t_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nt = t_end >= 0 ? t_end : (int64_t)tnx * tny * tnz;
     if (t >= nt) return;
+    out[t] = rbf_apply_point(G, w, s, tnx, tny, tx, ty, tz, stencils, etab, t) + add;
+}
+__device__ __forceinline__ float rbf_apply_point(const RbfGeom& G, const float* __restrict__ w, int s, int tnx, int tny,
+                                                 const float* __restrict__ tx, const float* __restrict__ ty,
+                                                 const float* __restrict__ tz, const Stencil* __restrict__ stencils,
+                                                 const double* __restrict__ etab, int64_t t)
+{
+    const double inv_sigma = 1.0 / G.sigma;
     const int i = (int)(t % tnx), j = (int)((t / tnx) % tny), k = (int)(t / ((int64_t)tnx * tny));
     const Stencil& S = stencils[((k % s) * s + (j % s)) * s + (i % s)];
     const int bi = i / s, bj = j / s, bk = k / s;
@@ -507,7 +518,7 @@ __global__ void __launch_bounds__(256) rbf_apply_kernel(RbfGeom G, const float* 
             acc = (float)((double)acc + (double)w[((int64_t)ck * G.ny + cj) * G.nx + ci] * exp_neg_fast(u * u, etab));
         }
     }
-    out[t] = acc + add;
+    return acc;
 }
 
 // y = K x, K = compute_sparse_kernel_matrix (:142-176); row accumulation in ascending linear index
@@ -610,19 +621,24 @@ __global__ void __launch_bounds__(256) rbf_matvec_k_kernel(RbfGeom G, RbfTaps T,
 // matvec looks them up: per axis and offset a byte per lattice index names the variant.  Same values, same order
 // of accumulation => bit-identical to rbf_matvec_kernel, without its 81 exp() per row and without the 43 GB
 // materialised matrix of rbf_matvec_k_kernel; the table (<= 2 MB for R = 2) lives in L2.
-#define RBF_NV 16   // variants per (axis, offset) the table has room for; more -> the materialised / on-the-fly paths
+#define RBF_NV 16   // variants per (axis, offset) the matvec table has room for; more -> the materialised / on-the-fly paths
+#define RBF_NVA 64  // ... and the evaluation tables (the differences against the separately rounded output grid take 20-40)
 struct RbfLutGeom {
     int nx, ny, nz, R, tap_d2;
     const uint8_t *vx, *vy, *vz;   // [2R+1][n_axis]: variant id of (index, offset), 255 = neighbour outside the lattice
     const float* T;                // [(2R+1)^3][NV][NV][NV], x variant fastest; 0 = entry absent (val <= threshold)
+    const double* TA;              // same shape: the kernel values of the EVALUATION (rbf_apply_kernel's arithmetic); 0 = beyond max_distance
 };
 struct RbfLutVals {
-    float v[3][7][RBF_NV];         // the variant values per axis and offset
+    float v[3][7][RBF_NVA];        // the variant values per axis and offset
     int R;
     double sigma, thr;
+    float max_distance;
 };
-__global__ void __launch_bounds__(256) rbf_lut_build_kernel(RbfLutVals V, float* __restrict__ T)
+// (the variant values travel through device memory: the struct is larger than a kernel argument block)
+__global__ void __launch_bounds__(256) rbf_lut_build_kernel(const RbfLutVals* __restrict__ Vp, float* __restrict__ T)
 {
+    const RbfLutVals& V = *Vp;
     const int W = 2 * V.R + 1;
     const int64_t n = (int64_t)W * W * W * RBF_NV * RBF_NV * RBF_NV;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -636,17 +652,37 @@ __global__ void __launch_bounds__(256) rbf_lut_build_kernel(RbfLutVals V, float*
     const double val = exp(-(u * u));
     T[t] = (val > V.thr) ? (float)val : 0.0f;   // (unused variant slots hold NaN values -> comparisons false -> 0)
 }
-template <int R>
-__global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const float* __restrict__ x, float* __restrict__ y,
-                                                            int64_t t_begin = 0, int64_t t_end = -1, int64_t x_lo = 0,
-                                                            int64_t x_hi = -1)
+// one row through per-lane clamped addresses and predicates: rows of the first / last R planes, of wavefronts that
+// straddle two planes and of a slab whose halo ends nearby
+// the table of the evaluation (rbf_apply_kernel with targets = lattice points): same differences, that kernel's arithmetic
+__global__ void __launch_bounds__(256) rbf_lut_build_apply_kernel(const RbfLutVals* __restrict__ Vp, double* __restrict__ TA)
 {
-    // [t_begin, t_end): rows of this launch; [x_lo, x_hi]: the part of x that exists on this device (a Z-slab with its
-    // halo; x and y are addressed as the whole vectors) - the clamp of absent neighbours stays inside it
+    const RbfLutVals& V = *Vp;
+    __shared__ double etab[64];
+    if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_neg_64[threadIdx.x];
+    __syncthreads();
+    const int W = 2 * V.R + 1;
+    const int64_t n = (int64_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int a = (int)(t % RBF_NVA), b = (int)((t / RBF_NVA) % RBF_NVA), c = (int)((t / (RBF_NVA * RBF_NVA)) % RBF_NVA);
+    const int tap = (int)(t / (RBF_NVA * RBF_NVA * RBF_NVA));
+    const int di = tap % W, dj = (tap / W) % W, dk = tap / (W * W);
+    const float dx = V.v[0][di][a], dy = V.v[1][dj][b], dz = V.v[2][dk][c];
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    const double inv_sigma = 1.0 / V.sigma;
+    double val = 0.0;
+    if (dist <= V.max_distance) {   // (NaN differences of unused variant slots: false)
+        const double u = (double)dist * inv_sigma;
+        val = exp_neg_fast(u * u, etab);
+    }
+    TA[t] = val;
+}
+template <int R>
+__device__ __forceinline__ float rbf_lut_row_clamped(const RbfLutGeom& G, const float* __restrict__ x, int64_t t, int64_t first,
+                                                     int64_t last)
+{
     constexpr int W = 2 * R + 1;
-    const int64_t t = t_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
-    if (t >= (t_end >= 0 ? t_end : n)) return;
     const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((int64_t)G.nx * G.ny));
     uint32_t ax[W], by[W], cz[W];
 #pragma unroll
@@ -656,10 +692,6 @@ __global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const
         cz[d] = G.vz[d * G.nz + k];
     }
     float acc = 0.0f;
-    // the loop order of rbf_matvec_kernel (ck, cj, ci ascending): the row sum is formed from the same values in the same
-    // order.  The table and vector loads of a (dk, dj) row are unconditional and independent (clamped addresses, absent
-    // entries read as weight 0), so the memory system sees 2 W loads in flight per row instead of a dependent chain.
-    const int64_t first = x_lo, last = x_hi >= 0 ? x_hi : n - 1;
 #pragma unroll
     for (int dk = 0; dk < W; ++dk) {
 #pragma unroll
@@ -685,35 +717,243 @@ __global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const
                 if (w[di] != 0.0f) acc += w[di] * xv[di];
         }
     }
-    y[t] = acc;
+    return acc;
+}
+template <int R, int D2>   // D2: G.tap_d2 as a compile-time constant (no branches between the tap groups), or -1
+__global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const float* __restrict__ x, float* __restrict__ y,
+                                                            int64_t t_begin = 0, int64_t t_end = -1, int64_t x_lo = 0,
+                                                            int64_t x_hi = -1)
+{
+    // [t_begin, t_end): rows of this launch; [x_lo, x_hi]: the part of x that exists on this device (a Z-slab with its
+    // halo; x and y are addressed as the whole vectors) - the clamp of absent neighbours stays inside it.
+    // The loop order of rbf_matvec_kernel (ck, cj, ci ascending) is kept: the row sum is formed from the same values in
+    // the same order.
+    //
+    // A wavefront = 64 consecutive rows.  When they lie in one Z plane with all 2R+1 neighbour planes addressable, every
+    // address is (wave-uniform pointer) + (32-bit lane offset) + (immediate): the vector loads carry their base in SGPRs
+    // and the loop spends its VALU work on the products only (the row-by-row form above needs ~20 VALU instructions per
+    // tap for 64-bit offsets, clamps and predicates, and was bound by them).  Neighbours outside the lattice in x or y
+    // take variant slot RBF_NV-1, which rbf_lut_axis leaves unused on every axis: its table entries are 0 (built from
+    // NaN differences), i.e. "entry absent", and the x they multiply is some other element of the vector that is never
+    // used.
+    constexpr int W = 2 * R + 1;
+    constexpr uint32_t NV3 = RBF_NV * RBF_NV * RBF_NV;
+    const int d2max = D2 >= 0 ? D2 : G.tap_d2;
+    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
+    const int64_t tend = t_end >= 0 ? t_end : n;
+    const int64_t first = x_lo, last = x_hi >= 0 ? x_hi : n - 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tw0 = t_begin + (int64_t)blockIdx.x * 256 + (int64_t)wv * 64;   // first row of the wavefront (in SGPRs)
+    const int64_t t = tw0 + lane;
+    if (tw0 >= tend) return;
+    const int64_t tw1 = tw0 + 63 < tend ? tw0 + 63 : tend - 1;
+    const int64_t plane = (int64_t)G.nx * G.ny;
+    const int64_t reach = (int64_t)R * plane + (int64_t)R * G.nx + R;
+    const int k = __builtin_amdgcn_readfirstlane((int)(tw0 / plane));
+    const bool fast = (tw1 / plane == k) && k >= R && k < G.nz - R && tw0 - reach >= first && tw1 + reach <= last;
+    if (!fast) {
+        if (t < tend) y[t] = rbf_lut_row_clamped<R>(G, x, t, first, last);
+        return;
+    }
+    const int64_t tc = t < tend ? t : tend - 1;   // (idle lanes of the last wavefront repeat its last row)
+    const uint32_t r2 = (uint32_t)(tc - (int64_t)k * plane);
+    const uint32_t j = r2 / (uint32_t)G.nx, i = r2 - j * (uint32_t)G.nx;
+    uint32_t ab[W][W];   // (y variant, x variant) part of the table index per (dj, di), as a BYTE offset (saddr + voffset loads)
+    {
+        uint32_t a[W], b[W];
+#pragma unroll
+        for (int d = 0; d < W; ++d) {
+            const uint32_t va = G.vx[d * G.nx + i], vb = G.vy[d * G.ny + j];
+            a[d] = va != 255u ? va : (uint32_t)(RBF_NV - 1);
+            b[d] = vb != 255u ? vb : (uint32_t)(RBF_NV - 1);
+        }
+#pragma unroll
+        for (int dj = 0; dj < W; ++dj)
+#pragma unroll
+            for (int di = 0; di < W; ++di) ab[dj][di] = (b[dj] * RBF_NV + a[di]) * 4u;
+    }
+    // buffer loads: descriptor + scalar offset in SGPRs, the lane part as a 32-bit byte offset - no address arithmetic
+    // in the VALU.  (x: a window of the vector around the wavefront's rows, so that the offsets fit 32 bits on any grid)
+    const uint32_t lane4 = lane * 4u;
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)G.T, 0, (int)((uint32_t)(W * W * W) * NV3 * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(x + (tw0 - reach)), 0, (int)((2 * reach + 64) * 4), 0x00020000);
+    float acc = 0.0f;
+#pragma unroll
+    for (int dk = 0; dk < W; ++dk) {
+        const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)G.vz[dk * G.nz + k]);   // (k is interior: never 255)
+#pragma unroll
+        for (int dj = 0; dj < W; ++dj) {
+            if ((dk - R) * (dk - R) + (dj - R) * (dj - R) > d2max) continue;
+            const uint32_t Trow = (((uint32_t)((dk * W + dj) * W) * RBF_NV + c) * (RBF_NV * RBF_NV)) * 4u;
+            const uint32_t xrow = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx - R) * 4u;
+            float w[W], xv[W];
+#pragma unroll
+            for (int di = 0; di < W; ++di) {
+                w[di] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (int)ab[dj][di], (int)(Trow + (uint32_t)di * NV3 * 4u), 0));
+                xv[di] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)(xrow + (uint32_t)di * 4u), 0));
+            }
+#pragma unroll
+            for (int di = 0; di < W; ++di) {
+                const bool in = (dk - R) * (dk - R) + (dj - R) * (dj - R) + (di - R) * (di - R) <= d2max;   // (uniform)
+                if (in && w[di] != 0.0f) acc += w[di] * xv[di];
+            }
+        }
+    }
+    if (t < tend) y[t] = acc;
+}
+
+static void launch_rbf_matvec_lut(const RbfLutGeom& LG, unsigned nb, hipStream_t st, const float* x, float* y, int64_t t0 = 0,
+                                  int64_t t1 = -1, int64_t xlo = 0, int64_t xhi = -1)
+{
+    if (LG.R == 2 && LG.tap_d2 == 7) rbf_matvec_lut_kernel<2, 7><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);   // threshold 1e-3 (default)
+    else if (LG.R == 1) rbf_matvec_lut_kernel<1, -1><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);
+    else if (LG.R == 2) rbf_matvec_lut_kernel<2, -1><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);
+    else rbf_matvec_lut_kernel<3, -1><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);
+}
+
+// rbf_apply_kernel for one target per lattice point (same grid; tx, ty, tz: the targets' coordinates, which the table's
+// variants were formed with) through the table TA: the neighbours in the order of the
+// stencil (lattice distance^2, then dz, dy, dx - build_stencil), Float64 product and sum rounded to Float32 per
+// neighbour as there.  Wavefronts away from the first / last R planes take the table; the others evaluate as before.
+template <int R, int D2>
+__global__ void __launch_bounds__(256) rbf_apply_lut_kernel(RbfGeom G, RbfLutGeom L, const float* __restrict__ w,
+                                                           const float* __restrict__ tx, const float* __restrict__ ty,
+                                                           const float* __restrict__ tz, const Stencil* __restrict__ stencils,
+                                                           float add, float* __restrict__ out, int64_t t_begin, int64_t t_end,
+                                                           int64_t x_lo, int64_t x_hi)
+{
+    constexpr int W = 2 * R + 1;
+    constexpr uint32_t NV3 = RBF_NVA * RBF_NVA * RBF_NVA;
+    __shared__ double etab[64];
+    if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_neg_64[threadIdx.x];
+    __syncthreads();
+    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
+    const int64_t tend = t_end >= 0 ? t_end : n;
+    const int64_t first = x_lo, last = x_hi >= 0 ? x_hi : n - 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tw0 = t_begin + (int64_t)blockIdx.x * 256 + (int64_t)wv * 64;
+    const int64_t t = tw0 + lane;
+    if (tw0 >= tend) return;
+    const int64_t tw1 = tw0 + 63 < tend ? tw0 + 63 : tend - 1;
+    const int64_t plane = (int64_t)G.nx * G.ny;
+    const int64_t reach = (int64_t)R * plane + (int64_t)R * G.nx + R;
+    const int k = __builtin_amdgcn_readfirstlane((int)(tw0 / plane));
+    const bool fast = (tw1 / plane == k) && k >= R && k < G.nz - R && tw0 - reach >= first && tw1 + reach <= last;
+    if (!fast) {
+        if (t < tend) out[t] = rbf_apply_point(G, w, 1, G.nx, G.ny, tx, ty, tz, stencils, etab, t) + add;
+        return;
+    }
+    const int64_t tc = t < tend ? t : tend - 1;
+    const uint32_t r2 = (uint32_t)(tc - (int64_t)k * plane);
+    const uint32_t j = r2 / (uint32_t)G.nx, i = r2 - j * (uint32_t)G.nx;
+    uint32_t ab[W][W];   // byte offsets of the (y variant, x variant) pair in a table row of doubles
+    {
+        uint32_t a[W], b[W];
+#pragma unroll
+        for (int d = 0; d < W; ++d) {
+            const uint32_t va = L.vx[d * G.nx + i], vb = L.vy[d * G.ny + j];
+            a[d] = va != 255u ? va : (uint32_t)(RBF_NVA - 1);
+            b[d] = vb != 255u ? vb : (uint32_t)(RBF_NVA - 1);
+        }
+#pragma unroll
+        for (int dj = 0; dj < W; ++dj)
+#pragma unroll
+            for (int di = 0; di < W; ++di) ab[dj][di] = (b[dj] * RBF_NVA + a[di]) * 8u;
+    }
+    uint32_t c[W];
+#pragma unroll
+    for (int d = 0; d < W; ++d) c[d] = __builtin_amdgcn_readfirstlane((uint32_t)L.vz[d * G.nz + k]);   // (k interior: never 255)
+    const uint32_t lane4 = lane * 4u;
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)L.TA, 0, (int)((uint32_t)(W * W * W) * NV3 * 8u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(w + (tw0 - reach)), 0, (int)((2 * reach + 64) * 4), 0x00020000);
+    float acc = 0.0f;
+#pragma unroll
+    for (int d2 = 0; d2 <= D2; ++d2) {
+#pragma unroll
+        for (int dk = 0; dk < W; ++dk) {
+#pragma unroll
+            for (int dj = 0; dj < W; ++dj) {
+#pragma unroll
+                for (int di = 0; di < W; ++di) {
+                    if ((dk - R) * (dk - R) + (dj - R) * (dj - R) + (di - R) * (di - R) != d2) continue;   // (compile time)
+                    const uint32_t toff = ((uint32_t)((dk * W + dj) * W + di) * RBF_NVA + c[dk]) * (RBF_NVA * RBF_NVA) * 8u;
+                    const uint32_t xoff = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx + (di - R)) * 4u;
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 eb = __builtin_amdgcn_raw_buffer_load_b64(rT, (int)ab[dj][di], (int)toff, 0);
+                    const double e = __hiloint2double((int)eb.y, (int)eb.x);
+                    const float wq = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)xoff, 0));
+                    if (e != 0.0) acc = (float)((double)acc + (double)wq * e);
+                }
+            }
+        }
+    }
+    if (t < tend) out[t] = acc + add;
+}
+// does the run-time stencil visit the neighbours in the order the kernel above has compiled in?
+static bool rbf_stencil_is_canonical(const Stencil& S, int R, int D2)
+{
+    int q = 0;
+    for (int d2 = 0; d2 <= D2; ++d2)
+        for (int dz = -R; dz <= R; ++dz)
+            for (int dy = -R; dy <= R; ++dy)
+                for (int dx = -R; dx <= R; ++dx) {
+                    if (dz * dz + dy * dy + dx * dx != d2) continue;
+                    if (q >= S.n || S.off[q][0] != dx || S.off[q][1] != dy || S.off[q][2] != dz) return false;
+                    ++q;
+                }
+    return q == S.n;
+}
+// true if launched; false: this (R, tap_d2) has no table kernel -> the caller evaluates on the fly
+static bool launch_rbf_apply_lut(const RbfGeom& G, const RbfLutGeom& LG, const Stencil& host_stencil, unsigned nb, hipStream_t st,
+                                 const float* w, const float* tx, const float* ty, const float* tz, const Stencil* d_stencil, float add,
+                                 float* out, int64_t t0 = 0, int64_t t1 = -1, int64_t xlo = 0, int64_t xhi = -1)
+{
+    if (!LG.TA || !rbf_stencil_is_canonical(host_stencil, LG.R, LG.tap_d2)) return false;
+    if (LG.R == 2 && LG.tap_d2 == 7) rbf_apply_lut_kernel<2, 7><<<nb, 256, 0, st>>>(G, LG, w, tx, ty, tz, d_stencil, add, out, t0, t1, xlo, xhi);
+    else if (LG.R == 1 && LG.tap_d2 <= 3) rbf_apply_lut_kernel<1, 3><<<nb, 256, 0, st>>>(G, LG, w, tx, ty, tz, d_stencil, add, out, t0, t1, xlo, xhi);
+    else if (LG.R == 2 && LG.tap_d2 <= 8) rbf_apply_lut_kernel<2, 8><<<nb, 256, 0, st>>>(G, LG, w, tx, ty, tz, d_stencil, add, out, t0, t1, xlo, xhi);
+    else return false;
+    return true;
 }
 
 // host side of the table: distinct Float32 differences per axis and offset, variant ids per lattice index
-static bool rbf_lut_axis(const std::vector<float>& c, int R, float vals[7][RBF_NV], std::vector<uint8_t>& ids)
+// (t: coordinates of the rows / targets, c: of the columns / sources - the same lattice for K, possibly a separately
+// rounded one for the evaluation on the "fine" grid at smooth = 1)
+// returns the largest number of variants of an offset (<= RBF_NVA - 1: the last slot stays unused on every axis and
+// means "no such neighbour"), or 0 when there are more.  The matvec table has room for RBF_NV - 1.
+static int rbf_lut_axis(const std::vector<float>& t, const std::vector<float>& c, int R, float vals[7][RBF_NVA], std::vector<uint8_t>& ids)
 {
+    if (t.size() != c.size()) return 0;
     const int n = (int)c.size(), W = 2 * R + 1;
+    int most = 1;
     ids.assign((size_t)W * n, 255);
     for (int d = 0; d < W; ++d) {
         std::vector<float> u;
         for (int i = 0; i < n; ++i) {
             const int ci = i + d - R;
             if (ci < 0 || ci >= n) continue;
-            u.push_back(c[i] - c[ci]);   // px - G.cx[ci] of rbf_matvec_kernel (IEEE single subtraction on both sides)
+            u.push_back(t[i] - c[ci]);   // px - G.cx[ci] of rbf_matvec_kernel (IEEE single subtraction on both sides)
         }
         std::sort(u.begin(), u.end());
         u.erase(std::unique(u.begin(), u.end()), u.end());
-        if (u.size() > RBF_NV) return false;
-        for (int q = 0; q < RBF_NV; ++q) vals[d][q] = q < (int)u.size() ? u[q] : NAN;
+        if (u.size() > RBF_NVA - 1) return 0;
+        most = std::max(most, (int)u.size());
+        for (int q = 0; q < RBF_NVA; ++q) vals[d][q] = q < (int)u.size() ? u[q] : NAN;
         for (int i = 0; i < n; ++i) {
             const int ci = i + d - R;
             if (ci < 0 || ci >= n) continue;
-            const float v = c[i] - c[ci];
+            const float v = t[i] - c[ci];
             ids[(size_t)d * n + i] = (uint8_t)(std::lower_bound(u.begin(), u.end(), v) - u.begin());
         }
     }
-    return true;
+    return most;
 }
-
 // process_vector (:15-22), pass 1: max |v| over |v| < 1e9 (as Float32 bits, all non-negative)
 __global__ void pv_max_kernel(const double* __restrict__ v, int64_t n, float* __restrict__ f, uint32_t* __restrict__ maxbits,
                               uint32_t* __restrict__ any)
@@ -872,11 +1112,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     const int64_t nf = (int64_t)fx * fy * fz;
     hipStream_t st = nullptr;
     DevBuf d_sdf, d_f, d_w, d_lsf, d_fine, d_cx, d_cy, d_cz, d_tx, d_ty, d_tz, d_st, d_cnt, d_r, d_u, d_q, d_part, d_sum;
-    DevBuf d_lut, d_vx, d_vy, d_vz;
+    DevBuf d_lut, d_luta, d_vx, d_vy, d_vz, d_lutf, d_fvx, d_fvy, d_fvz, d_lv, d_lvf;
     VolumeWork vw;
     auto cleanup = [&]() {
         DevBuf* all[] = {&d_sdf, &d_f, &d_w, &d_lsf, &d_fine, &d_cx, &d_cy, &d_cz, &d_tx, &d_ty, &d_tz, &d_st, &d_cnt,
-                         &d_r, &d_u, &d_q, &d_part, &d_sum, &d_lut, &d_vx, &d_vy, &d_vz};
+                         &d_r, &d_u, &d_q, &d_part, &d_sum, &d_lut, &d_luta, &d_vx, &d_vy, &d_vz, &d_lutf, &d_fvx, &d_fvy, &d_fvz, &d_lv, &d_lvf};
         for (DevBuf* b : all) b->release();
         vw.release();
     };
@@ -958,6 +1198,69 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         G.tap_d2 = (int)std::floor(R2 * 1.05 + 0.25);      // 1e-3 -> 7 (i.e. 6: 7 is not a sum of three squares)
         G.tap_r = (int)std::floor(std::sqrt((double)G.tap_d2));
     }
+    // ---- tables of the distinct kernel values: the CG matvec (T) and the evaluation on the same grid (TA) ----
+    // (exact, no matrix in memory; R2S_RBF_MATVEC=k|fly and R2S_RBF_APPLY=fly force the other paths - the tests compare them)
+    const char* mv_env = getenv("R2S_RBF_MATVEC");   // (read per call: the tests switch)
+    const char* ap_env = getenv("R2S_RBF_APPLY");
+    const bool want_mv_lut = is_interp && !(mv_env && (mv_env[0] == 'k' || mv_env[0] == 'f'));
+    const bool want_ap_lut = !(ap_env && ap_env[0] == 'f');
+    RbfLutGeom LG, LGF;   // LGF: the evaluation of the output field at smooth = 1 (its grid is rounded separately)
+    memset(&LG, 0, sizeof LG);
+    memset(&LGF, 0, sizeof LGF);
+    const bool fine_one_to_one = smooth == 1 && fx == nx && fy == ny && fz == nz;
+    if (G.tap_r >= 1 && G.tap_r <= 3 && want_ap_lut && fine_one_to_one) {
+        RbfLutVals LV;
+        memset(&LV, 0, sizeof LV);
+        LV.R = G.tap_r; LV.sigma = G.sigma; LV.thr = G.thr; LV.max_distance = G.max_distance;
+        std::vector<uint8_t> ix, iy, iz;
+        if (rbf_lut_axis(tx, cx, G.tap_r, LV.v[0], ix) && rbf_lut_axis(ty, cy, G.tap_r, LV.v[1], iy) && rbf_lut_axis(tz, cz, G.tap_r, LV.v[2], iz)) {
+            const int W = 2 * G.tap_r + 1;
+            const size_t nT = (size_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
+            ENSURE_C(d_fvx, ix.size()); ENSURE_C(d_fvy, iy.size()); ENSURE_C(d_fvz, iz.size());
+            HIP_C(hipMemcpy(d_fvx.p, ix.data(), ix.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(d_fvy.p, iy.data(), iy.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(d_fvz.p, iz.data(), iz.size(), hipMemcpyHostToDevice));
+            LGF.nx = nx; LGF.ny = ny; LGF.nz = nz; LGF.R = G.tap_r; LGF.tap_d2 = G.tap_d2;
+            LGF.vx = d_fvx.as<uint8_t>(); LGF.vy = d_fvy.as<uint8_t>(); LGF.vz = d_fvz.as<uint8_t>();
+            ENSURE_C(d_lutf, sizeof(double) * nT);
+            ENSURE_C(d_lvf, sizeof LV);
+            HIP_C(hipMemcpy(d_lvf.p, &LV, sizeof LV, hipMemcpyHostToDevice));
+            rbf_lut_build_apply_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(d_lvf.as<RbfLutVals>(), d_lutf.as<double>());
+            LGF.TA = d_lutf.as<double>();
+        }
+    }
+    if (G.tap_r >= 1 && G.tap_r <= 3 && (want_mv_lut || want_ap_lut)) {
+        RbfLutVals LV;
+        memset(&LV, 0, sizeof LV);
+        LV.R = G.tap_r; LV.sigma = G.sigma; LV.thr = G.thr; LV.max_distance = G.max_distance;
+        std::vector<uint8_t> ix, iy, iz;
+        const int m0 = rbf_lut_axis(cx, cx, G.tap_r, LV.v[0], ix), m1 = rbf_lut_axis(cy, cy, G.tap_r, LV.v[1], iy),
+                  m2 = rbf_lut_axis(cz, cz, G.tap_r, LV.v[2], iz);
+        const bool mv_fits = std::max(m0, std::max(m1, m2)) <= RBF_NV - 1;
+        if (m0 && m1 && m2) {
+            const int W = 2 * G.tap_r + 1;
+            const size_t nT = (size_t)W * W * W * RBF_NV * RBF_NV * RBF_NV;
+            ENSURE_C(d_vx, ix.size()); ENSURE_C(d_vy, iy.size()); ENSURE_C(d_vz, iz.size());
+            HIP_C(hipMemcpy(d_vx.p, ix.data(), ix.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(d_vy.p, iy.data(), iy.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(d_vz.p, iz.data(), iz.size(), hipMemcpyHostToDevice));
+            LG.nx = nx; LG.ny = ny; LG.nz = nz; LG.R = G.tap_r; LG.tap_d2 = G.tap_d2;
+            LG.vx = d_vx.as<uint8_t>(); LG.vy = d_vy.as<uint8_t>(); LG.vz = d_vz.as<uint8_t>();
+            ENSURE_C(d_lv, sizeof LV);
+            HIP_C(hipMemcpy(d_lv.p, &LV, sizeof LV, hipMemcpyHostToDevice));
+            if (want_mv_lut && mv_fits) {
+                ENSURE_C(d_lut, sizeof(float) * nT);
+                rbf_lut_build_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(d_lv.as<RbfLutVals>(), d_lut.as<float>());
+                LG.T = d_lut.as<float>();
+            }
+            if (want_ap_lut) {
+                const size_t nTA = (size_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
+                ENSURE_C(d_luta, sizeof(double) * nTA);
+                rbf_lut_build_apply_kernel<<<(unsigned)((nTA + 255) / 256), 256, 0, st>>>(d_lv.as<RbfLutVals>(), d_luta.as<double>());
+                LG.TA = d_luta.as<double>();
+            }
+        }
+    }
     // ---- weights ----
     int its = 0;
     if (is_interp) {   // compute_rbf_weights (:191-202): cg(K, b), IterativeSolvers 0.9.4 defaults
@@ -987,31 +1290,9 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
                     taps.off[taps.n][0] = (signed char)di; taps.off[taps.n][1] = (signed char)dj; taps.off[taps.n][2] = (signed char)dk;
                     taps.n++;
                 }
-        // first choice: the table of distinct entries (exact, no matrix in memory); R2S_RBF_MATVEC=k|fly forces the others
-        bool use_lut = false, use_k = false;
-        const char* mv_env = getenv("R2S_RBF_MATVEC");   // (read per call: the tests switch between the three)
-        RbfLutGeom LG;
-        memset(&LG, 0, sizeof LG);
-        if (G.tap_r >= 1 && G.tap_r <= 3 && !(mv_env && (mv_env[0] == 'k' || mv_env[0] == 'f'))) {
-            RbfLutVals LV;
-            memset(&LV, 0, sizeof LV);
-            LV.R = G.tap_r; LV.sigma = G.sigma; LV.thr = G.thr;
-            std::vector<uint8_t> ix, iy, iz;
-            if (rbf_lut_axis(cx, G.tap_r, LV.v[0], ix) && rbf_lut_axis(cy, G.tap_r, LV.v[1], iy) && rbf_lut_axis(cz, G.tap_r, LV.v[2], iz)) {
-                const int W = 2 * G.tap_r + 1;
-                const size_t nT = (size_t)W * W * W * RBF_NV * RBF_NV * RBF_NV;
-                ENSURE_C(d_lut, sizeof(float) * nT);
-                ENSURE_C(d_vx, ix.size()); ENSURE_C(d_vy, iy.size()); ENSURE_C(d_vz, iz.size());
-                HIP_C(hipMemcpy(d_vx.p, ix.data(), ix.size(), hipMemcpyHostToDevice));
-                HIP_C(hipMemcpy(d_vy.p, iy.data(), iy.size(), hipMemcpyHostToDevice));
-                HIP_C(hipMemcpy(d_vz.p, iz.data(), iz.size(), hipMemcpyHostToDevice));
-                rbf_lut_build_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(LV, d_lut.as<float>());
-                LG.nx = nx; LG.ny = ny; LG.nz = nz; LG.R = G.tap_r; LG.tap_d2 = G.tap_d2;
-                LG.vx = d_vx.as<uint8_t>(); LG.vy = d_vy.as<uint8_t>(); LG.vz = d_vz.as<uint8_t>();
-                LG.T = d_lut.as<float>();
-                use_lut = true;
-            }
-        }
+        // first choice: the table of distinct entries; then the materialised matrix; then on the fly
+        const bool use_lut = LG.T != nullptr;
+        bool use_k = false;
         std::unique_lock<std::mutex> kv_lock(g_rbf_kv_mutex, std::defer_lock);
         if (!use_lut && !(mv_env && mv_env[0] == 'f')) kv_lock.try_lock();   // busy: fall back to on-the-fly
         if (!use_lut && taps_ok && kv_lock.owns_lock()) {
@@ -1033,9 +1314,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         while (!(residual <= tol) && its < n) {
             const float beta = (residual * residual) / (prev * prev);
             cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
-            if (use_lut && G.tap_r == 1) rbf_matvec_lut_kernel<1><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
-            else if (use_lut && G.tap_r == 2) rbf_matvec_lut_kernel<2><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
-            else if (use_lut) rbf_matvec_lut_kernel<3><<<nb, 256, 0, st>>>(LG, d_u.as<float>(), d_q.as<float>());
+            if (use_lut) launch_rbf_matvec_lut(LG, nb, st, d_u.as<float>(), d_q.as<float>());
             else if (use_k) rbf_matvec_k_kernel<<<nb, 256, 0, st>>>(G, taps, g_rbf_kv.as<float>(), d_u.as<float>(), d_q.as<float>());
             else rbf_matvec_kernel<<<nb, 256, 0, st>>>(G, d_u.as<float>(), d_q.as<float>());
             float uq;
@@ -1052,8 +1331,10 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     }
     if (cg_iters) *cg_iters = its;
     // ---- LSF on the coarse grid (:357) and the volume-preserving level (:359, :265-300) ----
-    rbf_apply_kernel<<<nb, 256, 0, st>>>(G, d_w.as<float>(), 1, nx, ny, nz, d_cx.as<float>(), d_cy.as<float>(),
-                                        d_cz.as<float>(), d_st.as<Stencil>(), 0.0f, d_lsf.as<float>());
+    if (!launch_rbf_apply_lut(G, LG, sts[0], nb, st, d_w.as<float>(), d_cx.as<float>(), d_cy.as<float>(), d_cz.as<float>(),
+                              d_st.as<Stencil>(), 0.0f, d_lsf.as<float>()))
+        rbf_apply_kernel<<<nb, 256, 0, st>>>(G, d_w.as<float>(), 1, nx, ny, nz, d_cx.as<float>(), d_cy.as<float>(),
+                                            d_cz.as<float>(), d_st.as<Stencil>(), 0.0f, d_lsf.as<float>());
     if (lsf_out) HIP_C(hipMemcpy(lsf_out, d_lsf.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     int mmh[2] = {0x7FFFFFFF, (int)0x80000000};
     HIP_C(hipMemcpy(d_cnt.p, mmh, 8, hipMemcpyHostToDevice));
@@ -1078,8 +1359,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     if (th_out) *th_out = th;
     // ---- fine grid (:363-366) ----
     const unsigned nbf = (unsigned)((nf + 255) / 256);
-    rbf_apply_kernel<<<nbf, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
-                                         d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine);
+    // (smooth = 1: one target per lattice point - through the table of ITS coordinate differences)
+    if (!(fine_one_to_one && launch_rbf_apply_lut(G, LGF, sts[1], nbf, st, d_w.as<float>(), d_tx.as<float>(), d_ty.as<float>(),
+                                                  d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine)))
+        rbf_apply_kernel<<<nbf, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
+                                             d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine);
     HIP_C(hipGetLastError());
     if (out_dev) HIP_C(hipDeviceSynchronize());
     else HIP_C(hipMemcpy(fine_out, d_fine.p, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost));
@@ -1437,19 +1721,36 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         if (S[q].h0 > std::max(0, S[q].k0 - halo) || S[q].h1 < std::min(nz, S[q].k1 + halo))
             return fail(R2S_ERR_ARG, "slab [%d,%d) holds [%d,%d): the smoothing stencils need a halo of %d planes", S[q].k0, S[q].k1,
                         S[q].h0, S[q].h1, halo);
-    // matvec through the table of distinct matrix entries when the lattice allows it (else on the fly)
+    // matvec and same-grid evaluation through the tables of distinct kernel values when the lattice allows it (else on the fly)
     RbfLutVals LV;
     memset(&LV, 0, sizeof LV);
     std::vector<uint8_t> ix, iy, iz;
-    bool use_lut = false;
-    if (is_interp && G0.tap_r >= 1 && G0.tap_r <= 3) {
-        LV.R = G0.tap_r; LV.sigma = G0.sigma; LV.thr = G0.thr;
-        use_lut = rbf_lut_axis(cx, G0.tap_r, LV.v[0], ix) && rbf_lut_axis(cy, G0.tap_r, LV.v[1], iy) && rbf_lut_axis(cz, G0.tap_r, LV.v[2], iz);
+    bool lut_axes = false, mv_fits = false;
+    const char* ap_env = getenv("R2S_RBF_APPLY");
+    const bool want_ap_lut = !(ap_env && ap_env[0] == 'f');
+    if ((is_interp || want_ap_lut) && G0.tap_r >= 1 && G0.tap_r <= 3) {
+        LV.R = G0.tap_r; LV.sigma = G0.sigma; LV.thr = G0.thr; LV.max_distance = G0.max_distance;
+        const int m0 = rbf_lut_axis(cx, cx, G0.tap_r, LV.v[0], ix), m1 = rbf_lut_axis(cy, cy, G0.tap_r, LV.v[1], iy),
+                  m2 = rbf_lut_axis(cz, cz, G0.tap_r, LV.v[2], iz);
+        lut_axes = m0 && m1 && m2;
+        mv_fits = std::max(m0, std::max(m1, m2)) <= RBF_NV - 1;
     }
+    const bool use_lut = is_interp && lut_axes && mv_fits;
+    const bool fine_one_to_one = smooth == 1 && fx == nx && fy == ny && fz == nz;
+    RbfLutVals LVF;
+    memset(&LVF, 0, sizeof LVF);
+    std::vector<uint8_t> fix, fiy, fiz;
+    bool lutf_axes = false;
+    if (want_ap_lut && fine_one_to_one && G0.tap_r >= 1 && G0.tap_r <= 3) {
+        LVF.R = G0.tap_r; LVF.sigma = G0.sigma; LVF.thr = G0.thr; LVF.max_distance = G0.max_distance;
+        lutf_axes = rbf_lut_axis(tx, cx, G0.tap_r, LVF.v[0], fix) && rbf_lut_axis(ty, cy, G0.tap_r, LVF.v[1], fiy) &&
+                    rbf_lut_axis(tz, cz, G0.tap_r, LVF.v[2], fiz);
+    }
+    SlabBufs blutf(S), bfvx(S), bfvy(S), bfvz(S), blv(S), blvf(S);
     SlabBufs bf(S), bw(S), br(S), bu(S), bq(S), blsf(S), bfine(S), bcx(S), bcy(S), bcz(S), btx(S), bty(S), btz(S), bst(S), bcnt(S),
-        bpart(S), blut(S), bvx(S), bvy(S), bvz(S), brows(S);
+        bpart(S), blut(S), bluta(S), bvx(S), bvy(S), bvz(S), brows(S);
     std::vector<RbfGeom> Gq(G, G0);
-    std::vector<RbfLutGeom> LG(G);
+    std::vector<RbfLutGeom> LG(G), LGF(G);
     std::vector<VolumeWork> vw(G);
     std::vector<void*> base(G, nullptr);
     auto nheld = [&](size_t q) { return (size_t)(S[q].h1 - S[q].h0) * (size_t)plane; };
@@ -1499,16 +1800,37 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         SLAB_TRY(up(btx, tx.data(), 4 * tx.size())); SLAB_TRY(up(bty, ty.data(), 4 * ty.size())); SLAB_TRY(up(btz, tz.data(), 4 * tz.size()));
         SLAB_TRY(up(bst, sts.data(), sizeof(Stencil) * sts.size()));
         Gq[q].cx = bcx.at<float>(q); Gq[q].cy = bcy.at<float>(q); Gq[q].cz = bcz.at<float>(q);
-        if (use_lut) {
+        memset(&LG[q], 0, sizeof(RbfLutGeom));
+        if (lut_axes) {
             const int W = 2 * G0.tap_r + 1;
             const size_t nT = (size_t)W * W * W * RBF_NV * RBF_NV * RBF_NV;
-            SLAB_TRY(blut.ensure(q, sizeof(float) * nT));
             SLAB_TRY(up(bvx, ix.data(), ix.size())); SLAB_TRY(up(bvy, iy.data(), iy.size())); SLAB_TRY(up(bvz, iz.data(), iz.size()));
-            rbf_lut_build_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, d.stream>>>(LV, blut.at<float>(q));
-            memset(&LG[q], 0, sizeof(RbfLutGeom));
+            SLAB_TRY(up(blv, &LV, sizeof LV));
             LG[q].nx = nx; LG[q].ny = ny; LG[q].nz = nz; LG[q].R = G0.tap_r; LG[q].tap_d2 = G0.tap_d2;
             LG[q].vx = bvx.at<uint8_t>(q); LG[q].vy = bvy.at<uint8_t>(q); LG[q].vz = bvz.at<uint8_t>(q);
-            LG[q].T = blut.at<float>(q);
+            if (use_lut) {
+                SLAB_TRY(blut.ensure(q, sizeof(float) * nT));
+                rbf_lut_build_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, d.stream>>>(blv.at<RbfLutVals>(q), blut.at<float>(q));
+                LG[q].T = blut.at<float>(q);
+            }
+            if (want_ap_lut) {
+                const size_t nTA = (size_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
+                SLAB_TRY(bluta.ensure(q, sizeof(double) * nTA));
+                rbf_lut_build_apply_kernel<<<(unsigned)((nTA + 255) / 256), 256, 0, d.stream>>>(blv.at<RbfLutVals>(q), bluta.at<double>(q));
+                LG[q].TA = bluta.at<double>(q);
+            }
+        }
+        memset(&LGF[q], 0, sizeof(RbfLutGeom));
+        if (lutf_axes) {
+            const int W = 2 * G0.tap_r + 1;
+            const size_t nT = (size_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
+            SLAB_TRY(up(bfvx, fix.data(), fix.size())); SLAB_TRY(up(bfvy, fiy.data(), fiy.size())); SLAB_TRY(up(bfvz, fiz.data(), fiz.size()));
+            LGF[q].nx = nx; LGF[q].ny = ny; LGF[q].nz = nz; LGF[q].R = G0.tap_r; LGF[q].tap_d2 = G0.tap_d2;
+            LGF[q].vx = bfvx.at<uint8_t>(q); LGF[q].vy = bfvy.at<uint8_t>(q); LGF[q].vz = bfvz.at<uint8_t>(q);
+            SLAB_TRY(blutf.ensure(q, sizeof(double) * nT));
+            SLAB_TRY(up(blvf, &LVF, sizeof LVF));
+            rbf_lut_build_apply_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, d.stream>>>(blvf.at<RbfLutVals>(q), blutf.at<double>(q));
+            LGF[q].TA = blutf.at<double>(q);
         }
         // process_vector pass 1 on the OWNED planes (every plane counts once for the maximum)
         SLAB_HIP(hipMemsetAsync(bcnt.b[q].p, 0, 64, d.stream));
@@ -1565,9 +1887,7 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
                 float* xv = vptr(bu.at<float>(q), q);
                 float* yv = vptr(bq.at<float>(q), q);
                 const int64_t xlo = (int64_t)d.h0 * plane, xhi = (int64_t)d.h1 * plane - 1;
-                if (use_lut && G0.tap_r == 1) rbf_matvec_lut_kernel<1><<<nb, 256, 0, d.stream>>>(LG[q], xv, yv, t0, t1, xlo, xhi);
-                else if (use_lut && G0.tap_r == 2) rbf_matvec_lut_kernel<2><<<nb, 256, 0, d.stream>>>(LG[q], xv, yv, t0, t1, xlo, xhi);
-                else if (use_lut) rbf_matvec_lut_kernel<3><<<nb, 256, 0, d.stream>>>(LG[q], xv, yv, t0, t1, xlo, xhi);
+                if (use_lut) launch_rbf_matvec_lut(LG[q], nb, d.stream, xv, yv, t0, t1, xlo, xhi);
                 else rbf_matvec_kernel<<<nb, 256, 0, d.stream>>>(Gq[q], xv, yv, t0, t1);
             }
             float uq;
@@ -1599,9 +1919,12 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         const Slab& d = S[q];
         const int64_t t0 = (int64_t)d.k0 * plane, t1 = (int64_t)d.k1 * plane;
         SLAB_HIP(hipSetDevice(d.device));
-        rbf_apply_kernel<<<(unsigned)((t1 - t0 + 255) / 256), 256, 0, d.stream>>>(Gq[q], vptr(bw.at<float>(q), q), 1, nx, ny, nz, bcx.at<float>(q),
-                                                                                bcy.at<float>(q), bcz.at<float>(q), bst.at<Stencil>(q), 0.0f,
-                                                                                vptr(blsf.at<float>(q), q), t0, t1);
+        if (!launch_rbf_apply_lut(Gq[q], LG[q], sts[0], (unsigned)((t1 - t0 + 255) / 256), d.stream, vptr(bw.at<float>(q), q), bcx.at<float>(q),
+                                  bcy.at<float>(q), bcz.at<float>(q), bst.at<Stencil>(q), 0.0f, vptr(blsf.at<float>(q), q), t0, t1,
+                                  (int64_t)d.h0 * plane, (int64_t)d.h1 * plane - 1))
+            rbf_apply_kernel<<<(unsigned)((t1 - t0 + 255) / 256), 256, 0, d.stream>>>(Gq[q], vptr(bw.at<float>(q), q), 1, nx, ny, nz, bcx.at<float>(q),
+                                                                                    bcy.at<float>(q), bcz.at<float>(q), bst.at<Stencil>(q), 0.0f,
+                                                                                    vptr(blsf.at<float>(q), q), t0, t1);
     }
     SLAB_TRY(sync_slabs(S));
     SLAB_TRY(halo_xchg(blsf, 1));   // the cells of the last owned plane reach into the next one
@@ -1673,9 +1996,12 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         const int64_t t0 = (int64_t)f0 * fplane, t1 = (int64_t)f1 * fplane;
         SLAB_HIP(hipSetDevice(d.device));
         SLAB_TRY(bfine.ensure(q, 4 * (size_t)(t1 - t0)));
-        rbf_apply_kernel<<<(unsigned)((t1 - t0 + 255) / 256), 256, 0, d.stream>>>(Gq[q], vptr(bw.at<float>(q), q), smooth, fx, fy, fz, btx.at<float>(q),
-                                                                                bty.at<float>(q), btz.at<float>(q), bst.at<Stencil>(q) + 1, th,
-                                                                                bfine.at<float>(q) - t0, t0, t1);
+        if (!(fine_one_to_one && launch_rbf_apply_lut(Gq[q], LGF[q], sts[1], (unsigned)((t1 - t0 + 255) / 256), d.stream, vptr(bw.at<float>(q), q),
+                                                      btx.at<float>(q), bty.at<float>(q), btz.at<float>(q), bst.at<Stencil>(q) + 1, th,
+                                                      bfine.at<float>(q) - t0, t0, t1, (int64_t)d.h0 * plane, (int64_t)d.h1 * plane - 1)))
+            rbf_apply_kernel<<<(unsigned)((t1 - t0 + 255) / 256), 256, 0, d.stream>>>(Gq[q], vptr(bw.at<float>(q), q), smooth, fx, fy, fz, btx.at<float>(q),
+                                                                                    bty.at<float>(q), btz.at<float>(q), bst.at<Stencil>(q) + 1, th,
+                                                                                    bfine.at<float>(q) - t0, t0, t1);
         SLAB_HIP(hipMemcpyAsync(fine_out_host + t0, bfine.at<float>(q), 4 * (size_t)(t1 - t0), hipMemcpyDeviceToHost, d.stream));
     }
     SLAB_TRY(sync_slabs(S));

@@ -183,3 +183,22 @@ def test_rbf_matvec_variants_are_bit_identical(pkg, oracle, monkeypatch):
         assert outs[mode][1] == outs["lut"][1] and outs[mode][2] == outs["lut"][2]
         assert np.array_equal(outs[mode][0], outs["lut"][0]) and np.array_equal(outs[mode][3], outs["lut"][3])
     pkg._lib.lib().r2s_release_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interp", [False, True])
+def test_rbf_evaluation_table_is_bit_identical(pkg, oracle, monkeypatch, interp):
+    """same-grid evaluation (the LSF of the level bisection and the output field at smooth = 1) through the table of
+    distinct kernel values vs neighbour-by-neighbour evaluation (R2S_RBF_APPLY=fly): same values, same order"""
+    X, IEN, rho, og, sdf = _raw_sdf(oracle, "beam_vfrac_04", 0.518555)
+    oracle.remove_artifacts(sdf, og)
+    vd, vf = oracle.mesh_volume(X, IEN, rho)
+    pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
+    outs = {}
+    for mode in ("lut", "fly"):
+        monkeypatch.setenv("R2S_RBF_APPLY", mode)
+        info = {}
+        outs[mode] = (pkg.RBFs_smoothing(sdf, pg, interp, 1, vd * vf, info=info), info["th"], info["lsf"])
+    assert outs["fly"][1] == outs["lut"][1]
+    assert np.array_equal(outs["fly"][0], outs["lut"][0]) and np.array_equal(outs["fly"][2], outs["lut"][2])
+    assert np.isfinite(outs["lut"][0]).all() and np.ptp(outs["lut"][0]) > 0
