@@ -279,12 +279,50 @@ __global__ void __launch_bounds__(256) sum_f32_kernel(const float* __restrict__ 
 // integer division).  Full cells are summed per thread; cut cells are listed in LDS in x order and
 // then worked off one WAVEFRONT per cell (lanes split the order^3 Gauss points), so a few cut cells
 // do not stall 63 idle lanes for 729 iterations.  Every reduction has a fixed order (no float atomics).
+// smallest / largest corner value over the cells of every 64-cell segment of every cell row: the level bisection
+// evaluates the volume of the same field at up to 40 levels, and a segment whose values all lie on one side of the
+// level needs no loads (volume_rows_kernel)
+__global__ void __launch_bounds__(256) volume_seg_minmax_kernel(const float* __restrict__ sdf, int nx, int ny, int nz,
+                                                               float* __restrict__ segmn, float* __restrict__ segmx, int row0)
+{
+    const int row = row0 + blockIdx.x;
+    const int j = row % (ny - 1), k = row / (ny - 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t sy = nx, sz = (int64_t)nx * ny;
+    const int nseg = (nx - 1 + 63) / 64;
+    for (int sg = wave; sg < nseg; sg += 4) {
+        const int i = sg * 64 + lane;
+        float mn = INFINITY, mx = -INFINITY;
+        if (i < nx - 1) {
+            const int64_t b = ((int64_t)k * ny + j) * nx + i;
+            const float c000 = sdf[b], c100 = sdf[b + 1], c010 = sdf[b + sy], c110 = sdf[b + sy + 1], c001 = sdf[b + sz],
+                        c101 = sdf[b + sz + 1], c011 = sdf[b + sz + sy], c111 = sdf[b + sz + sy + 1];
+            mn = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111)));
+            mx = fmaxf(fmaxf(fmaxf(c000, c100), fmaxf(c010, c110)), fmaxf(fmaxf(c001, c101), fmaxf(c011, c111)));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        }
+        if (lane == 0) {
+            segmn[(size_t)row * nseg + sg] = mn;
+            segmx[(size_t)row * nseg + sg] = mx;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restrict__ sdf, int nx, int ny, int nz,
                                                          float shift, float iso, float elvol, float jac,
-                                                         QuadTab q, float* __restrict__ partial, int row0 = 0)
+                                                         QuadTab q, float* __restrict__ partial, int row0 = 0,
+                                                         const float* __restrict__ segmn = nullptr,
+                                                         const float* __restrict__ segmx = nullptr)
 {
     // (row0: first cell row of this launch - a Z-slab of a multi-device run works on the rows of its planes, with
-    //  `sdf` and `partial` addressed as the whole grid's)
+    //  `sdf`, `partial` and the segment arrays addressed as the whole grid's)
+    // segmn / segmx (volume_seg_minmax_kernel, optional): rounding is monotonic, so (segment max - shift) < iso puts
+    // every cell of the segment outside and (segment min - shift) >= iso makes every cell full - the same decisions the
+    // cells would take one by one, without their loads; every thread still adds the same numbers in the same order.
     __shared__ float red[256];
     __shared__ int s_cut[256];
     __shared__ int s_wcnt[4];
@@ -293,12 +331,40 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t sy = nx, sz = (int64_t)nx * ny;
     const int npts = q.order * q.order * q.order;
+    const int nseg = (nx - 1 + 63) / 64;
+    const bool segs = segmn != nullptr;
+    if (segs) {
+        bool any = false;
+        for (int sg = 0; sg < nseg; ++sg) any = any || !(segmx[(size_t)row * nseg + sg] - shift < iso);
+        if (!any) {   // every cell outside: all partial sums are 0
+            if (tid == 0) partial[row] = 0.0f;
+            return;
+        }
+    }
     float acc = 0.0f;    // full cells (per thread)
     float wacc = 0.0f;   // cut cells (lane 0 of each wave)
     for (int i0 = 0; i0 < nx - 1; i0 += 256) {
         const int i = i0 + tid;
         int cls = 0;
-        if (i < nx - 1) {
+        int state = 2;          // of this wavefront's segment: 0 outside, 1 full, 2 look at the cells
+        bool chunk_cut = true;  // some segment of this chunk needs its cells looked at (uniform over the workgroup)
+        if (segs) {
+            chunk_cut = false;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int sg = (i0 >> 6) + w;
+                int st = 0;
+                if (sg < nseg) {
+                    const float smn = segmn[(size_t)row * nseg + sg] - shift, smx = segmx[(size_t)row * nseg + sg] - shift;
+                    st = (smx < iso) ? 0 : (smn >= iso ? 1 : 2);
+                }
+                chunk_cut = chunk_cut || st == 2;
+                if (w == wave) state = st;
+            }
+        }
+        if (state == 1) {
+            if (i < nx - 1) acc += elvol;
+        } else if (state == 2 && i < nx - 1) {
             const int64_t b = ((int64_t)k * ny + j) * nx + i;
             const float c000 = sdf[b] - shift, c100 = sdf[b + 1] - shift, c010 = sdf[b + sy] - shift,
                         c110 = sdf[b + sy + 1] - shift, c001 = sdf[b + sz] - shift, c101 = sdf[b + sz + 1] - shift,
@@ -310,6 +376,7 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
                 else cls = 1;
             }
         }
+        if (!chunk_cut) continue;
         // cut cells listed in x order: ballot per wavefront, offsets from the four wave counts (no serial scan)
         const uint64_t m = __ballot(cls != 0);
         if (lane == 0) s_wcnt[wave] = __popcll(m);
@@ -347,17 +414,22 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
         }
         __syncthreads();
     }
+    // the sum tree red[t] += red[t + s], s = 128 ... 1, with its last six levels inside wavefront 0 (same additions)
     red[tid] = acc + wacc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
+    if (tid < 128) red[tid] += red[tid + 128];
+    __syncthreads();
+    if (wave == 0) {
+        float v = red[lane] + red[lane + 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);   // lanes < off hold the tree's values
+        if (lane == 0) partial[row] = v;
     }
-    if (tid == 0) partial[row] = red[0];
 }
 
 struct VolumeWork {
-    DevBuf partial, result;
+    DevBuf partial, result, segmn, segmx;
+    const float* seg_field = nullptr;   // the field the segment extrema were computed for (prepare)
     QuadTab q;
     int nblocks = 2048;
     int init(int order)
@@ -371,6 +443,18 @@ struct VolumeWork {
         ENSURE(result, 64);
         return 0;
     }
+    // before a series of run() calls on the same field: segment extrema, so that each level only looks at the cells near it
+    int prepare(const float* d_sdf, int nx, int ny, int nz, hipStream_t st)
+    {
+        const int nrows = (ny - 1) * (nz - 1), nseg = (nx - 1 + 63) / 64;
+        seg_field = nullptr;
+        if (nrows <= 0 || nseg <= 0) return 0;
+        ENSURE(segmn, sizeof(float) * (size_t)nrows * nseg);
+        ENSURE(segmx, sizeof(float) * (size_t)nrows * nseg);
+        volume_seg_minmax_kernel<<<nrows, 256, 0, st>>>(d_sdf, nx, ny, nz, segmn.as<float>(), segmx.as<float>(), 0);
+        seg_field = d_sdf;
+        return 0;
+    }
     // volume of {sdf - shift >= iso}; synchronises the stream
     int run(const float* d_sdf, int nx, int ny, int nz, float edge, float shift, float iso, hipStream_t st, float* out)
     {
@@ -378,13 +462,15 @@ struct VolumeWork {
         const float jac = elvol / 8.0f;               // :51
         const int nrows = (ny - 1) * (nz - 1);
         ENSURE(partial, sizeof(float) * (size_t)nrows);
-        volume_rows_kernel<<<nrows, 256, 0, st>>>(d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>());
+        const bool segs = seg_field == d_sdf && seg_field != nullptr;
+        volume_rows_kernel<<<nrows, 256, 0, st>>>(d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>(), 0,
+                                                 segs ? segmn.as<float>() : nullptr, segs ? segmx.as<float>() : nullptr);
         sum_f32_kernel<<<1, 256, 0, st>>>(partial.as<float>(), nrows, result.as<float>());
         HIP_TRY(hipMemcpyAsync(out, result.p, sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         return 0;
     }
-    void release() { partial.release(); result.release(); }
+    void release() { partial.release(); result.release(); segmn.release(); segmx.release(); seg_field = nullptr; }
 };
 
 // ====================================================================================
@@ -622,6 +708,12 @@ __global__ void __launch_bounds__(256) rbf_matvec_k_kernel(RbfGeom G, RbfTaps T,
 // of accumulation => bit-identical to rbf_matvec_kernel, without its 81 exp() per row and without the 43 GB
 // materialised matrix of rbf_matvec_k_kernel; the table (<= 2 MB for R = 2) lives in L2.
 #define RBF_NV 16   // variants per (axis, offset) the matvec table has room for; more -> the materialised / on-the-fly paths
+#ifndef RBF_MATVEC_BATCH
+#define RBF_MATVEC_BATCH 16
+#endif
+#ifndef RBF_APPLY_BATCH
+#define RBF_APPLY_BATCH 12
+#endif
 #define RBF_NVA 64  // ... and the evaluation tables (the differences against the separately rounded output grid take 20-40)
 struct RbfLutGeom {
     int nx, ny, nz, R, tap_d2;
@@ -652,6 +744,42 @@ __global__ void __launch_bounds__(256) rbf_lut_build_kernel(const RbfLutVals* __
     const double val = exp(-(u * u));
     T[t] = (val > V.thr) ? (float)val : 0.0f;   // (unused variant slots hold NaN values -> comparisons false -> 0)
 }
+// the neighbours of a lattice point in the order of build_stencil at smooth = 1: lattice distance^2, then dz, dy, dx
+template <int R>
+struct RbfTapOrder {
+    int n;
+    signed char dk[(2 * R + 1) * (2 * R + 1) * (2 * R + 1)], dj[(2 * R + 1) * (2 * R + 1) * (2 * R + 1)], di[(2 * R + 1) * (2 * R + 1) * (2 * R + 1)];
+};
+template <int R, int D2>
+constexpr RbfTapOrder<R> rbf_tap_order_rowwise()   // dk, dj, di ascending: the order of the matrix rows (rbf_matvec_kernel)
+{
+    RbfTapOrder<R> t{};
+    t.n = 0;
+    for (int dk = -R; dk <= R; ++dk)
+        for (int dj = -R; dj <= R; ++dj)
+            for (int di = -R; di <= R; ++di)
+                if (dk * dk + dj * dj + di * di <= D2) {
+                    t.dk[t.n] = (signed char)(dk + R); t.dj[t.n] = (signed char)(dj + R); t.di[t.n] = (signed char)(di + R);
+                    t.n++;
+                }
+    return t;
+}
+template <int R, int D2>
+constexpr RbfTapOrder<R> rbf_tap_order()
+{
+    RbfTapOrder<R> t{};
+    t.n = 0;
+    for (int d2 = 0; d2 <= D2; ++d2)
+        for (int dk = -R; dk <= R; ++dk)
+            for (int dj = -R; dj <= R; ++dj)
+                for (int di = -R; di <= R; ++di)
+                    if (dk * dk + dj * dj + di * di == d2) {
+                        t.dk[t.n] = (signed char)(dk + R); t.dj[t.n] = (signed char)(dj + R); t.di[t.n] = (signed char)(di + R);
+                        t.n++;
+                    }
+    return t;
+}
+
 // one row through per-lane clamped addresses and predicates: rows of the first / last R planes, of wavefronts that
 // straddle two planes and of a slab whose halo ends nearby
 // the table of the evaluation (rbf_apply_kernel with targets = lattice points): same differences, that kernel's arithmetic
@@ -781,24 +909,51 @@ __global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(x + (tw0 - reach)), 0, (int)((2 * reach + 64) * 4), 0x00020000);
     float acc = 0.0f;
+    if constexpr (D2 >= 0) {
+        // batches of RBF_MATVEC_BATCH entries: the loads of a batch are in flight together, then the (serial) row sum
+        constexpr RbfTapOrder<R> TO = rbf_tap_order_rowwise<R, D2>();
+        uint32_t c[W];
 #pragma unroll
-    for (int dk = 0; dk < W; ++dk) {
-        const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)G.vz[dk * G.nz + k]);   // (k is interior: never 255)
+        for (int d = 0; d < W; ++d) c[d] = __builtin_amdgcn_readfirstlane((uint32_t)G.vz[d * G.nz + k]);   // (k is interior: never 255)
 #pragma unroll
-        for (int dj = 0; dj < W; ++dj) {
-            if ((dk - R) * (dk - R) + (dj - R) * (dj - R) > d2max) continue;
-            const uint32_t Trow = (((uint32_t)((dk * W + dj) * W) * RBF_NV + c) * (RBF_NV * RBF_NV)) * 4u;
-            const uint32_t xrow = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx - R) * 4u;
-            float w[W], xv[W];
+        for (int q0 = 0; q0 < TO.n; q0 += RBF_MATVEC_BATCH) {
+            uint32_t wb[RBF_MATVEC_BATCH], xb[RBF_MATVEC_BATCH];
 #pragma unroll
-            for (int di = 0; di < W; ++di) {
-                w[di] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (int)ab[dj][di], (int)(Trow + (uint32_t)di * NV3 * 4u), 0));
-                xv[di] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)(xrow + (uint32_t)di * 4u), 0));
+            for (int u = 0; u < RBF_MATVEC_BATCH; ++u) {
+                const int q = q0 + u < TO.n ? q0 + u : TO.n - 1;
+                const int dk = TO.dk[q], dj = TO.dj[q], di = TO.di[q];
+                const uint32_t toff = ((uint32_t)((dk * W + dj) * W + di) * RBF_NV + c[dk]) * (RBF_NV * RBF_NV) * 4u;
+                const uint32_t xoff = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx + (di - R)) * 4u;
+                wb[u] = __builtin_amdgcn_raw_buffer_load_b32(rT, (int)ab[dj][di], (int)toff, 0);
+                xb[u] = __builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)xoff, 0);
             }
 #pragma unroll
-            for (int di = 0; di < W; ++di) {
-                const bool in = (dk - R) * (dk - R) + (dj - R) * (dj - R) + (di - R) * (di - R) <= d2max;   // (uniform)
-                if (in && w[di] != 0.0f) acc += w[di] * xv[di];
+            for (int u = 0; u < RBF_MATVEC_BATCH; ++u) {
+                if (q0 + u >= TO.n) continue;
+                const float wq = __uint_as_float(wb[u]);
+                if (wq != 0.0f) acc += wq * __uint_as_float(xb[u]);
+            }
+        }
+    } else {
+    #pragma unroll
+        for (int dk = 0; dk < W; ++dk) {
+            const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)G.vz[dk * G.nz + k]);   // (k is interior: never 255)
+    #pragma unroll
+            for (int dj = 0; dj < W; ++dj) {
+                if ((dk - R) * (dk - R) + (dj - R) * (dj - R) > d2max) continue;
+                const uint32_t Trow = (((uint32_t)((dk * W + dj) * W) * RBF_NV + c) * (RBF_NV * RBF_NV)) * 4u;
+                const uint32_t xrow = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx - R) * 4u;
+                float w[W], xv[W];
+    #pragma unroll
+                for (int di = 0; di < W; ++di) {
+                    w[di] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (int)ab[dj][di], (int)(Trow + (uint32_t)di * NV3 * 4u), 0));
+                    xv[di] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)(xrow + (uint32_t)di * 4u), 0));
+                }
+    #pragma unroll
+                for (int di = 0; di < W; ++di) {
+                    const bool in = (dk - R) * (dk - R) + (dj - R) * (dj - R) + (di - R) * (di - R) <= d2max;   // (uniform)
+                    if (in && w[di] != 0.0f) acc += w[di] * xv[di];
+                }
             }
         }
     }
@@ -873,24 +1028,27 @@ __global__ void __launch_bounds__(256) rbf_apply_lut_kernel(RbfGeom G, RbfLutGeo
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(w + (tw0 - reach)), 0, (int)((2 * reach + 64) * 4), 0x00020000);
     float acc = 0.0f;
+    // batches of RBF_APPLY_BATCH neighbours: all loads of a batch are in flight together, then the (serial) sums
+    constexpr RbfTapOrder<R> TO = rbf_tap_order<R, D2>();
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int d2 = 0; d2 <= D2; ++d2) {
+    for (int q0 = 0; q0 < TO.n; q0 += RBF_APPLY_BATCH) {
+        u32x2 eb[RBF_APPLY_BATCH];
+        uint32_t wb[RBF_APPLY_BATCH];
 #pragma unroll
-        for (int dk = 0; dk < W; ++dk) {
+        for (int u = 0; u < RBF_APPLY_BATCH; ++u) {
+            const int q = q0 + u < TO.n ? q0 + u : TO.n - 1;
+            const int dk = TO.dk[q], dj = TO.dj[q], di = TO.di[q];
+            const uint32_t toff = ((uint32_t)((dk * W + dj) * W + di) * RBF_NVA + c[dk]) * (RBF_NVA * RBF_NVA) * 8u;
+            const uint32_t xoff = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx + (di - R)) * 4u;
+            eb[u] = __builtin_amdgcn_raw_buffer_load_b64(rT, (int)ab[dj][di], (int)toff, 0);
+            wb[u] = __builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)xoff, 0);
+        }
 #pragma unroll
-            for (int dj = 0; dj < W; ++dj) {
-#pragma unroll
-                for (int di = 0; di < W; ++di) {
-                    if ((dk - R) * (dk - R) + (dj - R) * (dj - R) + (di - R) * (di - R) != d2) continue;   // (compile time)
-                    const uint32_t toff = ((uint32_t)((dk * W + dj) * W + di) * RBF_NVA + c[dk]) * (RBF_NVA * RBF_NVA) * 8u;
-                    const uint32_t xoff = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx + (di - R)) * 4u;
-                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 eb = __builtin_amdgcn_raw_buffer_load_b64(rT, (int)ab[dj][di], (int)toff, 0);
-                    const double e = __hiloint2double((int)eb.y, (int)eb.x);
-                    const float wq = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)xoff, 0));
-                    if (e != 0.0) acc = (float)((double)acc + (double)wq * e);
-                }
-            }
+        for (int u = 0; u < RBF_APPLY_BATCH; ++u) {
+            if (q0 + u >= TO.n) continue;
+            const double e = __hiloint2double((int)eb[u].y, (int)eb[u].x);
+            if (e != 0.0) acc = (float)((double)acc + (double)__uint_as_float(wb[u]) * e);
         }
     }
     if (t < tend) out[t] = acc + add;
@@ -1343,6 +1501,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     auto dec = [](int b) { b = b >= 0 ? b : (b ^ 0x7FFFFFFF); float f; memcpy(&f, &b, 4); return f; };
     float lo = dec(mmh[0]), hi = dec(mmh[1]);
     TRY_C(vw.init(9));
+    TRY_C(vw.prepare(d_lsf.as<float>(), nx, ny, nz, st));
     const float edge = std::sqrt((cx[1] - cx[0]) * (cx[1] - cx[0]));   // norm(fine_grid[2,1,1] - fine_grid[1,1,1])
     double eps = 1.0;
     float th = 0.0f;
@@ -1746,7 +1905,7 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         lutf_axes = rbf_lut_axis(tx, cx, G0.tap_r, LVF.v[0], fix) && rbf_lut_axis(ty, cy, G0.tap_r, LVF.v[1], fiy) &&
                     rbf_lut_axis(tz, cz, G0.tap_r, LVF.v[2], fiz);
     }
-    SlabBufs blutf(S), bfvx(S), bfvy(S), bfvz(S), blv(S), blvf(S);
+    SlabBufs blutf(S), bfvx(S), bfvy(S), bfvz(S), blv(S), blvf(S), bsegmn(S), bsegmx(S);
     SlabBufs bf(S), bw(S), br(S), bu(S), bq(S), blsf(S), bfine(S), bcx(S), bcy(S), bcz(S), btx(S), bty(S), btz(S), bst(S), bcnt(S),
         bpart(S), blut(S), bluta(S), bvx(S), bvy(S), bvz(S), brows(S);
     std::vector<RbfGeom> Gq(G, G0);
@@ -1956,6 +2115,13 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
             SLAB_HIP(hipSetDevice(S[q].device));
             SLAB_TRY(vw[q].init(9));
             SLAB_TRY(brows.ensure(q, sizeof(float) * (size_t)std::max(nrows, 1)));
+            // segment extrema of the slab's rows (arrays addressed by the row numbers of the whole grid)
+            const int nseg = (nx - 1 + 63) / 64, kc1 = std::min(S[q].k1, nz - 1);
+            SLAB_TRY(bsegmn.ensure(q, sizeof(float) * (size_t)std::max(nrows, 1) * nseg));
+            SLAB_TRY(bsegmx.ensure(q, sizeof(float) * (size_t)std::max(nrows, 1) * nseg));
+            if (kc1 > S[q].k0)
+                volume_seg_minmax_kernel<<<(kc1 - S[q].k0) * (ny - 1), 256, 0, S[q].stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, bsegmn.at<float>(q),
+                                                                                             bsegmx.at<float>(q), S[q].k0 * (ny - 1));
         }
         const float edge = std::sqrt((cx[1] - cx[0]) * (cx[1] - cx[0]));
         const float elvol = edge * edge * edge, jac = elvol / 8.0f;
@@ -1970,7 +2136,7 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
                 const int row0 = d.k0 * (ny - 1), nr = (kc1 - d.k0) * (ny - 1);
                 SLAB_HIP(hipSetDevice(d.device));
                 volume_rows_kernel<<<nr, 256, 0, d.stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, th, 0.0f, elvol, jac, vw[q].q,
-                                                            brows.at<float>(q), row0);
+                                                            brows.at<float>(q), row0, bsegmn.at<float>(q), bsegmx.at<float>(q));
                 if (q != q0)
                     SLAB_HIP(hipMemcpyPeerAsync(brows.at<float>(q0) + row0, S[q0].device, brows.at<float>(q) + row0, d.device,
                                                 sizeof(float) * (size_t)nr, d.stream));
