@@ -924,8 +924,16 @@ __global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const
                 const int dk = TO.dk[q], dj = TO.dj[q], di = TO.di[q];
                 const uint32_t toff = ((uint32_t)((dk * W + dj) * W + di) * RBF_NV + c[dk]) * (RBF_NV * RBF_NV) * 4u;
                 const uint32_t xoff = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx + (di - R)) * 4u;
+#if defined(RBF_DIAG) && RBF_DIAG == 1   // timing-only builds: what the kernel costs without its table / vector loads
+                wb[u] = __float_as_uint(1.0f + (float)ab[dj][di]);
+#else
                 wb[u] = __builtin_amdgcn_raw_buffer_load_b32(rT, (int)ab[dj][di], (int)toff, 0);
+#endif
+#if defined(RBF_DIAG) && RBF_DIAG == 2
+                xb[u] = __float_as_uint(1.0f + (float)lane4);
+#else
                 xb[u] = __builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)xoff, 0);
+#endif
             }
 #pragma unroll
             for (int u = 0; u < RBF_MATVEC_BATCH; ++u) {
@@ -960,10 +968,93 @@ __global__ void __launch_bounds__(256) rbf_matvec_lut_kernel(RbfLutGeom G, const
     if (t < tend) y[t] = acc;
 }
 
+// The same product with the table rows of a workgroup staged in LDS.  A workgroup = 256 consecutive rows of one Z
+// plane: they span 1-2 (at most RBF_MV_ROWS) lattice rows j, so per neighbour offset it needs one 64-byte table row
+// (16 x variants) per j - 81 x 64 B = 5 KB per j at the default threshold.  The lanes then pick their entry with an LDS
+// read (address = per-lane x variant + immediate) instead of a 64-lane gather from L1/L2, which cost twice what the
+// loads of the vector itself do (timing-only builds without either: 2.5 / 3.9 ms of 5.25 ms at 512^3).
+#define RBF_MV_ROWS 4
+template <int R, int D2>
+__global__ void __launch_bounds__(256) rbf_matvec_lds_kernel(RbfLutGeom G, const float* __restrict__ x, float* __restrict__ y,
+                                                            int64_t t_begin, int64_t t_end, int64_t x_lo, int64_t x_hi)
+{
+    constexpr int W = 2 * R + 1;
+    constexpr RbfTapOrder<R> TO = rbf_tap_order_rowwise<R, D2>();
+    constexpr int NT = TO.n;
+    __shared__ float sT[RBF_MV_ROWS * NT * RBF_NV];
+    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
+    const int64_t tend = t_end >= 0 ? t_end : n;
+    const int64_t first = x_lo, last = x_hi >= 0 ? x_hi : n - 1;
+    const int64_t tb0 = t_begin + (int64_t)blockIdx.x * 256;   // first row of the workgroup
+    if (tb0 >= tend) return;
+    const int64_t tb1 = tb0 + 255 < tend ? tb0 + 255 : tend - 1;
+    const int64_t plane = (int64_t)G.nx * G.ny;
+    const int64_t reach = (int64_t)R * plane + (int64_t)R * G.nx + R;
+    const int k = (int)(tb0 / plane);
+    const int jA = (int)((tb0 - (int64_t)k * plane) / G.nx), jB = (int)((tb1 - (int64_t)k * plane) / G.nx);
+    const bool fast = (tb1 / plane == k) && k >= R && k < G.nz - R && tb0 - reach >= first && tb1 + reach <= last &&
+                      jB - jA + 1 <= RBF_MV_ROWS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const int64_t t = tb0 + tid;
+    if (!fast) {   // (uniform over the workgroup)
+        if (t < tend) y[t] = rbf_lut_row_clamped<R>(G, x, t, first, last);
+        return;
+    }
+    // ---- table rows of this workgroup -> LDS: sT[jr][q][x variant] ----
+    const int nj = jB - jA + 1;
+    for (int e = (int)tid; e < nj * NT * RBF_NV; e += 256) {
+        const int jr = e / (NT * RBF_NV), r = e - jr * (NT * RBF_NV), q = r / RBF_NV, v = r - q * RBF_NV;
+        const int dk = TO.dk[q], dj = TO.dj[q], di = TO.di[q];
+        const uint32_t c = G.vz[dk * G.nz + k];   // (k is interior: never 255)
+        uint32_t b = G.vy[dj * G.ny + jA + jr];
+        b = b != 255u ? b : (uint32_t)(RBF_NV - 1);
+        sT[e] = G.T[((((size_t)((dk * W + dj) * W + di)) * RBF_NV + c) * RBF_NV + b) * RBF_NV + (uint32_t)v];
+    }
+    __syncthreads();
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tw0 = tb0 + (int64_t)wv * 64;
+    if (tw0 >= tend) return;
+    const int64_t tc = t < tend ? t : tend - 1;   // (idle lanes of the last wavefront repeat its last row)
+    const uint32_t r2 = (uint32_t)(tc - (int64_t)k * plane);
+    const uint32_t j = r2 / (uint32_t)G.nx, i = r2 - j * (uint32_t)G.nx;
+    uint32_t a4[W];   // byte offset of the lane's entry inside a staged table row, plus the offset of its j block
+#pragma unroll
+    for (int d = 0; d < W; ++d) {
+        const uint32_t va = G.vx[d * G.nx + i];
+        a4[d] = (va != 255u ? va : (uint32_t)(RBF_NV - 1)) * 4u + (j - (uint32_t)jA) * (uint32_t)(NT * RBF_NV * 4);
+    }
+    const uint32_t lane4 = lane * 4u;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(x + (tw0 - reach)), 0, (int)((2 * reach + 64) * 4), 0x00020000);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q0 = 0; q0 < NT; q0 += RBF_MATVEC_BATCH) {
+        uint32_t xb[RBF_MATVEC_BATCH];
+        float wb[RBF_MATVEC_BATCH];
+#pragma unroll
+        for (int u = 0; u < RBF_MATVEC_BATCH; ++u) {
+            const int q = q0 + u < NT ? q0 + u : NT - 1;
+            const int dk = TO.dk[q], dj = TO.dj[q], di = TO.di[q];
+            const uint32_t xoff = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx + (di - R)) * 4u;
+            xb[u] = __builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)xoff, 0);
+            wb[u] = *(const float*)((const char*)sT + a4[di] + (uint32_t)(q * RBF_NV * 4));
+        }
+#pragma unroll
+        for (int u = 0; u < RBF_MATVEC_BATCH; ++u) {
+            if (q0 + u >= NT) continue;
+            if (wb[u] != 0.0f) acc += wb[u] * __uint_as_float(xb[u]);
+        }
+    }
+    if (t < tend) y[t] = acc;
+}
+
 static void launch_rbf_matvec_lut(const RbfLutGeom& LG, unsigned nb, hipStream_t st, const float* x, float* y, int64_t t0 = 0,
                                   int64_t t1 = -1, int64_t xlo = 0, int64_t xhi = -1)
 {
-    if (LG.R == 2 && LG.tap_d2 == 7) rbf_matvec_lut_kernel<2, 7><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);   // threshold 1e-3 (default)
+    const char* mv_env = getenv("R2S_RBF_MATVEC");
+    const bool global_only = mv_env && !strcmp(mv_env, "lutg");   // table entries gathered from L1/L2 (the tests compare)
+    if (LG.R == 2 && LG.tap_d2 == 7 && !global_only) rbf_matvec_lds_kernel<2, 7><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);   // threshold 1e-3 (default)
+    else if (LG.R == 2 && LG.tap_d2 == 7) rbf_matvec_lut_kernel<2, 7><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);
     else if (LG.R == 1) rbf_matvec_lut_kernel<1, -1><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);
     else if (LG.R == 2) rbf_matvec_lut_kernel<2, -1><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);
     else rbf_matvec_lut_kernel<3, -1><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);
@@ -1469,7 +1560,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         TRY_C(dot(d_r.as<float>(), d_r.as<float>(), &rr));
         float residual = std::sqrt(rr), prev = 1.0f;
         const float tol = 3.4526698e-4f * residual;   // reltol = sqrt(eps(Float32)), abstol = 0
+#ifdef RBF_DIAG   // (timing-only builds compute wrong products: a fixed number of iterations)
+        while (its < 6) {
+#else
         while (!(residual <= tol) && its < n) {
+#endif
             const float beta = (residual * residual) / (prev * prev);
             cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
             if (use_lut) launch_rbf_matvec_lut(LG, nb, st, d_u.as<float>(), d_q.as<float>());

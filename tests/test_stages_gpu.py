@@ -167,7 +167,7 @@ def test_connectivity_outside_node_range_is_an_error(pkg, oracle, badval):
 
 
 def test_rbf_matvec_variants_are_bit_identical(pkg, oracle, monkeypatch):
-    """the CG's matrix-vector product has three implementations: the table of distinct matrix entries (default), the
+    """the CG's matrix-vector product has three implementations: the table of distinct matrix entries (default; two kernels), the
     materialised matrix (R2S_RBF_MATVEC=k) and on-the-fly evaluation (=fly).  All three form every row sum from the
     same Float32 values in the same order, so weights, iteration counts and the smoothed field must be identical"""
     X, IEN, rho, og, sdf = _raw_sdf(oracle, "beam_vfrac_04", 0.518555)
@@ -175,11 +175,11 @@ def test_rbf_matvec_variants_are_bit_identical(pkg, oracle, monkeypatch):
     vd, vf = oracle.mesh_volume(X, IEN, rho)
     pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
     outs = {}
-    for mode in ("lut", "k", "fly"):
+    for mode in ("lut", "lutg", "k", "fly"):   # lut: table rows staged in LDS; lutg: table entries gathered from L1 / L2
         monkeypatch.setenv("R2S_RBF_MATVEC", mode)
         info = {}
         outs[mode] = (pkg.RBFs_smoothing(sdf, pg, True, 1, vd * vf, info=info), info["cg_iterations"], info["th"], info["lsf"])
-    for mode in ("k", "fly"):
+    for mode in ("lutg", "k", "fly"):
         assert outs[mode][1] == outs["lut"][1] and outs[mode][2] == outs["lut"][2]
         assert np.array_equal(outs[mode][0], outs["lut"][0]) and np.array_equal(outs[mode][3], outs["lut"][3])
     pkg._lib.lib().r2s_release_cache()
