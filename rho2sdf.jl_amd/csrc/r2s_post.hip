@@ -48,43 +48,89 @@ __device__ __forceinline__ void uf_union(uint32_t* L, uint32_t a, uint32_t b)
     }
 }
 
-__global__ void ccl_init_kernel(const double* __restrict__ sdf, uint32_t n, double thr, uint32_t* __restrict__ L)
+// Runs of consecutive voxels along x are components by themselves, so only their first voxels ("heads") take part in
+// the union-find: pass 1 points every voxel of a run piece at the piece's head (a piece = a run cut at the boundaries of
+// the 64-voxel wavefronts, found with one ballot), pass 2 joins a piece to the piece before it across a wavefront boundary
+// and runs to the runs of the next row / plane ONCE per overlap interval (at its first voxel), pass 3 points the heads at
+// their roots.  The result - every voxel labelled with the smallest index of its component - is that of one union per
+// pair of neighbouring voxels (round 1: three CAS loops per voxel, 5.0 + 5.3 ms at 512^3), with ~100 times fewer
+// atomics and no pointer chasing outside the heads.  All three kernels use the same voxel <-> lane mapping.
+__global__ void __launch_bounds__(256) ccl_init_kernel(const double* __restrict__ sdf, uint32_t n, int nx, double thr, uint32_t* __restrict__ L)
 {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < n) L[v] = (sdf[v] >= thr) ? v : NOLABEL;
+    const int lane = threadIdx.x & 63;
+    const bool in = v < n && sdf[v] >= thr;
+    const unsigned long long m_in = __ballot(in);
+    const bool prev = lane > 0 && ((m_in >> (lane - 1)) & 1ull);
+    const bool head = in && (lane == 0 || v % (uint32_t)nx == 0u || !prev);
+    const unsigned long long m_head = __ballot(head);
+    if (v < n) {
+        const unsigned long long below = m_head & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));   // heads at or below this lane
+        L[v] = in ? v - (uint32_t)lane + (uint32_t)(63 - __clzll((long long)below)) : NOLABEL;
+    }
 }
 
-__global__ void ccl_union_kernel(uint32_t* __restrict__ L, int nx, int ny, int nz)
+__global__ void __launch_bounds__(256) ccl_union_kernel(uint32_t* __restrict__ L, int nx, int ny, int nz)
 {
     const uint32_t n = (uint32_t)nx * ny * nz;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    if (uf_load(L, v) == NOLABEL) return;
-    const int i = v % nx, j = (v / nx) % ny, k = v / ((uint32_t)nx * ny);
-    if (i + 1 < nx && uf_load(L, v + 1) != NOLABEL) uf_union(L, v, v + 1);
-    if (j + 1 < ny && uf_load(L, v + nx) != NOLABEL) uf_union(L, v, v + nx);
-    if (k + 1 < nz && uf_load(L, v + (uint32_t)nx * ny) != NOLABEL) uf_union(L, v, v + (uint32_t)nx * ny);
+    // (whether a voxel is labelled never changes; the labels of heads do: those are read inside uf_union only)
+    if (L[v] == NOLABEL) return;
+    const uint32_t plane = (uint32_t)nx * ny;
+    const int i = v % nx, j = (v / nx) % ny, k = v / plane;
+    const bool left = i > 0 && L[v - 1] != NOLABEL;
+    if (left && (threadIdx.x & 63) == 0) uf_union(L, v, v - 1);   // a piece that continues the run of the previous wavefront
+    if (j + 1 < ny && L[v + nx] != NOLABEL && (!left || L[v + nx - 1] == NOLABEL)) uf_union(L, v, v + nx);
+    if (k + 1 < nz && L[v + plane] != NOLABEL && (!left || L[v + plane - 1] == NOLABEL)) uf_union(L, v, v + plane);
 }
 
-__global__ void ccl_flatten_count_kernel(const uint32_t* __restrict__ L, uint32_t n, uint32_t* __restrict__ root,
-                                         uint32_t* __restrict__ size)
+__global__ void __launch_bounds__(256) ccl_compress_heads_kernel(uint32_t* __restrict__ L, uint32_t n, int nx)
 {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t r = (v < n) ? L[v] : NOLABEL;
-    if (r != NOLABEL)
-        while (L[r] != r) r = L[r];
-    if (v < n) root[v] = r;
-    // most lanes of a wavefront share a root (one big component): one atomic per distinct root and wave
-    bool pending = r != NOLABEL;
-    const int lane = threadIdx.x & 63;
-    while (__any(pending)) {
-        const unsigned long long todo = __ballot(pending);
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t lr = __shfl(r, leader, 64);
-        const unsigned long long same = __ballot(pending && r == lr);
-        if (lane == leader) atomicAdd(&size[lr], (uint32_t)__popcll(same));
-        if (r == lr) pending = false;
+    if (v >= n) return;
+    if (L[v] == NOLABEL) return;
+    const bool head = (threadIdx.x & 63) == 0 || v % (uint32_t)nx == 0u || L[v - 1] == NOLABEL;
+    if (head) {
+        const uint32_t r = uf_find(L, v);
+        if (r != v) __hip_atomic_store(L + v, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an ancestor: walks through v stay valid)
     }
+}
+
+__global__ void __launch_bounds__(256) ccl_flatten_count_kernel(const uint32_t* __restrict__ L, uint32_t n, uint32_t* __restrict__ root,
+                                                               uint32_t* __restrict__ size)
+{
+    // (after ccl_compress_heads_kernel: L[v] = head of the voxel's run piece, L[head] = root; the loop ends at once)
+    // Sizes: a fixed grid strides over the voxels and every wavefront keeps a running (root, count) pair that it only
+    // flushes when the root changes - a few thousand same-address atomics instead of one per wavefront of the DATA
+    // (420 k on the one big component at 512^3: 5 ms).
+    const int lane = threadIdx.x & 63;
+    uint32_t cur = NOLABEL, cnt = 0;   // wave-uniform
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint64_t v = base + threadIdx.x;
+        uint32_t r = (v < n) ? L[v] : NOLABEL;
+        if (r != NOLABEL)
+            while (L[r] != r) r = L[r];
+        if (v < n) root[v] = r;
+        bool pending = r != NOLABEL;
+        while (__any(pending)) {
+            const unsigned long long todo = __ballot(pending);
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lr = __shfl(r, leader, 64);
+            const unsigned long long same = __ballot(pending && r == lr);
+            const uint32_t c = (uint32_t)__popcll(same);
+            if (lr == cur) {
+                cnt += c;
+            } else {
+                if (cnt && lane == 0) atomicAdd(&size[cur], cnt);
+                cur = lr;
+                cnt = c;
+            }
+            if (r == lr) pending = false;
+        }
+    }
+    if (cnt && lane == 0) atomicAdd(&size[cur], cnt);
 }
 
 // counters: [0] largest size, [1] smallest root having it, [2] flipped count, [3] interior count
@@ -132,9 +178,10 @@ static int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double thresho
     hipError_t e = hipMemcpyAsync(cnt.p, h, sizeof h, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(size.p, 0, sizeof(uint32_t) * (size_t)n, st);
     if (e != hipSuccess) { cleanup(); return fail(R2S_ERR_HIP, "%s", hipGetErrorString(e)); }
-    ccl_init_kernel<<<nb, 256, 0, st>>>(d_sdf, n, threshold, L.as<uint32_t>());
+    ccl_init_kernel<<<nb, 256, 0, st>>>(d_sdf, n, nx, threshold, L.as<uint32_t>());
     ccl_union_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), nx, ny, nz);
-    ccl_flatten_count_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), n, root.as<uint32_t>(), size.as<uint32_t>());
+    ccl_compress_heads_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), n, nx);
+    ccl_flatten_count_kernel<<<(nb < 4096u ? nb : 4096u), 256, 0, st>>>(L.as<uint32_t>(), n, root.as<uint32_t>(), size.as<uint32_t>());
     ccl_max_kernel<<<nb, 256, 0, st>>>(size.as<uint32_t>(), n, cnt.as<uint32_t>());
     ccl_argmax_kernel<<<nb, 256, 0, st>>>(size.as<uint32_t>(), n, cnt.as<uint32_t>());
     e = hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, st);
@@ -1749,9 +1796,10 @@ int remove_artifacts_slabs(const std::vector<Slab>& S, const r2s_grid* g, double
         uint32_t h[4] = {0, NOLABEL, 0, 0};
         SLAB_HIP(hipMemcpyAsync(cnt.at<uint32_t>(q), h, sizeof h, hipMemcpyHostToDevice, d.stream));
         SLAB_HIP(hipMemsetAsync(size.at<uint32_t>(q), 0, 4 * (size_t)n64, d.stream));
-        ccl_init_kernel<<<nb, 256, 0, d.stream>>>(sdf, nvox[q], threshold, L.at<uint32_t>(q));
+        ccl_init_kernel<<<nb, 256, 0, d.stream>>>(sdf, nvox[q], nx, threshold, L.at<uint32_t>(q));
         ccl_union_kernel<<<nb, 256, 0, d.stream>>>(L.at<uint32_t>(q), nx, ny, d.k1 - d.k0);
-        ccl_flatten_count_kernel<<<nb, 256, 0, d.stream>>>(L.at<uint32_t>(q), nvox[q], root.at<uint32_t>(q), size.at<uint32_t>(q));
+        ccl_compress_heads_kernel<<<nb, 256, 0, d.stream>>>(L.at<uint32_t>(q), nvox[q], nx);
+        ccl_flatten_count_kernel<<<(nb < 4096u ? nb : 4096u), 256, 0, d.stream>>>(L.at<uint32_t>(q), nvox[q], root.at<uint32_t>(q), size.at<uint32_t>(q));
         ccl_max_kernel<<<nb, 256, 0, d.stream>>>(size.at<uint32_t>(q), nvox[q], cnt.at<uint32_t>(q));   // [3]: interior voxels
     }
     SLAB_TRY(sync_slabs(S));
