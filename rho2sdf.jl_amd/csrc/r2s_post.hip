@@ -326,6 +326,22 @@ __global__ void __launch_bounds__(256) sum_f32_kernel(const float* __restrict__ 
 // integer division).  Full cells are summed per thread; cut cells are listed in LDS in x order and
 // then worked off one WAVEFRONT per cell (lanes split the order^3 Gauss points), so a few cut cells
 // do not stall 63 idle lanes for 729 iterations.  Every reduction has a fixed order (no float atomics).
+// The order^3 quadrature points of a cut cell as a table: {xi, 1-xi, eta, 1-eta, zeta, 1-zeta, weight, -} per point, in
+// the order the lanes of volume_rows_kernel visit them.  The values are those the kernel used to form per point and cell
+// (index decoding with three integer divisions took more instructions than the interpolation itself).
+__global__ void quad_points_kernel(QuadTab q, float jac, float* __restrict__ out)
+{
+    const int npts = q.order * q.order * q.order;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npts) return;
+    const int iq = p % q.order, jq = (p / q.order) % q.order, kq = p / (q.order * q.order);
+    const float zeta = (q.gp[kq] + 1) / 2, eta = (q.gp[jq] + 1) / 2, xi = (q.gp[iq] + 1) / 2;
+    float* o = out + (size_t)p * 8;
+    o[0] = xi; o[1] = 1.0f - xi; o[2] = eta; o[3] = 1.0f - eta; o[4] = zeta; o[5] = 1.0f - zeta;
+    o[6] = q.gw[iq] * q.gw[jq] * q.gw[kq] * jac;
+    o[7] = 0.0f;
+}
+
 // smallest / largest corner value over the cells of every 64-cell segment of every cell row: the level bisection
 // evaluates the volume of the same field at up to 40 levels, and a segment whose values all lie on one side of the
 // level needs no loads (volume_rows_kernel)
@@ -363,7 +379,8 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
                                                          float shift, float iso, float elvol, float jac,
                                                          QuadTab q, float* __restrict__ partial, int row0 = 0,
                                                          const float* __restrict__ segmn = nullptr,
-                                                         const float* __restrict__ segmx = nullptr)
+                                                         const float* __restrict__ segmx = nullptr,
+                                                         const float4* __restrict__ qpts = nullptr)
 {
     // (row0: first cell row of this launch - a Z-slab of a multi-device run works on the rows of its planes, with
     //  `sdf`, `partial` and the segment arrays addressed as the whole grid's)
@@ -388,6 +405,9 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
             return;
         }
     }
+#if defined(VOL_DIAG) && VOL_DIAG == 2   // timing-only build: only the row-level test
+    if (segs) { if (tid == 0) partial[row] = 1.0f; return; }
+#endif
     float acc = 0.0f;    // full cells (per thread)
     float wacc = 0.0f;   // cut cells (lane 0 of each wave)
     for (int i0 = 0; i0 < nx - 1; i0 += 256) {
@@ -437,12 +457,28 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
         }
         if (cls) s_cut[before + __popcll(m & ((1ull << lane) - 1ull))] = i;
         __syncthreads();
+#if defined(VOL_DIAG) && VOL_DIAG == 1   // timing-only build: without the quadrature of the cut cells
+        ncut = 0;
+#endif
         for (int c = wave; c < ncut; c += 4) {
             const int64_t b = ((int64_t)k * ny + j) * nx + s_cut[c];
             const float c000 = sdf[b] - shift, c100 = sdf[b + 1] - shift, c010 = sdf[b + sy] - shift,
                         c110 = sdf[b + sy + 1] - shift, c001 = sdf[b + sz] - shift, c101 = sdf[b + sz + 1] - shift,
                         c011 = sdf[b + sz + sy] - shift, c111 = sdf[b + sz + sy + 1] - shift;
             float part = 0.0f;
+            if (qpts) {   // (quad_points_kernel: the same numbers, looked up.  Unrolling this loop 4 / 6 / 12 times: slower)
+                for (int p = lane; p < npts; p += 64) {
+                    const float4 A = qpts[2 * p], B = qpts[2 * p + 1];   // xi, 1-xi, eta, 1-eta | zeta, 1-zeta, weight
+                    const float c00 = c000 * A.y + c100 * A.x;
+                    const float c01 = c001 * A.y + c101 * A.x;
+                    const float c10 = c010 * A.y + c110 * A.x;
+                    const float c11 = c011 * A.y + c111 * A.x;
+                    const float c0 = c00 * A.w + c10 * A.z;
+                    const float c1 = c01 * A.w + c11 * A.z;
+                    const float pv = c0 * B.y + c1 * B.x;
+                    if (pv >= iso) part += B.z;
+                }
+            } else
             for (int p = lane; p < npts; p += 64) {
                 const int iq = p % q.order, jq = (p / q.order) % q.order, kq = p / (q.order * q.order);
                 const float zeta = (q.gp[kq] + 1) / 2, eta = (q.gp[jq] + 1) / 2, xi = (q.gp[iq] + 1) / 2;
@@ -475,7 +511,8 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
 }
 
 struct VolumeWork {
-    DevBuf partial, result, segmn, segmx;
+    DevBuf partial, result, segmn, segmx, qpts;
+    float qpts_jac = -1.0f;             // the Jacobian the point table was built with
     const float* seg_field = nullptr;   // the field the segment extrema were computed for (prepare)
     QuadTab q;
     int nblocks = 2048;
@@ -488,6 +525,16 @@ struct VolumeWork {
         q.order = order;
         ENSURE(partial, sizeof(float) * (size_t)nblocks);
         ENSURE(result, 64);
+        return 0;
+    }
+    // table of the quadrature points for cells of this size (quad_points_kernel)
+    int points(float jac, hipStream_t st)
+    {
+        if (qpts.p && qpts_jac == jac) return 0;
+        const int npts = q.order * q.order * q.order;
+        ENSURE(qpts, sizeof(float) * 8 * (size_t)npts);
+        quad_points_kernel<<<(npts + 255) / 256, 256, 0, st>>>(q, jac, qpts.as<float>());
+        qpts_jac = jac;
         return 0;
     }
     // before a series of run() calls on the same field: segment extrema, so that each level only looks at the cells near it
@@ -510,14 +557,19 @@ struct VolumeWork {
         const int nrows = (ny - 1) * (nz - 1);
         ENSURE(partial, sizeof(float) * (size_t)nrows);
         const bool segs = seg_field == d_sdf && seg_field != nullptr;
+        {
+            int rc = points(jac, st);
+            if (rc) return rc;
+        }
         volume_rows_kernel<<<nrows, 256, 0, st>>>(d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>(), 0,
-                                                 segs ? segmn.as<float>() : nullptr, segs ? segmx.as<float>() : nullptr);
+                                                 segs ? segmn.as<float>() : nullptr, segs ? segmx.as<float>() : nullptr,
+                                                 qpts.as<float4>());
         sum_f32_kernel<<<1, 256, 0, st>>>(partial.as<float>(), nrows, result.as<float>());
         HIP_TRY(hipMemcpyAsync(out, result.p, sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         return 0;
     }
-    void release() { partial.release(); result.release(); segmn.release(); segmx.release(); seg_field = nullptr; }
+    void release() { partial.release(); result.release(); segmn.release(); segmx.release(); qpts.release(); seg_field = nullptr; qpts_jac = -1.0f; }
 };
 
 // ====================================================================================
@@ -2268,6 +2320,10 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         }
         const float edge = std::sqrt((cx[1] - cx[0]) * (cx[1] - cx[0]));
         const float elvol = edge * edge * edge, jac = elvol / 8.0f;
+        for (size_t q : order) {
+            SLAB_HIP(hipSetDevice(S[q].device));
+            SLAB_TRY(vw[q].points(jac, S[q].stream));
+        }
         double eps = 1.0;
         int it = 0;
         while (it < 40 && eps > 1.0e-4) {
@@ -2279,7 +2335,7 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
                 const int row0 = d.k0 * (ny - 1), nr = (kc1 - d.k0) * (ny - 1);
                 SLAB_HIP(hipSetDevice(d.device));
                 volume_rows_kernel<<<nr, 256, 0, d.stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, th, 0.0f, elvol, jac, vw[q].q,
-                                                            brows.at<float>(q), row0, bsegmn.at<float>(q), bsegmx.at<float>(q));
+                                                            brows.at<float>(q), row0, bsegmn.at<float>(q), bsegmx.at<float>(q), vw[q].qpts.as<float4>());
                 if (q != q0)
                     SLAB_HIP(hipMemcpyPeerAsync(brows.at<float>(q0) + row0, S[q0].device, brows.at<float>(q) + row0, d.device,
                                                 sizeof(float) * (size_t)nr, d.stream));
