@@ -186,6 +186,28 @@ def test_rbf_matvec_variants_are_bit_identical(pkg, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("threshold", [1e-2, 0.1])
+def test_rbf_tables_other_kernel_thresholds(pkg, oracle, monkeypatch, threshold):
+    """other supports (threshold 1e-2: radius 2 with fewer neighbours; 0.1: radius 1) run the generic instantiations of
+    the table kernels: CG with table / on the fly products and table / neighbour-by-neighbour evaluation must agree bit
+    for bit there too"""
+    X, IEN, rho, og, sdf = _raw_sdf(oracle, "beam_vfrac_04", 0.518555)
+    oracle.remove_artifacts(sdf, og)
+    vd, vf = oracle.mesh_volume(X, IEN, rho)
+    pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
+    outs = {}
+    for mode in ("lut", "fly"):
+        monkeypatch.setenv("R2S_RBF_MATVEC", mode)
+        monkeypatch.setenv("R2S_RBF_APPLY", mode)
+        info = {}
+        outs[mode] = (pkg.RBFs_smoothing(sdf, pg, True, 1, vd * vf, threshold, info=info), info["cg_iterations"], info["th"], info["lsf"])
+    assert outs["fly"][1] == outs["lut"][1] and outs["fly"][2] == outs["lut"][2]
+    assert np.array_equal(outs["fly"][0], outs["lut"][0]) and np.array_equal(outs["fly"][3], outs["lut"][3])
+    assert np.isfinite(outs["lut"][0]).all() and outs["lut"][1] > 0
+    pkg._lib.lib().r2s_release_cache()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("interp", [False, True])
 def test_rbf_evaluation_table_is_bit_identical(pkg, oracle, monkeypatch, interp):
     """same-grid evaluation (the LSF of the level bisection and the output field at smooth = 1) through the table of
