@@ -43,8 +43,8 @@ __constant__ int c_hex_isn[6][4] = {{0, 3, 2, 1}, {0, 1, 5, 4}, {1, 2, 6, 5},
 // ------------------------------------------------------------------------------------
 // exclusive scan of uint32 (block = 1024 threads x 4 items)
 // ------------------------------------------------------------------------------------
-#define SCAN_BLOCK 1024
-#define SCAN_ITEMS 4
+#define SCAN_BLOCK 256   // (4 wavefronts: a 1024-thread workgroup needs 4 free wave slots with registers on EVERY SIMD of
+#define SCAN_ITEMS 16    //  one CU at once and waited 2.8 ms for them beside the persistent projection kernel)
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
 
 // up to two arrays of the same length per launch (blockIdx.y picks the array): the pipeline's count arrays
@@ -1384,18 +1384,19 @@ __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __res
                                                            uint32_t* __restrict__ active_tri,
                                                            uint32_t* __restrict__ counters)
 {
-    // block-aggregated append: the three lists are collected in LDS (wave-aggregated LDS atomics), then ONE
-    // global atomic per block and list reserves the output range (2.1 M tiles used to mean ~100 k same-address
-    // atomics = 0.49 ms)
-    __shared__ uint32_t s_cnt[6], s_base[6], s_max[2];
-    __shared__ uint32_t s_list[6][256 * AT_ITEMS];
-    if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0;
+    // block-aggregated append: every wavefront counts its members of the six lists per pass (ballots), one thread per
+    // list turns the 4 x AT_ITEMS counts into offsets and reserves the block's output range with ONE global atomic per
+    // list (2.1 M tiles used to mean ~100 k same-address atomics = 0.49 ms), then the members are written straight to
+    // their places.  (Round 1 staged the lists in 48 KB of LDS: beside the persistent projection kernel, whose one-wave
+    // workgroups fragment the LDS, such a workgroup waited 2.6 ms for a contiguous piece.)
+    __shared__ uint32_t s_cnt[6][AT_ITEMS][4], s_base[6], s_max[2];
     if (threadIdx.x < 2) s_max[threadIdx.x] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t t0 = blockIdx.x * (256u * AT_ITEMS);
     uint32_t mxb = 0, mxs = 0;
+    uint32_t flags[AT_ITEMS];
+#pragma unroll
     for (int i = 0; i < AT_ITEMS; ++i) {
         const uint32_t t = t0 + (uint32_t)i * 256u + threadIdx.x;
         const bool in = t < ntiles;
@@ -1406,36 +1407,48 @@ __global__ void __launch_bounds__(256) active_tiles_kernel(const uint32_t* __res
         // [4] / [5]: band tiles without / with boundary triangles (lean / full gather kernel)
         const bool ft = f[0] && tri[t] != 0;
         const bool fl[6] = {f[0], f[1], f[0] || f[1], f[1] && !f[0], f[0] && !ft, ft};
+        uint32_t fb = 0;
 #pragma unroll
         for (int l = 0; l < 6; ++l) {
             const unsigned long long m = __ballot(fl[l]);
-            if (m) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&s_cnt[l], (uint32_t)__popcll(m));
-                base = __shfl(base, 0, 64);
-                if (fl[l]) s_list[l][base + __popcll(m & below)] = t;
-            }
+            if (lane == 0) s_cnt[l][i][wave] = (uint32_t)__popcll(m);
+            fb |= fl[l] ? (1u << l) : 0u;
         }
+        flags[i] = fb;
         if (fl[0] && bc > mxb) mxb = bc;
         if (fl[1] && sc > mxs) mxs = sc;
     }
+    __syncthreads();
     // longest lists (decides whether the wave-per-tile sort has to run at all)
     if (mxb > 64u) atomicMax(&s_max[0], mxb);
     if (mxs > 64u) atomicMax(&s_max[1], mxs);
-    __syncthreads();
     if (threadIdx.x < 6) {
         const int idx[6] = {1, 2, 5, 6, 10, 11};
-        const uint32_t n = s_cnt[threadIdx.x];
+        uint32_t n = 0;
+        for (int i = 0; i < AT_ITEMS; ++i)
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t c = s_cnt[threadIdx.x][i][w];
+                s_cnt[threadIdx.x][i][w] = n;   // count -> offset inside the block's range
+                n += c;
+            }
         s_base[threadIdx.x] = n ? atomicAdd(&counters[idx[threadIdx.x]], n) : 0u;
-    } else if (threadIdx.x < 8) {
+    }
+    __syncthreads();
+    if (threadIdx.x >= 6 && threadIdx.x < 8) {
         const uint32_t v = s_max[threadIdx.x - 6];
         if (v > 64u) atomicMax(&counters[threadIdx.x - 3], v);
     }
-    __syncthreads();
     uint32_t* const out[6] = {active_band, active_sign, active_any, active_sonly, active_lean, active_tri};
 #pragma unroll
-    for (int l = 0; l < 6; ++l)
-        for (uint32_t j = threadIdx.x; j < s_cnt[l]; j += 256u) out[l][s_base[l] + j] = s_list[l][j];
+    for (int i = 0; i < AT_ITEMS; ++i) {
+        const uint32_t t = t0 + (uint32_t)i * 256u + threadIdx.x;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            const bool f = (flags[i] >> l) & 1u;
+            const unsigned long long m = __ballot(f);
+            if (f) out[l][s_base[l] + s_cnt[l][i][wave] + (uint32_t)__popcll(m & below)] = t;
+        }
+    }
 }
 
 // short lists (<= 64 entries): SORT_LANES lanes per active tile, rank sort (every lane ranks every SORT_LANES-th
@@ -1885,7 +1898,7 @@ struct r2s_plan {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // second stream: sentinel sweep + sign pass run beside the iso-surface projection (fused SDF output)
     hipStream_t st2 = nullptr;
-    hipEvent_t ev2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev2[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 // exclusive scans of one or two (in1 != nullptr) arrays of n entries each
@@ -2021,7 +2034,7 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 128, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostGetDevicePointer((void**)&P->d_pinned, P->h_pinned, 0));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
-    for (int i = 0; i < 6; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
+    for (int i = 0; i < 7; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
     {
         // high priority: the short stages of the second stream (sentinel sweep, inverse maps of the sign pass,
         // sign-only gather) get wave slots ahead of the long persistent projection kernel.  Measured on the
@@ -2049,7 +2062,7 @@ void r2s_plan_destroy(r2s_plan* P)
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
     for (int i = 0; i < 8; ++i)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
         if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
     if (P->st2) (void)hipStreamDestroy(P->st2);
     delete P;
@@ -2230,22 +2243,59 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     }
     HIP_TRY(hipEventRecord(P->ev[1], st));
 
+    // ---- HEX8, speculated sizes: the projection kernel starts NOW, beside the binning ----
+    // It only needs the work items; the tile lists (0.27 ms of ~25 short, latency-bound kernels that leave the GPU almost
+    // idle) are for the inverse maps and the gathers.  With the sizes of the previous call at hand nothing has to wait for
+    // a read-back: the chunk / storage totals are compared on the device first (abort flag, as for every speculated size),
+    // the projection kernel is launched with 2 wavefronts per SIMD (336 of 512 VGPRs: the short kernels, the sweep and
+    // sign_project find room beside it; 3 per SIMD would lock them out for 3 ms), and the binning moves to the second
+    // stream, in front of the sweep.  R2S_NO_EARLY_ISO=1: the old order.
+    static const bool overlap_env0 = !(getenv("R2S_NO_OVERLAP") && atoi(getenv("R2S_NO_OVERLAP")));
+    static const bool early_env = !(getenv("R2S_NO_EARLY_ISO") && atoi(getenv("R2S_NO_EARLY_ISO")));
+    bool early_iso = false;
+    if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
+        early_iso = spec && early_env && overlap_env0 && want_sign && want_dist && nel > 0 && n_items && cnt[10] && cnt[11] && !(mode & R2S_OUT_XP);
+        if (early_iso) {
+            ReadBack rbA;
+            rbA.add(P->chunk_off.as<uint32_t>() + n_items, 1, 10);
+            rbA.add(P->store_off.as<uint32_t>() + n_items, 1, 12);
+            read_back_kernel<<<1, 64, 0, st>>>(rbA, P->d_pinned, ex, counters + 15);
+            HIP_TRY(hipEventRecord(P->ev2[6], st));   // work items complete: the binning (second stream) may start
+            const uint32_t n_chunks_e = cnt[10], n_store_e = cnt[12];
+            ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_store_e, 1));
+            static const int wps_env = getenv("R2S_ISO_WPS") ? atoi(getenv("R2S_ISO_WPS")) : 0;   // tuning knob
+            const uint32_t wps = (wps_env >= 1 && wps_env <= 3) ? (uint32_t)wps_env : 2u;
+            const uint32_t resident = (uint32_t)P->n_cu * 4u * wps;
+            const uint32_t group = std::min(4u, std::max(1u, n_chunks_e / (resident * 12u)));
+            const uint32_t ngroups = (n_chunks_e + group - 1) / group;
+            HIP_TRY(hipEventRecord(P->ev[7], st));
+            iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
+                P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks_e, group, P->erec.as<ElemRec>(), g,
+                s, rho_t, P->iso_res.as<double>(), nullptr, counters + 8, P->perm.as<uint32_t>(), abort_flag);
+            HIP_TRY(hipEventRecord(P->ev[6], st));
+            HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[6], 0));
+            // (the sentinel sweep on a third stream right here, beside the binning: its wavefronts delay the first short
+            //  kernels by what it saves later - 4.24 vs 4.20 ms; it stays behind the binning on the second stream)
+        }
+    }
+    hipStream_t bs = early_iso ? P->st2 : st;   // stream of the binning
+
     // ---- tile bins ----
     // (TET4 sign lists leave out the elements that cannot reach rho_t, see sign_bin_kernel; 1e-12: the rounding of
     // the interpolated density, 8 eps, with room to spare)
     const double rmax_needed = std::is_same<typename ET::Rec, ElemRec>::value ? -INFINITY : rho_t - 1e-12 * (fabs(rho_t) + 1.0);
-    zero_many(st, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)},
+    zero_many(bs, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)},
                    {P->hot.p, (size_t)ntiles + 1}, {P->tri.p, (size_t)ntiles + 1}});
     if (n_items)
-        band_bin_kernel<false><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr, P->tri.as<uint8_t>(), abort_flag);
+        band_bin_kernel<false><<<(n_items * BIN_LANES + 127) / 128, 128, 0, bs>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr, P->tri.as<uint8_t>(), abort_flag);
     if (want_sign)
     {
-        sign_hot_kernel<typename ET::Rec><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
-        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>(), abort_flag, rmax_needed);
+        sign_hot_kernel<typename ET::Rec><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, bs>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
+        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, bs>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>(), abort_flag, rmax_needed);
     }
     {
         int rc = scan_exclusive2(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->sign_cnt.as<uint32_t>(),
-                                 P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, st);
+                                 P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, bs);
         if (rc) return rc;
     }
     constexpr bool HEX = std::is_same<typename ET::Rec, ElemRec>::value;
@@ -2258,23 +2308,23 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             ENSURE(P->s_chunk_off, sizeof(uint32_t) * (size_t)(nel + 1));
             ENSURE(P->s_nstore, sizeof(uint32_t) * (size_t)(nel + 1));
             ENSURE(P->s_store_off, sizeof(uint32_t) * (size_t)(nel + 1));
-            zero_many(st, {{P->s_nchunks.p, sizeof(uint32_t) * (size_t)(nel + 1)}, {P->s_nstore.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
-            sign_box_kernel<<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>(), P->s_nstore.as<uint32_t>());
+            zero_many(bs, {{P->s_nchunks.p, sizeof(uint32_t) * (size_t)(nel + 1)}, {P->s_nstore.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
+            sign_box_kernel<<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, bs>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>(), P->s_nstore.as<uint32_t>());
             int rc = scan_exclusive2(P, P->s_nchunks.as<uint32_t>(), P->s_chunk_off.as<uint32_t>(), P->s_nstore.as<uint32_t>(),
-                                     P->s_store_off.as<uint32_t>(), nel + 1, st);
+                                     P->s_store_off.as<uint32_t>(), nel + 1, bs);
             if (rc) return rc;
             rb2.add(P->s_chunk_off.as<uint32_t>() + nel, 1, 11);
             rb2.add(P->s_store_off.as<uint32_t>() + nel, 1, 13);
         }
     }
-    active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, st>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), P->active_sonly.as<uint32_t>(), P->tri.as<uint8_t>(), P->active_lean.as<uint32_t>(), P->active_tri.as<uint32_t>(), counters);
+    active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, bs>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), P->active_sonly.as<uint32_t>(), P->tri.as<uint8_t>(), P->active_lean.as<uint32_t>(), P->active_tri.as<uint32_t>(), counters);
     rb2.add(P->band_off.as<uint32_t>() + ntiles, 1, 2);
     rb2.add(P->sign_off.as<uint32_t>() + ntiles, 1, 3);
     rb2.add(counters + 1, 6, 4);
     rb2.add(counters + 10, 2, 14);
-    read_back_kernel<<<1, 64, 0, st>>>(rb2, P->d_pinned, ex, counters + 15);
+    read_back_kernel<<<1, 64, 0, bs>>>(rb2, P->d_pinned, ex, counters + 15);
     if (!spec) {
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamSynchronize(bs));
         for (int q = 2; q < 16; ++q) cnt[q] = P->h_pinned[q];
     }
     const uint32_t n_band = cnt[2], n_sign = cnt[3], n_active = cnt[4], n_active_sign = cnt[5];
@@ -2290,25 +2340,25 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->band_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_band, 1));
     ENSURE(P->sign_raw, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_sign, 1));
     ENSURE(P->sign_ent, sizeof(uint32_t) * (size_t)std::max<uint32_t>(n_sign, 1));
-    zero_many(st, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}});
+    zero_many(bs, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}});
     if (n_items)
-        band_bin_kernel<true><<<(n_items * BIN_LANES + 127) / 128, 128, 0, st>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), nullptr, abort_flag);
+        band_bin_kernel<true><<<(n_items * BIN_LANES + 127) / 128, 128, 0, bs>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), nullptr, abort_flag);
     if (want_sign)
-        sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, st>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), HEX ? P->sign_raw.as<uint32_t>() : P->sign_ent.as<uint32_t>(), P->hot.as<uint8_t>(), abort_flag, rmax_needed);
+        sign_bin_kernel<typename ET::Rec, true><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, bs>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), HEX ? P->sign_raw.as<uint32_t>() : P->sign_ent.as<uint32_t>(), P->hot.as<uint8_t>(), abort_flag, rmax_needed);
     // (TET4: a voxel is +1 when ANY candidate holds it with rho >= rho_t - "the first one" of SignDetection.jl:128-147
     // only ends the search - so the order of a list does not matter and the lists are used as filled)
     // lists longer than 64 entries only occur when the grid is coarse relative to the mesh (few tiles)
     if (n_active) {
-        bin_sort_small_kernel<<<(n_active * SORT_LANES + 255) / 256, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>(), abort_flag);
+        bin_sort_small_kernel<<<(n_active * SORT_LANES + 255) / 256, 256, 0, bs>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>(), abort_flag);
         if (cnt[6] > 64u)
-            bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, st>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>(), abort_flag);
+            bin_sort_kernel<<<(n_active + 3) / 4, 256, 0, bs>>>(P->active.as<uint32_t>(), n_active, P->band_off.as<uint32_t>(), P->band_raw.as<uint32_t>(), P->band_ent.as<uint32_t>(), abort_flag);
     }
     if (n_active_sign && HEX) {
-        bin_sort_small_kernel<<<(n_active_sign * SORT_LANES + 255) / 256, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>(), abort_flag);
+        bin_sort_small_kernel<<<(n_active_sign * SORT_LANES + 255) / 256, 256, 0, bs>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>(), abort_flag);
         if (cnt[7] > 64u)
-            bin_sort_kernel<<<(n_active_sign + 3) / 4, 256, 0, st>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>(), abort_flag);
+            bin_sort_kernel<<<(n_active_sign + 3) / 4, 256, 0, bs>>>(P->active_sign.as<uint32_t>(), n_active_sign, P->sign_off.as<uint32_t>(), P->sign_raw.as<uint32_t>(), P->sign_ent.as<uint32_t>(), abort_flag);
     }
-    HIP_TRY(hipEventRecord(P->ev[2], st));
+    HIP_TRY(hipEventRecord(P->ev[2], bs));
 
     // ---- fork ----
     // HEX8, distance + sign wanted: the inverse maps of the sign pass (and the sign-only gather) run on a
@@ -2382,8 +2432,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             HIP_TRY(hipEventRecord(P->ev2[2], ss));
             A.iso_res = P->iso_res.as<double>();
             A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
-            HIP_TRY(hipEventRecord(P->ev[7], st));
-            if (want_dist && n_chunks) {
+            if (!early_iso) HIP_TRY(hipEventRecord(P->ev[7], st));
+            if (want_dist && n_chunks && !early_iso) {
                 static const int wps_env = getenv("R2S_ISO_WPS") ? atoi(getenv("R2S_ISO_WPS")) : 0;   // tuning knob
                 const uint32_t wps = (wps_env >= 1 && wps_env <= 3) ? (uint32_t)wps_env : 3u;
                 static const int free_env = getenv("R2S_ISO_FREE") ? atoi(getenv("R2S_ISO_FREE")) : 0;   // tuning knob: wave slots left to the second stream
@@ -2403,7 +2453,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                     s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, counters + 8,
                     P->perm.as<uint32_t>(), abort_flag);
             }
-            HIP_TRY(hipEventRecord(P->ev[6], st));
+            if (!early_iso) HIP_TRY(hipEventRecord(P->ev[6], st));
             if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[4], 0));   // (the sweep precedes it on that stream)
             // ordered per-voxel gather: band items (distance) and candidate elements (sign) of every tile
             if (want_dist && want_sign && early_sign_tiles) {
