@@ -1878,7 +1878,7 @@ struct r2s_plan {
     int n_cu = 256;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
-    DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], nchunks, chunk_off, iso_res, iso_res_xp;
+    DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], scan_tmp2[3], nchunks, chunk_off, iso_res, iso_res_xp;
     DevBuf perm, wchunks, hardflag;   // work order of the persistent projection kernel (HEX8)
     DevBuf sbox, s_nchunks, s_chunk_off, sres;   // item-major inverse maps of the sign pass (HEX8)
     DevBuf nstore, store_off, s_nstore, s_store_off;   // storage (tile) chunk counts / offsets
@@ -1898,13 +1898,15 @@ struct r2s_plan {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // second stream: sentinel sweep + sign pass run beside the iso-surface projection (fused SDF output)
     hipStream_t st2 = nullptr;
-    hipEvent_t ev2[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev2[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 // exclusive scans of one or two (in1 != nullptr) arrays of n entries each
+// (bank 1: the workspace of scans that run on the second stream beside scans of the first)
 static int scan_exclusive2(r2s_plan* P, const uint32_t* in0, uint32_t* out0, const uint32_t* in1, uint32_t* out1,
-                           int64_t n, hipStream_t st, int level = 0)
+                           int64_t n, hipStream_t st, int level = 0, int bank = 0)
 {
+    DevBuf* tmp = bank ? P->scan_tmp2 : P->scan_tmp;
     if (n <= 0) return 0;
     const unsigned ny = in1 ? 2u : 1u;
     const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -1916,12 +1918,12 @@ static int scan_exclusive2(r2s_plan* P, const uint32_t* in0, uint32_t* out0, con
         return 0;
     }
     if (level >= 3) return fail(R2S_ERR_ARG, "scan too large");
-    if (P->scan_tmp[level].ensure(sizeof(uint32_t) * 2 * (size_t)nb)) return fail(R2S_ERR_NOMEM, "scan workspace");
-    sp.sums[0] = P->scan_tmp[level].as<uint32_t>();
+    if (tmp[level].ensure(sizeof(uint32_t) * 2 * (size_t)nb)) return fail(R2S_ERR_NOMEM, "scan workspace");
+    sp.sums[0] = tmp[level].as<uint32_t>();
     sp.sums[1] = sp.sums[0] + nb;
     scan_block_kernel<<<dim3((unsigned)nb, ny), SCAN_BLOCK, 0, st>>>(sp, n);
     int rc = scan_exclusive2(P, sp.sums[0], sp.sums[0], in1 ? sp.sums[1] : nullptr, in1 ? sp.sums[1] : nullptr, nb, st,
-                             level + 1);
+                             level + 1, bank);
     if (rc) return rc;
     scan_add_kernel<<<dim3((unsigned)nb, ny), SCAN_BLOCK, 0, st>>>(sp, n);
     return 0;
@@ -2034,7 +2036,7 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     HIP_TRY(hipHostMalloc((void**)&P->h_pinned, 128, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostGetDevicePointer((void**)&P->d_pinned, P->h_pinned, 0));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
-    for (int i = 0; i < 7; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
+    for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
     {
         // high priority: the short stages of the second stream (sentinel sweep, inverse maps of the sign pass,
         // sign-only gather) get wave slots ahead of the long persistent projection kernel.  Measured on the
@@ -2057,12 +2059,12 @@ void r2s_plan_destroy(r2s_plan* P)
                      &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any, &P->active_sonly, &P->active_lean, &P->active_tri, &P->tri,
                      &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp,
                      &P->perm, &P->wchunks, &P->hardflag, &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres, &P->nstore, &P->store_off, &P->s_nstore, &P->s_store_off,
-                     &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2]};
+                     &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2], &P->scan_tmp2[0], &P->scan_tmp2[1], &P->scan_tmp2[2]};
     for (DevBuf* b : all) b->release();
     if (P->h_pinned) (void)hipHostFree(P->h_pinned);
     for (int i = 0; i < 8; ++i)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
-    for (int i = 0; i < 7; ++i)
+    for (int i = 0; i < 8; ++i)
         if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
     if (P->st2) (void)hipStreamDestroy(P->st2);
     delete P;
@@ -2192,6 +2194,38 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         hex_planes_kernel<<<(unsigned)((nel * 6 + 255) / 256), 256, 0, P->st2>>>(P->erec.as<ElemRec>(), nel);
         HIP_TRY(hipEventRecord(P->ev2[5], P->st2));   // from here on: "planes done"
     }
+    // HEX8 sign pass: which tiles are hot, how long their candidate lists get and the boxes of the inverse maps depend on
+    // the element records only - counted here on the second stream, beside the boundary-face test and the work items of
+    // the first, instead of in the binning phase (0.12 ms off the chain fill -> inverse maps -> gathers)
+    constexpr bool HEX = std::is_same<typename ET::Rec, ElemRec>::value;
+    const double rmax_needed = HEX ? -INFINITY : rho_t - 1e-12 * (fabs(rho_t) + 1.0);   // (TET4: see sign_bin_kernel)
+    const bool sign_items = HEX && want_sign && nel > 0;
+    ReadBack rb2;   // second read-back point (after the count passes)
+    // (host order matters: ~7 us per launch.  Issued after the first launches of the first stream's chain instead, these
+    //  delay item_build and with it the projection kernel: 4.25 instead of 4.13 ms)
+    if constexpr (HEX) {
+        if (sign_items) {
+            zero_many(P->st2, {{P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->hot.p, (size_t)ntiles + 1}});
+            sign_hot_kernel<ElemRec><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, P->st2>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
+            sign_bin_kernel<ElemRec, false><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, P->st2>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>(), abort_flag, rmax_needed);
+            int rc = scan_exclusive2(P, P->sign_cnt.as<uint32_t>(), P->sign_off.as<uint32_t>(), nullptr, nullptr, (int64_t)ntiles + 1, P->st2, 0, 1);
+            if (rc) return rc;
+            // boxes of the elements that can be candidates in a hot tile (hot[] is complete after the count pass)
+            ENSURE(P->sbox, sizeof(SignBox) * (size_t)nel);
+            ENSURE(P->s_nchunks, sizeof(uint32_t) * (size_t)(nel + 1));
+            ENSURE(P->s_chunk_off, sizeof(uint32_t) * (size_t)(nel + 1));
+            ENSURE(P->s_nstore, sizeof(uint32_t) * (size_t)(nel + 1));
+            ENSURE(P->s_store_off, sizeof(uint32_t) * (size_t)(nel + 1));
+            zero_many(P->st2, {{P->s_nchunks.p, sizeof(uint32_t) * (size_t)(nel + 1)}, {P->s_nstore.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
+            sign_box_kernel<<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, P->st2>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>(), P->s_nstore.as<uint32_t>());
+            rc = scan_exclusive2(P, P->s_nchunks.as<uint32_t>(), P->s_chunk_off.as<uint32_t>(), P->s_nstore.as<uint32_t>(),
+                                 P->s_store_off.as<uint32_t>(), nel + 1, P->st2, 0, 1);
+            if (rc) return rc;
+            rb2.add(P->s_chunk_off.as<uint32_t>() + nel, 1, 11);
+            rb2.add(P->s_store_off.as<uint32_t>() + nel, 1, 13);
+            HIP_TRY(hipEventRecord(P->ev2[7], P->st2));   // sign counts, offsets and boxes complete
+        }
+    }
     HIP_TRY(hipStreamWaitEvent(st, P->ev2[1], 0));
     face_mask_kernel<ET><<<(unsigned)((nel * ET::NES + 255) / 256), 256, 0, st>>>(
         dIEN, nel, P->ine_ptr.as<uint32_t>(), P->ine.as<uint32_t>(), P->cls.as<uint8_t>(), P->fmask.as<uint32_t>(),
@@ -2218,7 +2252,6 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->chunk_off, sizeof(uint32_t) * (size_t)(n_items + 1));
     ENSURE(P->nstore, sizeof(uint32_t) * (size_t)(n_items + 1));
     ENSURE(P->store_off, sizeof(uint32_t) * (size_t)(n_items + 1));
-    ReadBack rb2;   // second read-back point (after the count passes)
     if (n_items) {
         ENSURE(P->hardflag, (size_t)n_items + 1);
         zero_many(st, {{P->nchunks.p, sizeof(uint32_t) * (size_t)(n_items + 1)}, {P->nstore.p, sizeof(uint32_t) * (size_t)(n_items + 1)},
@@ -2281,41 +2314,26 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     hipStream_t bs = early_iso ? P->st2 : st;   // stream of the binning
 
     // ---- tile bins ----
-    // (TET4 sign lists leave out the elements that cannot reach rho_t, see sign_bin_kernel; 1e-12: the rounding of
-    // the interpolated density, 8 eps, with room to spare)
-    const double rmax_needed = std::is_same<typename ET::Rec, ElemRec>::value ? -INFINITY : rho_t - 1e-12 * (fabs(rho_t) + 1.0);
-    zero_many(bs, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)},
-                   {P->hot.p, (size_t)ntiles + 1}, {P->tri.p, (size_t)ntiles + 1}});
-    if (n_items)
-        band_bin_kernel<false><<<(n_items * BIN_LANES + 127) / 128, 128, 0, bs>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr, P->tri.as<uint8_t>(), abort_flag);
-    if (want_sign)
-    {
-        sign_hot_kernel<typename ET::Rec><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, bs>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
-        sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, bs>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>(), abort_flag, rmax_needed);
-    }
-    {
+    if (sign_items) {   // (HEX8: the sign counts are on their way on the second stream, see above)
+        zero_many(bs, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->tri.p, (size_t)ntiles + 1}});
+        if (n_items)
+            band_bin_kernel<false><<<(n_items * BIN_LANES + 127) / 128, 128, 0, bs>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr, P->tri.as<uint8_t>(), abort_flag);
+        int rc = scan_exclusive2(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), nullptr, nullptr, (int64_t)ntiles + 1, bs);
+        if (rc) return rc;
+        HIP_TRY(hipStreamWaitEvent(bs, P->ev2[7], 0));
+    } else {
+        zero_many(bs, {{P->band_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)}, {P->sign_cnt.p, sizeof(uint32_t) * (size_t)(ntiles + 1)},
+                       {P->hot.p, (size_t)ntiles + 1}, {P->tri.p, (size_t)ntiles + 1}});
+        if (n_items)
+            band_bin_kernel<false><<<(n_items * BIN_LANES + 127) / 128, 128, 0, bs>>>(P->items.as<BandItem>(), n_items, g, s, P->band_cnt.as<uint32_t>(), nullptr, nullptr, P->tri.as<uint8_t>(), abort_flag);
+        if (want_sign)
+        {
+            sign_hot_kernel<typename ET::Rec><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, bs>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, rho_t, P->hot.as<uint8_t>());
+            sign_bin_kernel<typename ET::Rec, false><<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, bs>>>(P->erec.as<typename ET::Rec>(), (uint32_t)nel, g, s, P->sign_cnt.as<uint32_t>(), nullptr, nullptr, P->hot.as<uint8_t>(), abort_flag, rmax_needed);
+        }
         int rc = scan_exclusive2(P, P->band_cnt.as<uint32_t>(), P->band_off.as<uint32_t>(), P->sign_cnt.as<uint32_t>(),
                                  P->sign_off.as<uint32_t>(), (int64_t)ntiles + 1, bs);
         if (rc) return rc;
-    }
-    constexpr bool HEX = std::is_same<typename ET::Rec, ElemRec>::value;
-    const bool sign_items = HEX && want_sign && nel > 0;
-    if constexpr (HEX) {
-        if (sign_items) {
-            // boxes of the elements that can be candidates in a hot tile (hot[] is complete after the count pass)
-            ENSURE(P->sbox, sizeof(SignBox) * (size_t)nel);
-            ENSURE(P->s_nchunks, sizeof(uint32_t) * (size_t)(nel + 1));
-            ENSURE(P->s_chunk_off, sizeof(uint32_t) * (size_t)(nel + 1));
-            ENSURE(P->s_nstore, sizeof(uint32_t) * (size_t)(nel + 1));
-            ENSURE(P->s_store_off, sizeof(uint32_t) * (size_t)(nel + 1));
-            zero_many(bs, {{P->s_nchunks.p, sizeof(uint32_t) * (size_t)(nel + 1)}, {P->s_nstore.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
-            sign_box_kernel<<<(unsigned)((nel * BIN_LANES + 255) / 256), 256, 0, bs>>>(P->erec.as<ElemRec>(), (uint32_t)nel, g, s, P->hot.as<uint8_t>(), P->sbox.as<SignBox>(), P->s_nchunks.as<uint32_t>(), P->s_nstore.as<uint32_t>());
-            int rc = scan_exclusive2(P, P->s_nchunks.as<uint32_t>(), P->s_chunk_off.as<uint32_t>(), P->s_nstore.as<uint32_t>(),
-                                     P->s_store_off.as<uint32_t>(), nel + 1, bs);
-            if (rc) return rc;
-            rb2.add(P->s_chunk_off.as<uint32_t>() + nel, 1, 11);
-            rb2.add(P->s_store_off.as<uint32_t>() + nel, 1, 13);
-        }
     }
     active_tiles_kernel<<<(ntiles + 256 * AT_ITEMS - 1) / (256 * AT_ITEMS), 256, 0, bs>>>(P->band_cnt.as<uint32_t>(), P->sign_cnt.as<uint32_t>(), P->hot.as<uint8_t>(), ntiles, P->active.as<uint32_t>(), P->active_sign.as<uint32_t>(), P->active_any.as<uint32_t>(), P->active_sonly.as<uint32_t>(), P->tri.as<uint8_t>(), P->active_lean.as<uint32_t>(), P->active_tri.as<uint32_t>(), counters);
     rb2.add(P->band_off.as<uint32_t>() + ntiles, 1, 2);
