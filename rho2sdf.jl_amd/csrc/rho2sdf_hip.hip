@@ -2298,7 +2298,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_store_e, 1));
             static const int wps_env = getenv("R2S_ISO_WPS") ? atoi(getenv("R2S_ISO_WPS")) : 0;   // tuning knob
             const uint32_t wps = (wps_env >= 1 && wps_env <= 3) ? (uint32_t)wps_env : 2u;
-            const uint32_t resident = (uint32_t)P->n_cu * 4u * wps;
+            static const int free_env = getenv("R2S_ISO_FREE") ? atoi(getenv("R2S_ISO_FREE")) : 0;   // tuning knob: fewer persistent wavefronts
+            const uint32_t resident = (uint32_t)P->n_cu * 4u * wps - (uint32_t)std::min(std::max(free_env, 0), (int)P->n_cu * 4);
             const uint32_t group = std::min(4u, std::max(1u, n_chunks_e / (resident * 12u)));
             const uint32_t ngroups = (n_chunks_e + group - 1) / group;
             HIP_TRY(hipEventRecord(P->ev[7], st));
