@@ -383,8 +383,11 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
                                                          QuadTab q, float* __restrict__ partial, int row0 = 0,
                                                          const float* __restrict__ segmn = nullptr,
                                                          const float* __restrict__ segmx = nullptr,
-                                                         const float4* __restrict__ qpts = nullptr)
+                                                         const float4* __restrict__ qpts = nullptr, int nrows = -1)
 {
+    // nrows >= 0: the workgroups stride over the rows row0 .. row0 + nrows - 1 (fixed grid) and keep the quadrature points
+    // (order <= 9: 729 x 16 B) in LDS for all of their rows - as global look-ups they were a third of the cost of a cut
+    // cell (in registers: 193 VGPRs, 2 wavefronts per SIMD, slower).  nrows < 0: one workgroup per row (gridDim.x rows).
     // (row0: first cell row of this launch - a Z-slab of a multi-device run works on the rows of its planes, with
     //  `sdf`, `partial` and the segment arrays addressed as the whole grid's)
     // segmn / segmx (volume_seg_minmax_kernel, optional): rounding is monotonic, so (segment max - shift) < iso puts
@@ -393,23 +396,33 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
     __shared__ float red[256];
     __shared__ int s_cut[256];
     __shared__ int s_wcnt[4];
-    const int row = row0 + blockIdx.x;
-    const int j = row % (ny - 1), k = row / (ny - 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t sy = nx, sz = (int64_t)nx * ny;
     const int npts = q.order * q.order * q.order;
     const int nseg = (nx - 1 + 63) / 64;
     const bool segs = segmn != nullptr;
+    const bool in_lds = qpts != nullptr && npts <= 12 * 64;
+    __shared__ float4 sQ[12 * 64];   // xi, eta, zeta, weight per quadrature point
+    if (in_lds) {
+        for (int p = tid; p < npts; p += 256) {
+            const float4 A = qpts[2 * p], B = qpts[2 * p + 1];
+            sQ[p] = make_float4(A.x, A.z, B.x, B.z);
+        }
+        __syncthreads();
+    }
+    const int row_end = row0 + (nrows >= 0 ? nrows : (int)gridDim.x);
+    for (int row = row0 + blockIdx.x; row < row_end; row += gridDim.x) {
+    const int j = row % (ny - 1), k = row / (ny - 1);
     if (segs) {
         bool any = false;
         for (int sg = 0; sg < nseg; ++sg) any = any || !(segmx[(size_t)row * nseg + sg] - shift < iso);
         if (!any) {   // every cell outside: all partial sums are 0
             if (tid == 0) partial[row] = 0.0f;
-            return;
+            continue;
         }
     }
 #if defined(VOL_DIAG) && VOL_DIAG == 2   // timing-only build: only the row-level test
-    if (segs) { if (tid == 0) partial[row] = 1.0f; return; }
+    if (segs) { if (tid == 0) partial[row] = 1.0f; continue; }
 #endif
     float acc = 0.0f;    // full cells (per thread)
     float wacc = 0.0f;   // cut cells (lane 0 of each wave)
@@ -469,7 +482,20 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
                         c110 = sdf[b + sy + 1] - shift, c001 = sdf[b + sz] - shift, c101 = sdf[b + sz + 1] - shift,
                         c011 = sdf[b + sz + sy] - shift, c111 = sdf[b + sz + sy + 1] - shift;
             float part = 0.0f;
-            if (qpts) {   // (quad_points_kernel: the same numbers, looked up.  Unrolling this loop 4 / 6 / 12 times: slower)
+            if (in_lds) {   // (the same numbers, the same order of additions; 1 - x is recomputed, exactly)
+                for (int p = lane; p < npts; p += 64) {
+                    const float4 Q = sQ[p];
+                    const float xi = Q.x, eta = Q.y, zeta = Q.z;
+                    const float c00 = c000 * (1.0f - xi) + c100 * xi;
+                    const float c01 = c001 * (1.0f - xi) + c101 * xi;
+                    const float c10 = c010 * (1.0f - xi) + c110 * xi;
+                    const float c11 = c011 * (1.0f - xi) + c111 * xi;
+                    const float c0 = c00 * (1.0f - eta) + c10 * eta;
+                    const float c1 = c01 * (1.0f - eta) + c11 * eta;
+                    const float pv = c0 * (1.0f - zeta) + c1 * zeta;
+                    if (pv >= iso) part += Q.w;
+                }
+            } else if (qpts) {   // (quad_points_kernel: the same numbers, looked up.  Unrolling this loop 4 / 6 / 12 times: slower)
                 for (int p = lane; p < npts; p += 64) {
                     const float4 A = qpts[2 * p], B = qpts[2 * p + 1];   // xi, 1-xi, eta, 1-eta | zeta, 1-zeta, weight
                     const float c00 = c000 * A.y + c100 * A.x;
@@ -510,6 +536,8 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);   // lanes < off hold the tree's values
         if (lane == 0) partial[row] = v;
+    }
+    __syncthreads();   // (red[], s_cut[] are reused by the next row)
     }
 }
 
@@ -564,9 +592,9 @@ struct VolumeWork {
             int rc = points(jac, st);
             if (rc) return rc;
         }
-        volume_rows_kernel<<<nrows, 256, 0, st>>>(d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>(), 0,
-                                                 segs ? segmn.as<float>() : nullptr, segs ? segmx.as<float>() : nullptr,
-                                                 qpts.as<float4>());
+        volume_rows_kernel<<<std::min(nrows, 8192), 256, 0, st>>>(d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>(), 0,
+                                                                 segs ? segmn.as<float>() : nullptr, segs ? segmx.as<float>() : nullptr,
+                                                                 qpts.as<float4>(), nrows);
         sum_f32_kernel<<<1, 1024, 0, st>>>(partial.as<float>(), nrows, result.as<float>());
         HIP_TRY(hipMemcpyAsync(out, result.p, sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -2337,8 +2365,9 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
                 if (kc1 <= d.k0) continue;
                 const int row0 = d.k0 * (ny - 1), nr = (kc1 - d.k0) * (ny - 1);
                 SLAB_HIP(hipSetDevice(d.device));
-                volume_rows_kernel<<<nr, 256, 0, d.stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, th, 0.0f, elvol, jac, vw[q].q,
-                                                            brows.at<float>(q), row0, bsegmn.at<float>(q), bsegmx.at<float>(q), vw[q].qpts.as<float4>());
+                volume_rows_kernel<<<std::min(nr, 8192), 256, 0, d.stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, th, 0.0f, elvol, jac, vw[q].q,
+                                                                            brows.at<float>(q), row0, bsegmn.at<float>(q), bsegmx.at<float>(q),
+                                                                            vw[q].qpts.as<float4>(), nr);
                 if (q != q0)
                     SLAB_HIP(hipMemcpyPeerAsync(brows.at<float>(q0) + row0, S[q0].device, brows.at<float>(q) + row0, d.device,
                                                 sizeof(float) * (size_t)nr, d.stream));
