@@ -2311,6 +2311,29 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             // (the sentinel sweep on a third stream right here, beside the binning: its wavefronts delay the first short
             //  kernels by what it saves later - 4.24 vs 4.20 ms; it stays behind the binning on the second stream)
         }
+    } else {
+        // TET4, fused output: the same - the closed-form projection kernel (short-lived wavefronts, 44 VGPRs) runs on
+        // the first stream while the high-priority second stream builds the tile lists (2.8 ms on the 1 M elements of
+        // config 5), sweeps and runs the sign gather
+        early_iso = spec && early_env && overlap_env0 && mode == R2S_OUT_SDF && want_sign && want_dist && n_items && cnt[10];
+        if (early_iso) {
+            ReadBack rbA;
+            rbA.add(P->chunk_off.as<uint32_t>() + n_items, 1, 10);
+            rbA.add(P->store_off.as<uint32_t>() + n_items, 1, 12);
+            read_back_kernel<<<1, 64, 0, st>>>(rbA, P->d_pinned, ex, counters + 15);
+            HIP_TRY(hipEventRecord(P->ev2[6], st));
+            const uint32_t n_chunks_e = cnt[10], n_store_e = cnt[12];
+            ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_store_e, 1));
+            static const int cpw_env = getenv("R2S_ISO_CPW") ? atoi(getenv("R2S_ISO_CPW")) : 0;   // tuning knob
+            const uint32_t cpw = cpw_env > 0 ? (uint32_t)cpw_env : 8u;
+            const uint32_t nwaves = (n_chunks_e + cpw - 1) / cpw;
+            HIP_TRY(hipEventRecord(P->ev[7], st));
+            iso_project_kernel<typename ET::Rec><<<(nwaves + 3) / 4, 256, 0, st>>>(
+                P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks_e, P->erec.as<typename ET::Rec>(), g,
+                s, rho_t, P->iso_res.as<double>(), nullptr, abort_flag, cpw);
+            HIP_TRY(hipEventRecord(P->ev[6], st));
+            HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[6], 0));
+        }
     }
     hipStream_t bs = early_iso ? P->st2 : st;   // stream of the binning
 
@@ -2503,7 +2526,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[2], 0));   // sign-only gather (second stream), beside the band gather
             HIP_TRY(hipEventRecord(P->ev[4], st));
         } else {
-            HIP_TRY(hipEventRecord(P->ev[7], st));
+            if (!early_iso) HIP_TRY(hipEventRecord(P->ev[7], st));
             if (overlap) {
                 if (n_active_sign) {
                     MainArgs B = A;
@@ -2518,7 +2541,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             // item-major iso-surface projections, then the ordered gather over the band tiles
             A.iso_res = P->iso_res.as<double>();
             A.iso_res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
-            if (want_dist && n_chunks)
+            if (want_dist && n_chunks && !early_iso)
             {
                 static const int cpw_env = getenv("R2S_ISO_CPW") ? atoi(getenv("R2S_ISO_CPW")) : 0;   // tuning knob
                 const uint32_t cpw = cpw_env > 0 ? (uint32_t)cpw_env : 8u;
@@ -2527,7 +2550,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                     P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, P->erec.as<typename ET::Rec>(), g,
                     s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, abort_flag, cpw);
             }
-            HIP_TRY(hipEventRecord(P->ev[6], st));
+            if (!early_iso) HIP_TRY(hipEventRecord(P->ev[6], st));
             if (want_dist && n_active) {
                 A.active = P->active.as<uint32_t>(); A.n_active = n_active;
                 A.sign = nullptr;
