@@ -1419,6 +1419,31 @@ __global__ void __launch_bounds__(256) dot_planes_kernel(const float* __restrict
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
+// x += alpha u, r -= alpha q and the parts of dot(r, r) in one pass: the grid, the element -> thread assignment and the
+// order of the additions are those of dot_planes_kernel(r, r), so the partial sums come out bit for bit the same
+__global__ void __launch_bounds__(256) cg_update_xr_dot_kernel(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ u,
+                                                              const float* __restrict__ q, float alpha, int64_t plane,
+                                                              double* __restrict__ partial)
+{
+    __shared__ double red[256];
+    const int64_t k = blockIdx.x / DOT_PARTS, part = blockIdx.x % DOT_PARTS;
+    const int64_t chunk = (plane + DOT_PARTS - 1) / DOT_PARTS, lo = part * chunk, hi = (lo + chunk < plane) ? lo + chunk : plane;
+    const int64_t o = k * plane;
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        x[o + i] += alpha * u[o + i];
+        const float rn = r[o + i] - alpha * q[o + i];
+        r[o + i] = rn;
+        acc += (double)rn * (double)rn;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
 __global__ void __launch_bounds__(256) sum_f64_kernel(const double* __restrict__ in, int n, double* __restrict__ out)
 {
     __shared__ double red[256];
@@ -1436,15 +1461,6 @@ __global__ void cg_update_u_kernel(float* __restrict__ u, const float* __restric
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) u[i] = r[i] + beta * u[i];
-}
-__global__ void cg_update_xr_kernel(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ u,
-                                    const float* __restrict__ q, float alpha, int64_t n)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        x[i] += alpha * u[i];
-        r[i] -= alpha * q[i];
-    }
 }
 __global__ void minmax_kernel(const float* __restrict__ v, int64_t n, int* __restrict__ mm)
 {
@@ -1657,6 +1673,16 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             *out = (float)h;
             return 0;
         };
+        auto xr_dot = [&](float alpha, float* out) -> int {   // weights / residual update with dot(r, r)
+            cg_update_xr_dot_kernel<<<nz * DOT_PARTS, 256, 0, st>>>(d_w.as<float>(), d_r.as<float>(), d_u.as<float>(), d_q.as<float>(), alpha,
+                                                                   (int64_t)nx * ny, d_part.as<double>());
+            std::vector<double> hp((size_t)nz * DOT_PARTS);
+            HIP_TRY(hipMemcpy(hp.data(), d_part.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
+            double h = 0.0;
+            for (double v : hp) h += v;
+            *out = (float)h;
+            return 0;
+        };
         // materialise K when it fits comfortably (see rbf_kbuild_kernel)
         RbfTaps taps;
         taps.n = 0;
@@ -1703,9 +1729,8 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             float uq;
             TRY_C(dot(d_u.as<float>(), d_q.as<float>(), &uq));
             const float alpha = (residual * residual) / uq;
-            cg_update_xr_kernel<<<nb, 256, 0, st>>>(d_w.as<float>(), d_r.as<float>(), d_u.as<float>(), d_q.as<float>(), alpha, n);
             prev = residual;
-            TRY_C(dot(d_r.as<float>(), d_r.as<float>(), &rr));
+            TRY_C(xr_dot(alpha, &rr));
             residual = std::sqrt(rr);
             its++;
         }
@@ -2278,15 +2303,23 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
             float uq;
             SLAB_TRY(dot(bu, bq, &uq));
             const float alpha = (residual * residual) / uq;
-            for (size_t q : order) {
+            for (size_t q : order) {   // weights / residual update with the parts of dot(r, r)
                 const Slab& d = S[q];
-                const int64_t no = nowned(q);
                 SLAB_HIP(hipSetDevice(d.device));
-                cg_update_xr_kernel<<<(unsigned)((no + 255) / 256), 256, 0, d.stream>>>(owned(bw.at<float>(q), q), owned(br.at<float>(q), q),
-                                                                                        owned(bu.at<float>(q), q), owned(bq.at<float>(q), q), alpha, no);
+                hp[q].resize((size_t)(d.k1 - d.k0) * DOT_PARTS);
+                cg_update_xr_dot_kernel<<<(d.k1 - d.k0) * DOT_PARTS, 256, 0, d.stream>>>(owned(bw.at<float>(q), q), owned(br.at<float>(q), q),
+                                                                                         owned(bu.at<float>(q), q), owned(bq.at<float>(q), q), alpha,
+                                                                                         plane, bpart.at<double>(q));
+                SLAB_HIP(hipMemcpyAsync(hp[q].data(), bpart.at<double>(q), sizeof(double) * hp[q].size(), hipMemcpyDeviceToHost, d.stream));
             }
             prev = residual;
-            SLAB_TRY(dot(br, br, &rr));
+            SLAB_TRY(sync_slabs(S));
+            {
+                double h = 0.0;
+                for (size_t q : order)
+                    for (double v : hp[q]) h += v;
+                rr = (float)h;
+            }
             residual = std::sqrt(rr);
             its++;
         }
