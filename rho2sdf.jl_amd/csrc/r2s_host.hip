@@ -115,6 +115,7 @@ struct HostSession {
     void* stage[2] = {nullptr, nullptr};
     hipStream_t cs = nullptr;   // copy stream
     hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> evf;   // one per forwarded chunk of the smoothed field (r2s_rho2sdf)
     CopyPool* pool = nullptr;
 
     int init(int dev)
@@ -152,6 +153,8 @@ struct HostSession {
             stage[i] = nullptr;
             ev[i] = nullptr;
         }
+        for (hipEvent_t e : evf) (void)hipEventDestroy(e);
+        evf.clear();
         if (cs) (void)hipStreamDestroy(cs);
         cs = nullptr;
         delete pool;
@@ -681,52 +684,97 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     }
     double t4 = now_ms();
     ri.ms_artifacts = t4 - t3;
-    // the cleaned field travels to the host while the smoothing runs: one DMA into a pinned destination, else the staged
-    // copy on a helper thread (copy stream + staging buffers of the session; the smoothing uses the default stream)
+    // The cleaned field travels to the host while the smoothing runs, and the chunks of the smoothed field follow as the
+    // last kernel of the smoothing finishes them (r2s_int::rbf_smooth_dev, fine_chunk): one helper thread with the copy
+    // stream and the staging buffers of the session (the smoothing uses the default stream).  Pinned destinations get
+    // plain DMA, pageable ones the staged copy.
     bool dists_in_flight = false;
     std::thread dl_thread;
     int dl_rc = 0;
     std::string dl_err;
-    if (sdf_dists_out && pin_d) {
-        HIP_TRY(hipMemcpyAsync(sdf_dists_out, S->out[2].p, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost, S->cs));
-        dists_in_flight = true;
-    } else if (sdf_dists_out && !o.skip_rbf) {
-        dl_thread = std::thread([&]() {
-            if (hipSetDevice(dev0) != hipSuccess) { dl_rc = R2S_ERR_HIP; dl_err = "hipSetDevice failed"; return; }
-            std::vector<Segment> segs{{(char*)sdf_dists_out, (const char*)S->out[2].p, sizeof(double) * (size_t)ngp}};
-            dl_rc = download(S, segs, false);
-            if (dl_rc) dl_err = g_err;
-        });
-        dists_in_flight = true;
-    }
-    auto join_dl = [&]() -> int {
-        if (dl_thread.joinable()) dl_thread.join();
-        return dl_rc ? fail(dl_rc, "%s", dl_err.c_str()) : 0;
-    };
-    // ---- RBF smoothing (:222-224) ----
+    struct Chunk { int64_t t0, t1; hipEvent_t ev; };
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::vector<Chunk> queue;   // chunks of the smoothed field whose kernels have been launched
+    bool q_done = false;
     size_t nfine = 0;
     if (!o.skip_rbf) {
         nfine = 1;
         for (int i = 0; i < 3; ++i) nfine *= (size_t)(grid->N[i] * o.rbf_smooth + 1);
+    }
+    const bool pin_f = fine_sdf_out && is_pinned(fine_sdf_out);
+    if (sdf_dists_out && pin_d) {
+        HIP_TRY(hipMemcpyAsync(sdf_dists_out, S->out[2].p, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost, S->cs));
+        dists_in_flight = true;
+    }
+    if (!o.skip_rbf) {
+        const bool dists_here = sdf_dists_out && !pin_d;
+        dl_thread = std::thread([&, dists_here]() {
+            if (hipSetDevice(dev0) != hipSuccess) { dl_rc = R2S_ERR_HIP; dl_err = "hipSetDevice failed"; return; }
+            if (dists_here) {
+                std::vector<Segment> segs{{(char*)sdf_dists_out, (const char*)S->out[2].p, sizeof(double) * (size_t)ngp}};
+                dl_rc = download(S, segs, false);
+                if (dl_rc) { dl_err = g_err; return; }
+            }
+            size_t next = 0;
+            for (;;) {
+                Chunk c;
+                {
+                    std::unique_lock<std::mutex> lk(qmu);
+                    qcv.wait(lk, [&] { return next < queue.size() || q_done; });
+                    if (next >= queue.size()) return;
+                    c = queue[next++];
+                }
+                if (hipEventSynchronize(c.ev) != hipSuccess) { dl_rc = R2S_ERR_HIP; dl_err = "hipEventSynchronize failed"; return; }
+                std::vector<Segment> segs{{(char*)(fine_sdf_out + c.t0), (const char*)(S->fine.as<float>() + c.t0), sizeof(float) * (size_t)(c.t1 - c.t0)}};
+                dl_rc = download(S, segs, pin_f);
+                if (dl_rc) { dl_err = g_err; return; }
+            }
+        });
+        if (dists_here) dists_in_flight = true;
+    }
+    auto join_dl = [&]() -> int {
+        {
+            std::lock_guard<std::mutex> lk(qmu);
+            q_done = true;
+        }
+        qcv.notify_all();
+        if (dl_thread.joinable()) dl_thread.join();
+        return dl_rc ? fail(dl_rc, "%s", dl_err.c_str()) : 0;
+    };
+    // ---- RBF smoothing (:222-224) ----
+    if (!o.skip_rbf) {
         if (S->fine.ensure_exact(sizeof(float) * nfine)) { (void)join_dl(); return fail(R2S_ERR_NOMEM, "hipMalloc of the fine grid failed"); }
         int its = 0;
         if (S->fine.p == nullptr) { (void)join_dl(); return fail(R2S_ERR_NOMEM, "hipMalloc of the fine grid failed"); }
+        size_t n_ev = 0;
+        const std::function<int(int64_t, int64_t)> forward = [&](int64_t t0, int64_t t1) -> int {
+            if (n_ev >= S->evf.size()) {
+                hipEvent_t e = nullptr;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(R2S_ERR_HIP, "hipEventCreate failed");
+                S->evf.push_back(e);
+            }
+            hipEvent_t e = S->evf[n_ev++];
+            if (hipEventRecord(e, nullptr) != hipSuccess) return fail(R2S_ERR_HIP, "hipEventRecord failed");   // (the smoothing's stream)
+            {
+                std::lock_guard<std::mutex> lk(qmu);
+                queue.push_back({t0, t1, e});
+            }
+            qcv.notify_all();
+            return 0;
+        };
         rc = r2s_int::rbf_smooth_dev(S->out[2].as<double>(), grid, o.rbf_interp, o.rbf_smooth, o.rbf_kernel_threshold,
-                                     ri.V_frac * ri.V_domain, S->fine.as<float>(), &ri.level_shift, &its);
+                                     ri.V_frac * ri.V_domain, S->fine.as<float>(), &ri.level_shift, &its, &forward);
         if (rc) { (void)join_dl(); return rc; }
         ri.cg_iters = its;
     }
-    if ((rc = join_dl())) return rc;
     double t5 = now_ms();
     ri.ms_rbf = t5 - t4;
-    // ---- results to the caller ----
+    // ---- rest of the results to the caller ----
+    if ((rc = join_dl())) return rc;
     if (sdf_dists_out && !dists_in_flight) {
         std::vector<Segment> segs{{(char*)sdf_dists_out, (const char*)S->out[2].p, sizeof(double) * (size_t)ngp}};
         if ((rc = download(S, segs, false))) return rc;
-    }
-    if (!o.skip_rbf) {
-        std::vector<Segment> segs{{(char*)fine_sdf_out, (const char*)S->fine.p, sizeof(float) * nfine}};
-        if ((rc = download(S, segs, is_pinned(fine_sdf_out)))) return rc;
     }
     if (dists_in_flight) HIP_TRY(hipStreamSynchronize(S->cs));
     const double t6 = now_ms();

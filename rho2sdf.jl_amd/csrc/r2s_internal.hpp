@@ -3,6 +3,7 @@
 // chained r2s_rho2sdf() in r2s_host.hip.  All of them run on the CURRENT device and are synchronous on return.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "r2s_common.hpp"
@@ -32,8 +33,12 @@ int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, dou
                          int64_t* n_flipped);
 
 // RBFs_smoothing with device-resident input / output (RBFs4Smoothing.jl:321-377)
+// fine_chunk (optional): the output field is evaluated in a few Z chunks; after the launch of each one (default stream)
+// fine_chunk(first, last) is called with the range [first, last) of d_fine_out that kernel fills, so that the caller
+// can send finished chunks to the host while the next one is computed.  A non-zero return aborts.
 int rbf_smooth_dev(const double* d_sdf, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
-                   float* d_fine_out, float* th_out, int* cg_iters);
+                   float* d_fine_out, float* th_out, int* cg_iters,
+                   const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr);
 
 // ---- Z-slab distributed post-processing (single process, one entry per device; SURVEY 8(e) second half) ----------
 // A slab OWNS the grid planes [k0, k1) and HOLDS [h0, h1) (its planes plus the halo the stencils reach into);

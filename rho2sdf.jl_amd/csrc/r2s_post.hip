@@ -838,6 +838,7 @@ __global__ void __launch_bounds__(256) rbf_matvec_k_kernel(RbfGeom G, RbfTaps T,
 // of accumulation => bit-identical to rbf_matvec_kernel, without its 81 exp() per row and without the 43 GB
 // materialised matrix of rbf_matvec_k_kernel; the table (<= 2 MB for R = 2) lives in L2.
 #define RBF_NV 16   // variants per (axis, offset) the matvec table has room for; more -> the materialised / on-the-fly paths
+#define RBF_FINE_CHUNKS 4   // Z chunks of the output field when finished chunks are forwarded to the host
 #ifndef RBF_MATVEC_BATCH
 #define RBF_MATVEC_BATCH 16
 #endif
@@ -1496,7 +1497,8 @@ static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
 // sdf_dev / out_dev: `sdf` / `fine_out` are device pointers (device-resident chaining of the stages)
 static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, int smooth, double kthr,
                            double target_volume, float* fine_out, float* th_out, int* cg_iters, float* lsf_out,
-                           bool sdf_dev = false, bool out_dev = false)
+                           bool sdf_dev = false, bool out_dev = false,
+                           const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr)
 {
     if (!sdf || !g || !fine_out) return fail(R2S_ERR_ARG, "null argument");
     if (smooth < 1 || smooth > 4) return fail(R2S_ERR_ARG, "smooth must be 1..4");
@@ -1767,12 +1769,24 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     th = -th;
     if (th_out) *th_out = th;
     // ---- fine grid (:363-366) ----
-    const unsigned nbf = (unsigned)((nf + 255) / 256);
     // (smooth = 1: one target per lattice point - through the table of ITS coordinate differences)
-    if (!(fine_one_to_one && launch_rbf_apply_lut(G, LGF, sts[1], nbf, st, d_w.as<float>(), d_tx.as<float>(), d_ty.as<float>(),
-                                                  d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine)))
-        rbf_apply_kernel<<<nbf, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
-                                             d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine);
+    // In RBF_FINE_CHUNKS Z chunks when the caller wants to forward finished chunks (fine_chunk), else in one launch.
+    {
+        const int nchunk = (fine_chunk && fz >= 4 * RBF_FINE_CHUNKS) ? RBF_FINE_CHUNKS : 1;
+        for (int c = 0; c < nchunk; ++c) {
+            const int f0 = (int)((int64_t)fz * c / nchunk), f1 = (int)((int64_t)fz * (c + 1) / nchunk);
+            const int64_t t0 = (int64_t)f0 * fx * fy, t1 = (int64_t)f1 * fx * fy;
+            const unsigned nbc = (unsigned)((t1 - t0 + 255) / 256);
+            if (!(fine_one_to_one && launch_rbf_apply_lut(G, LGF, sts[1], nbc, st, d_w.as<float>(), d_tx.as<float>(), d_ty.as<float>(),
+                                                          d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine, t0, t1)))
+                rbf_apply_kernel<<<nbc, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
+                                                     d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine, t0, t1);
+            if (fine_chunk) {
+                const int rcc = (*fine_chunk)(t0, t1);
+                if (rcc) { cleanup(); return rcc; }
+            }
+        }
+    }
     HIP_C(hipGetLastError());
     if (out_dev) HIP_C(hipDeviceSynchronize());
     else HIP_C(hipMemcpy(fine_out, d_fine.p, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost));
@@ -2449,9 +2463,10 @@ int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, dou
     return ::remove_artifacts_dev(d_sdf, g, threshold, min_ratio, st, n_flipped);
 }
 int rbf_smooth_dev(const double* d_sdf, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
-                   float* d_fine_out, float* th_out, int* cg_iters)
+                   float* d_fine_out, float* th_out, int* cg_iters, const std::function<int(int64_t, int64_t)>* fine_chunk)
 {
-    return rbf_smooth_host(d_sdf, g, is_interp, smooth, kthr, target_volume, d_fine_out, th_out, cg_iters, nullptr, true, true);
+    return rbf_smooth_host(d_sdf, g, is_interp, smooth, kthr, target_volume, d_fine_out, th_out, cg_iters, nullptr, true, true,
+                           fine_chunk);
 }
 }  // namespace r2s_int
 
