@@ -165,6 +165,24 @@ def test_tet4_solid_boundary(pkg, oracle):
     _compare(pkg, oracle, X, IT, rn, 0.05, pg, og, 1.1, "tet4 solid boundary")
 
 
+@pytest.mark.parametrize("squash,seed", [(0.05, 1), (0.02, 2), (5e-4, 3)])
+def test_tet4_flat_elements_random_density(pkg, oracle, squash, seed):
+    """strongly jittered Schlafli tets whose upper half is squashed in z (flat elements: height / edge down to 5e-4, below
+    the 1e-3 limit under which the face-plane shortcuts of the sign pass switch themselves off) with RANDOM nodal
+    densities: the tile culling, the accept / reject planes and the unordered candidate lists must leave every sign,
+    sentinel and distance as the oracle has them"""
+    from rho2sdf_jl_amd import synthetic
+    X, IT, _ = synthetic.tet_mesh(5, jitter=0.3, seed=seed)
+    X = X.copy()
+    up = X[:, 2] > 0
+    X[up, 2] *= squash
+    rn = np.random.default_rng(seed).uniform(0.0, 1.0, len(X))
+    nmax = synthetic.grid_n_max_for_points(44)
+    pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
+    _compare(pkg, oracle, X, IT, rn, 0.5, pg, og, 1.1, f"tet4 flat {squash}")
+
+
 @pytest.mark.parametrize("dims_n,tets", [(40, False), (37, False), (37, True)])
 def test_interleaved_layers_equal_full_volume(pkg, oracle, dims_n, tets):
     """the balanced multi-GPU partition (4-plane tile layers dealt round-robin, r2s_params.zstride/zphase):
