@@ -1132,14 +1132,34 @@ __global__ void __launch_bounds__(256) rbf_matvec_lds_kernel(RbfLutGeom G, const
         return;
     }
     // ---- table rows of this workgroup -> LDS: sT[jr][q][x variant] ----
+    // two steps so that the loads of a step are independent of each other: (1) one thread per (j row, neighbour) chases
+    // offset -> variants of its plane / row -> position of the 64-byte table row; (2) all threads copy the rows, six
+    // 4-byte loads in flight each (one serial loop of offset look-ups + table load per element spent more time waiting
+    // than the products take)
     const int nj = jB - jA + 1;
-    for (int e = (int)tid; e < nj * NT * RBF_NV; e += 256) {
-        const int jr = e / (NT * RBF_NV), r = e - jr * (NT * RBF_NV), q = r / RBF_NV, v = r - q * RBF_NV;
+    __shared__ uint32_t sBase[RBF_MV_ROWS * NT];
+    for (int e = (int)tid; e < nj * NT; e += 256) {
+        const int jr = e / NT, q = e - jr * NT;
         const int dk = TO.dk[q], dj = TO.dj[q], di = TO.di[q];
         const uint32_t c = G.vz[dk * G.nz + k];   // (k is interior: never 255)
         uint32_t b = G.vy[dj * G.ny + jA + jr];
         b = b != 255u ? b : (uint32_t)(RBF_NV - 1);
-        sT[e] = G.T[((((size_t)((dk * W + dj) * W + di)) * RBF_NV + c) * RBF_NV + b) * RBF_NV + (uint32_t)v];
+        sBase[e] = ((((uint32_t)((dk * W + dj) * W + di)) * RBF_NV + c) * RBF_NV + b) * RBF_NV;
+    }
+    __syncthreads();
+    const int total = nj * NT * RBF_NV;
+    for (int e0 = 0; e0 < total; e0 += 6 * 256) {
+        float v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = e0 + u * 256 + (int)tid;
+            v[u] = e < total ? G.T[sBase[e / RBF_NV] + (uint32_t)(e % RBF_NV)] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = e0 + u * 256 + (int)tid;
+            if (e < total) sT[e] = v[u];
+        }
     }
     __syncthreads();
     const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
