@@ -116,6 +116,7 @@ struct HostSession {
     hipStream_t cs = nullptr;   // copy stream
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> evf;   // one per forwarded chunk of the smoothed field (r2s_rho2sdf)
+    void* rbf_ws = nullptr;        // buffers of the smoothing stage, kept between r2s_rho2sdf calls
     CopyPool* pool = nullptr;
 
     int init(int dev)
@@ -155,6 +156,8 @@ struct HostSession {
         }
         for (hipEvent_t e : evf) (void)hipEventDestroy(e);
         evf.clear();
+        r2s_int::rbf_workspace_release(rbf_ws);
+        rbf_ws = nullptr;
         if (cs) (void)hipStreamDestroy(cs);
         cs = nullptr;
         delete pool;
@@ -747,6 +750,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
         if (S->fine.ensure_exact(sizeof(float) * nfine)) { (void)join_dl(); return fail(R2S_ERR_NOMEM, "hipMalloc of the fine grid failed"); }
         int its = 0;
         if (S->fine.p == nullptr) { (void)join_dl(); return fail(R2S_ERR_NOMEM, "hipMalloc of the fine grid failed"); }
+        if (!S->rbf_ws) S->rbf_ws = r2s_int::rbf_workspace_create();
         size_t n_ev = 0;
         const std::function<int(int64_t, int64_t)> forward = [&](int64_t t0, int64_t t1) -> int {
             if (n_ev >= S->evf.size()) {
@@ -764,7 +768,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
             return 0;
         };
         rc = r2s_int::rbf_smooth_dev(S->out[2].as<double>(), grid, o.rbf_interp, o.rbf_smooth, o.rbf_kernel_threshold,
-                                     ri.V_frac * ri.V_domain, S->fine.as<float>(), &ri.level_shift, &its, &forward);
+                                     ri.V_frac * ri.V_domain, S->fine.as<float>(), &ri.level_shift, &its, &forward, S->rbf_ws);
         if (rc) { (void)join_dl(); return rc; }
         ri.cg_iters = its;
     }

@@ -38,7 +38,10 @@ int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, dou
 // can send finished chunks to the host while the next one is computed.  A non-zero return aborts.
 int rbf_smooth_dev(const double* d_sdf, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
                    float* d_fine_out, float* th_out, int* cg_iters,
-                   const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr);
+                   const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr, void* workspace = nullptr);
+// workspace (optional): the call's device buffers, kept between calls on the CURRENT device (create / release there)
+void* rbf_workspace_create();
+void rbf_workspace_release(void* workspace);
 
 // ---- Z-slab distributed post-processing (single process, one entry per device; SURVEY 8(e) second half) ----------
 // A slab OWNS the grid planes [k0, k1) and HOLDS [h0, h1) (its planes plus the halo the stencils reach into);

@@ -1514,11 +1514,20 @@ static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
     c[n - 1] = (float)mx;
 }
 
+struct RbfWork {   // the device buffers of one rbf_smooth_host call
+    DevBuf b[29];
+    VolumeWork vw;
+    void release()
+    {
+        for (DevBuf& x : b) x.release();
+        vw.release();
+    }
+};
 // sdf_dev / out_dev: `sdf` / `fine_out` are device pointers (device-resident chaining of the stages)
 static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, int smooth, double kthr,
                            double target_volume, float* fine_out, float* th_out, int* cg_iters, float* lsf_out,
                            bool sdf_dev = false, bool out_dev = false,
-                           const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr)
+                           const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr, RbfWork* ws = nullptr)
 {
     if (!sdf || !g || !fine_out) return fail(R2S_ERR_ARG, "null argument");
     if (smooth < 1 || smooth > 4) return fail(R2S_ERR_ARG, "smooth must be 1..4");
@@ -1528,14 +1537,17 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     const int fx = (int)g->N[0] * smooth + 1, fy = (int)g->N[1] * smooth + 1, fz = (int)g->N[2] * smooth + 1;
     const int64_t nf = (int64_t)fx * fy * fz;
     hipStream_t st = nullptr;
-    DevBuf d_sdf, d_f, d_w, d_lsf, d_fine, d_cx, d_cy, d_cz, d_tx, d_ty, d_tz, d_st, d_cnt, d_r, d_u, d_q, d_part, d_sum;
-    DevBuf d_lut, d_luta, d_vx, d_vy, d_vz, d_lutf, d_fvx, d_fvy, d_fvz, d_lv, d_lvf;
-    VolumeWork vw;
+    // (a caller that repeats the call keeps the ~30 buffers - 4.6 GB at 512^3 - in a workspace: allocating and freeing
+    //  them costs ~5 ms per call)
+    RbfWork local;
+    RbfWork& W = ws ? *ws : local;
+    DevBuf &d_sdf = W.b[0], &d_f = W.b[1], &d_w = W.b[2], &d_lsf = W.b[3], &d_fine = W.b[4], &d_cx = W.b[5], &d_cy = W.b[6], &d_cz = W.b[7],
+           &d_tx = W.b[8], &d_ty = W.b[9], &d_tz = W.b[10], &d_st = W.b[11], &d_cnt = W.b[12], &d_r = W.b[13], &d_u = W.b[14], &d_q = W.b[15],
+           &d_part = W.b[16], &d_sum = W.b[17], &d_lut = W.b[18], &d_luta = W.b[19], &d_vx = W.b[20], &d_vy = W.b[21], &d_vz = W.b[22],
+           &d_lutf = W.b[23], &d_fvx = W.b[24], &d_fvy = W.b[25], &d_fvz = W.b[26], &d_lv = W.b[27], &d_lvf = W.b[28];
+    VolumeWork& vw = W.vw;
     auto cleanup = [&]() {
-        DevBuf* all[] = {&d_sdf, &d_f, &d_w, &d_lsf, &d_fine, &d_cx, &d_cy, &d_cz, &d_tx, &d_ty, &d_tz, &d_st, &d_cnt,
-                         &d_r, &d_u, &d_q, &d_part, &d_sum, &d_lut, &d_luta, &d_vx, &d_vy, &d_vz, &d_lutf, &d_fvx, &d_fvy, &d_fvz, &d_lv, &d_lvf};
-        for (DevBuf* b : all) b->release();
-        vw.release();
+        if (!ws) W.release();
     };
 #define TRY_C(expr)                                                                   \
     do {                                                                              \
@@ -2483,10 +2495,18 @@ int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, dou
     return ::remove_artifacts_dev(d_sdf, g, threshold, min_ratio, st, n_flipped);
 }
 int rbf_smooth_dev(const double* d_sdf, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
-                   float* d_fine_out, float* th_out, int* cg_iters, const std::function<int(int64_t, int64_t)>* fine_chunk)
+                   float* d_fine_out, float* th_out, int* cg_iters, const std::function<int(int64_t, int64_t)>* fine_chunk,
+                   void* workspace)
 {
     return rbf_smooth_host(d_sdf, g, is_interp, smooth, kthr, target_volume, d_fine_out, th_out, cg_iters, nullptr, true, true,
-                           fine_chunk);
+                           fine_chunk, (RbfWork*)workspace);
+}
+void* rbf_workspace_create() { return new RbfWork(); }
+void rbf_workspace_release(void* w)
+{
+    if (!w) return;
+    ((RbfWork*)w)->release();
+    delete (RbfWork*)w;
 }
 }  // namespace r2s_int
 
