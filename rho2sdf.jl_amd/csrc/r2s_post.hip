@@ -850,7 +850,8 @@ struct RbfLutGeom {
     int nx, ny, nz, R, tap_d2;
     const uint8_t *vx, *vy, *vz;   // [2R+1][n_axis]: variant id of (index, offset), 255 = neighbour outside the lattice
     const float* T;                // [(2R+1)^3][NV][NV][NV], x variant fastest; 0 = entry absent (val <= threshold)
-    const double* TA;              // same shape: the kernel values of the EVALUATION (rbf_apply_kernel's arithmetic); 0 = beyond max_distance
+    const double* TA;              // [(2R+1)^3][NVA]^3: the kernel values of the EVALUATION (rbf_apply_kernel's arithmetic); 0 = beyond max_distance
+    const double* TA16;            // the same with RBF_NV slots per axis (lattice-to-lattice evaluation with <= 15 variants), or null
 };
 struct RbfLutVals {
     float v[3][7][RBF_NVA];        // the variant values per axis and offset
@@ -914,18 +915,19 @@ constexpr RbfTapOrder<R> rbf_tap_order()
 // one row through per-lane clamped addresses and predicates: rows of the first / last R planes, of wavefronts that
 // straddle two planes and of a slab whose halo ends nearby
 // the table of the evaluation (rbf_apply_kernel with targets = lattice points): same differences, that kernel's arithmetic
-__global__ void __launch_bounds__(256) rbf_lut_build_apply_kernel(const RbfLutVals* __restrict__ Vp, double* __restrict__ TA)
+// (nv: variant slots per axis of this table - RBF_NVA, or RBF_NV for the compact table of the lattice-to-lattice evaluation)
+__global__ void __launch_bounds__(256) rbf_lut_build_apply_kernel(const RbfLutVals* __restrict__ Vp, double* __restrict__ TA, int nv = RBF_NVA)
 {
     const RbfLutVals& V = *Vp;
     __shared__ double etab[64];
     if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_neg_64[threadIdx.x];
     __syncthreads();
     const int W = 2 * V.R + 1;
-    const int64_t n = (int64_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
+    const int64_t n = (int64_t)W * W * W * nv * nv * nv;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const int a = (int)(t % RBF_NVA), b = (int)((t / RBF_NVA) % RBF_NVA), c = (int)((t / (RBF_NVA * RBF_NVA)) % RBF_NVA);
-    const int tap = (int)(t / (RBF_NVA * RBF_NVA * RBF_NVA));
+    const int a = (int)(t % nv), b = (int)((t / nv) % nv), c = (int)((t / (nv * nv)) % nv);
+    const int tap = (int)(t / ((int64_t)nv * nv * nv));
     const int di = tap % W, dj = (tap / W) % W, dk = tap / (W * W);
     const float dx = V.v[0][di][a], dy = V.v[1][dj][b], dz = V.v[2][dk][c];
     const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -1295,6 +1297,102 @@ __global__ void __launch_bounds__(256) rbf_apply_lut_kernel(RbfGeom G, RbfLutGeo
     }
     if (t < tend) out[t] = acc + add;
 }
+// The lattice-to-lattice evaluation (the LSF of the level bisection) with the table rows of a workgroup staged in LDS, as
+// in rbf_matvec_lds_kernel: with <= 15 variants per offset a row of the compact table TA16 is 128 bytes, 81 rows = 10 KB
+// per lattice row j; a workgroup of 256 consecutive targets spans at most RBF_AP_ROWS of them (else: the gathered form).
+#define RBF_AP_ROWS 2
+template <int R, int D2>
+__global__ void __launch_bounds__(256) rbf_apply_lds_kernel(RbfGeom G, RbfLutGeom L, const float* __restrict__ w,
+                                                           const Stencil* __restrict__ stencils, float add, float* __restrict__ out,
+                                                           int64_t t_begin, int64_t t_end, int64_t x_lo, int64_t x_hi)
+{
+    constexpr int W = 2 * R + 1;
+    constexpr RbfTapOrder<R> TO = rbf_tap_order<R, D2>();
+    constexpr int NT = TO.n;
+    __shared__ double sT[RBF_AP_ROWS * NT * RBF_NV];
+    __shared__ uint32_t sBase[RBF_AP_ROWS * NT];
+    __shared__ double etab[64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const int64_t n = (int64_t)G.nx * G.ny * G.nz;
+    const int64_t tend = t_end >= 0 ? t_end : n;
+    const int64_t first = x_lo, last = x_hi >= 0 ? x_hi : n - 1;
+    const int64_t tb0 = t_begin + (int64_t)blockIdx.x * 256;
+    if (tb0 >= tend) return;
+    const int64_t tb1 = tb0 + 255 < tend ? tb0 + 255 : tend - 1;
+    const int64_t plane = (int64_t)G.nx * G.ny;
+    const int64_t reach = (int64_t)R * plane + (int64_t)R * G.nx + R;
+    const int k = (int)(tb0 / plane);
+    const int jA = (int)((tb0 - (int64_t)k * plane) / G.nx), jB = (int)((tb1 - (int64_t)k * plane) / G.nx);
+    const bool fast = (tb1 / plane == k) && k >= R && k < G.nz - R && tb0 - reach >= first && tb1 + reach <= last &&
+                      jB - jA + 1 <= RBF_AP_ROWS;
+    const int64_t t = tb0 + tid;
+    if (!fast) {   // (uniform over the workgroup)
+        if (tid < 64) etab[tid] = c_exp2_neg_64[tid];
+        __syncthreads();
+        if (t < tend) out[t] = rbf_apply_point(G, w, 1, G.nx, G.ny, G.cx, G.cy, G.cz, stencils, etab, t) + add;
+        return;
+    }
+    const int nj = jB - jA + 1;
+    for (int e = (int)tid; e < nj * NT; e += 256) {
+        const int jr = e / NT, q = e - jr * NT;
+        const int dk = TO.dk[q], dj = TO.dj[q], di = TO.di[q];
+        const uint32_t c = L.vz[dk * G.nz + k];   // (k is interior: never 255)
+        uint32_t b = L.vy[dj * G.ny + jA + jr];
+        b = b != 255u ? b : (uint32_t)(RBF_NV - 1);
+        sBase[e] = ((((uint32_t)((dk * W + dj) * W + di)) * RBF_NV + c) * RBF_NV + b) * RBF_NV;
+    }
+    __syncthreads();
+    const int total = nj * NT * RBF_NV;
+    for (int e0 = 0; e0 < total; e0 += 6 * 256) {
+        double v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = e0 + u * 256 + (int)tid;
+            v[u] = e < total ? L.TA16[sBase[e / RBF_NV] + (uint32_t)(e % RBF_NV)] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = e0 + u * 256 + (int)tid;
+            if (e < total) sT[e] = v[u];
+        }
+    }
+    __syncthreads();
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t tw0 = tb0 + (int64_t)wv * 64;
+    if (tw0 >= tend) return;
+    const int64_t tc = t < tend ? t : tend - 1;
+    const uint32_t r2 = (uint32_t)(tc - (int64_t)k * plane);
+    const uint32_t j = r2 / (uint32_t)G.nx, i = r2 - j * (uint32_t)G.nx;
+    uint32_t a8[W];   // byte offset of the lane's entry inside a staged row of doubles, plus the offset of its j block
+#pragma unroll
+    for (int d = 0; d < W; ++d) {
+        const uint32_t va = L.vx[d * G.nx + i];
+        a8[d] = (va != 255u ? va : (uint32_t)(RBF_NV - 1)) * 8u + (j - (uint32_t)jA) * (uint32_t)(NT * RBF_NV * 8);
+    }
+    const uint32_t lane4 = lane * 4u;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(w + (tw0 - reach)), 0, (int)((2 * reach + 64) * 4), 0x00020000);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q0 = 0; q0 < NT; q0 += RBF_APPLY_BATCH) {
+        uint32_t wb[RBF_APPLY_BATCH];
+#pragma unroll
+        for (int u = 0; u < RBF_APPLY_BATCH; ++u) {
+            const int q = q0 + u < NT ? q0 + u : NT - 1;
+            const int dk = TO.dk[q], dj = TO.dj[q], di = TO.di[q];
+            const uint32_t xoff = (uint32_t)(reach + ((int64_t)(dk - R) * G.ny + (dj - R)) * G.nx + (di - R)) * 4u;
+            wb[u] = __builtin_amdgcn_raw_buffer_load_b32(rX, (int)lane4, (int)xoff, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < RBF_APPLY_BATCH; ++u) {
+            if (q0 + u >= NT) continue;
+            const double e = *(const double*)((const char*)sT + a8[TO.di[q0 + u]] + (uint32_t)((q0 + u) * RBF_NV * 8));
+            if (e != 0.0) acc = (float)((double)acc + (double)__uint_as_float(wb[u]) * e);
+        }
+    }
+    if (t < tend) out[t] = acc + add;
+}
+
 // does the run-time stencil visit the neighbours in the order the kernel above has compiled in?
 static bool rbf_stencil_is_canonical(const Stencil& S, int R, int D2)
 {
@@ -1315,7 +1413,11 @@ static bool launch_rbf_apply_lut(const RbfGeom& G, const RbfLutGeom& LG, const S
                                  float* out, int64_t t0 = 0, int64_t t1 = -1, int64_t xlo = 0, int64_t xhi = -1)
 {
     if (!LG.TA || !rbf_stencil_is_canonical(host_stencil, LG.R, LG.tap_d2)) return false;
-    if (LG.R == 2 && LG.tap_d2 == 7) rbf_apply_lut_kernel<2, 7><<<nb, 256, 0, st>>>(G, LG, w, tx, ty, tz, d_stencil, add, out, t0, t1, xlo, xhi);
+    const char* ap_env = getenv("R2S_RBF_APPLY");
+    const bool gathered = ap_env && !strcmp(ap_env, "lutg");   // table entries gathered from L1 / L2 (the tests compare)
+    if (LG.R == 2 && LG.tap_d2 == 7 && LG.TA16 && LG.nx >= 256 && tx == G.cx && ty == G.cy && tz == G.cz && !gathered)   // (nx >= 256: a workgroup spans <= 2 rows)
+        rbf_apply_lds_kernel<2, 7><<<nb, 256, 0, st>>>(G, LG, w, d_stencil, add, out, t0, t1, xlo, xhi);
+    else if (LG.R == 2 && LG.tap_d2 == 7) rbf_apply_lut_kernel<2, 7><<<nb, 256, 0, st>>>(G, LG, w, tx, ty, tz, d_stencil, add, out, t0, t1, xlo, xhi);
     else if (LG.R == 1 && LG.tap_d2 <= 3) rbf_apply_lut_kernel<1, 3><<<nb, 256, 0, st>>>(G, LG, w, tx, ty, tz, d_stencil, add, out, t0, t1, xlo, xhi);
     else if (LG.R == 2 && LG.tap_d2 <= 8) rbf_apply_lut_kernel<2, 8><<<nb, 256, 0, st>>>(G, LG, w, tx, ty, tz, d_stencil, add, out, t0, t1, xlo, xhi);
     else return false;
@@ -1515,7 +1617,7 @@ static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
 }
 
 struct RbfWork {   // the device buffers of one rbf_smooth_host call
-    DevBuf b[29];
+    DevBuf b[30];
     VolumeWork vw;
     void release()
     {
@@ -1544,7 +1646,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     DevBuf &d_sdf = W.b[0], &d_f = W.b[1], &d_w = W.b[2], &d_lsf = W.b[3], &d_fine = W.b[4], &d_cx = W.b[5], &d_cy = W.b[6], &d_cz = W.b[7],
            &d_tx = W.b[8], &d_ty = W.b[9], &d_tz = W.b[10], &d_st = W.b[11], &d_cnt = W.b[12], &d_r = W.b[13], &d_u = W.b[14], &d_q = W.b[15],
            &d_part = W.b[16], &d_sum = W.b[17], &d_lut = W.b[18], &d_luta = W.b[19], &d_vx = W.b[20], &d_vy = W.b[21], &d_vz = W.b[22],
-           &d_lutf = W.b[23], &d_fvx = W.b[24], &d_fvy = W.b[25], &d_fvz = W.b[26], &d_lv = W.b[27], &d_lvf = W.b[28];
+           &d_lutf = W.b[23], &d_fvx = W.b[24], &d_fvy = W.b[25], &d_fvz = W.b[26], &d_lv = W.b[27], &d_lvf = W.b[28], &d_luta16 = W.b[29];
     VolumeWork& vw = W.vw;
     auto cleanup = [&]() {
         if (!ws) W.release();
@@ -1687,6 +1789,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
                 ENSURE_C(d_luta, sizeof(double) * nTA);
                 rbf_lut_build_apply_kernel<<<(unsigned)((nTA + 255) / 256), 256, 0, st>>>(d_lv.as<RbfLutVals>(), d_luta.as<double>());
                 LG.TA = d_luta.as<double>();
+                if (mv_fits) {   // compact table for the kernel that stages its rows in LDS
+                    ENSURE_C(d_luta16, sizeof(double) * nT);
+                    rbf_lut_build_apply_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(d_lv.as<RbfLutVals>(), d_luta16.as<double>(), RBF_NV);
+                    LG.TA16 = d_luta16.as<double>();
+                }
             }
         }
     }
@@ -2202,7 +2309,7 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         lutf_axes = rbf_lut_axis(tx, cx, G0.tap_r, LVF.v[0], fix) && rbf_lut_axis(ty, cy, G0.tap_r, LVF.v[1], fiy) &&
                     rbf_lut_axis(tz, cz, G0.tap_r, LVF.v[2], fiz);
     }
-    SlabBufs blutf(S), bfvx(S), bfvy(S), bfvz(S), blv(S), blvf(S), bsegmn(S), bsegmx(S);
+    SlabBufs blutf(S), bfvx(S), bfvy(S), bfvz(S), blv(S), blvf(S), bsegmn(S), bsegmx(S), bluta16(S);
     SlabBufs bf(S), bw(S), br(S), bu(S), bq(S), blsf(S), bfine(S), bcx(S), bcy(S), bcz(S), btx(S), bty(S), btz(S), bst(S), bcnt(S),
         bpart(S), blut(S), bluta(S), bvx(S), bvy(S), bvz(S), brows(S);
     std::vector<RbfGeom> Gq(G, G0);
@@ -2274,6 +2381,11 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
                 SLAB_TRY(bluta.ensure(q, sizeof(double) * nTA));
                 rbf_lut_build_apply_kernel<<<(unsigned)((nTA + 255) / 256), 256, 0, d.stream>>>(blv.at<RbfLutVals>(q), bluta.at<double>(q));
                 LG[q].TA = bluta.at<double>(q);
+                if (mv_fits) {
+                    SLAB_TRY(bluta16.ensure(q, sizeof(double) * nT));
+                    rbf_lut_build_apply_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, d.stream>>>(blv.at<RbfLutVals>(q), bluta16.at<double>(q), RBF_NV);
+                    LG[q].TA16 = bluta16.at<double>(q);
+                }
             }
         }
         memset(&LGF[q], 0, sizeof(RbfLutGeom));

@@ -208,6 +208,32 @@ def test_rbf_tables_other_kernel_thresholds(pkg, oracle, monkeypatch, threshold)
 
 
 @pytest.mark.gpu
+def test_rbf_lds_kernels_on_a_wide_grid(pkg, monkeypatch):
+    """the kernels that stage their table rows in LDS need rows of >= 256 points (a workgroup of 256 consecutive rows then
+    spans at most two lattice rows): a 261 x 41 x 37 lattice with a banded synthetic SDF, CG + evaluation, against the
+    gathered-table kernels and neighbour-by-neighbour evaluation - bit for bit"""
+    g = pkg.Grid(np.array([0.013, -0.2, 0.07]), np.array([26.013, 3.8, 3.67]), 260, 0)
+    nx, ny, nz = g.dims
+    assert nx >= 256
+    ax = [g.AABB_min[i] + g.cell_size * np.arange(n) for i, n in enumerate((nx, ny, nz))]
+    r = np.sqrt(((ax[0][None, None, :] - 13.0) / 6.0) ** 2 + (ax[1][None, :, None] - 1.8) ** 2 + (ax[2][:, None, None] - 1.9) ** 2)
+    sdf = 1.3 - r
+    sdf = np.where(np.abs(sdf) < 6 * g.cell_size, sdf, np.sign(sdf) * 1e10).ravel()
+    target = float((sdf > 0).sum()) * g.cell_size ** 3
+    outs = {}
+    for mode in ("lut", "lutg", "fly"):
+        monkeypatch.setenv("R2S_RBF_MATVEC", mode)
+        monkeypatch.setenv("R2S_RBF_APPLY", mode)
+        info = {}
+        outs[mode] = (pkg.RBFs_smoothing(sdf, g, True, 1, target, info=info), info["cg_iterations"], info["th"], info["lsf"])
+    for mode in ("lutg", "fly"):
+        assert outs[mode][1] == outs["lut"][1] and outs[mode][2] == outs["lut"][2]
+        assert np.array_equal(outs[mode][0], outs["lut"][0]) and np.array_equal(outs[mode][3], outs["lut"][3])
+    assert outs["lut"][1] > 0 and np.isfinite(outs["lut"][0]).all()
+    pkg._lib.lib().r2s_release_cache()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("interp", [False, True])
 def test_rbf_evaluation_table_is_bit_identical(pkg, oracle, monkeypatch, interp):
     """same-grid evaluation (the LSF of the level bisection and the output field at smooth = 1) through the table of
@@ -217,10 +243,11 @@ def test_rbf_evaluation_table_is_bit_identical(pkg, oracle, monkeypatch, interp)
     vd, vf = oracle.mesh_volume(X, IEN, rho)
     pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
     outs = {}
-    for mode in ("lut", "fly"):
+    for mode in ("lut", "lutg", "fly"):   # lut: table rows staged in LDS where a workgroup spans <= 2 rows; lutg: gathered
         monkeypatch.setenv("R2S_RBF_APPLY", mode)
         info = {}
         outs[mode] = (pkg.RBFs_smoothing(sdf, pg, interp, 1, vd * vf, info=info), info["th"], info["lsf"])
-    assert outs["fly"][1] == outs["lut"][1]
-    assert np.array_equal(outs["fly"][0], outs["lut"][0]) and np.array_equal(outs["fly"][2], outs["lut"][2])
+    for mode in ("lutg", "fly"):
+        assert outs[mode][1] == outs["lut"][1]
+        assert np.array_equal(outs[mode][0], outs["lut"][0]) and np.array_equal(outs[mode][2], outs["lut"][2])
     assert np.isfinite(outs["lut"][0]).all() and np.ptp(outs["lut"][0]) > 0
