@@ -388,17 +388,26 @@ __global__ void face_mask_kernel(const int64_t* __restrict__ IEN, int64_t nel, c
     const int64_t el = gid / ET::NES;
     const int sg = (int)(gid % ET::NES);
     if (el >= nel || cls[el] == CLS_SKIP || *bad) return;   // bad: IEN holds ids outside 1..nnp, the call fails after this kernel
-    const int64_t n0 = IEN[el * ET::NEN + ET::face(sg, 0)] - 1;
+    // elements that hold all nodes of the face: the candidates are the elements of its first node; whether a candidate
+    // holds the other nodes is read off its own connectivity row (one contiguous row instead of a scan of the other
+    // nodes' element lists)
+    int64_t fn[ET::NSN];
+#pragma unroll
+    for (int a = 0; a < ET::NSN; ++a) fn[a] = IEN[el * ET::NEN + ET::face(sg, a)];
+    const int64_t n0 = fn[0] - 1;
     int common = 0;
     for (uint32_t p = ine_ptr[n0]; p < ine_ptr[n0 + 1]; ++p) {
-        const uint32_t e = ine[p];
+        const int64_t* __restrict__ row = IEN + (int64_t)ine[p] * ET::NEN;
+        int64_t rn[ET::NEN];
+#pragma unroll
+        for (int m = 0; m < ET::NEN; ++m) rn[m] = row[m];
         bool all = true;
-        for (int a = 1; a < ET::NSN && all; ++a) {
-            const int64_t na = IEN[el * ET::NEN + ET::face(sg, a)] - 1;
+#pragma unroll
+        for (int a = 1; a < ET::NSN; ++a) {
             bool found = false;
-            for (uint32_t q = ine_ptr[na]; q < ine_ptr[na + 1]; ++q)
-                if (ine[q] == e) { found = true; break; }
-            all = found;
+#pragma unroll
+            for (int m = 0; m < ET::NEN; ++m) found = found || rn[m] == fn[a];
+            all = all && found;
         }
         common += all ? 1 : 0;
     }
@@ -2190,6 +2199,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipEventRecord(P->ev2[1], P->st2));
     if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
         // bounding half-spaces for the sign pass: behind the element records, on the second stream
+        // (after the sign counts instead, they run beside the start of the projection kernel: 4.27 instead of 4.13 ms)
         HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[5], 0));
         hex_planes_kernel<<<(unsigned)((nel * 6 + 255) / 256), 256, 0, P->st2>>>(P->erec.as<ElemRec>(), nel);
         HIP_TRY(hipEventRecord(P->ev2[5], P->st2));   // from here on: "planes done"
@@ -2302,6 +2312,9 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             const uint32_t resident = (uint32_t)P->n_cu * 4u * wps - (uint32_t)std::min(std::max(free_env, 0), (int)P->n_cu * 4);
             const uint32_t group = std::min(4u, std::max(1u, n_chunks_e / (resident * 12u)));
             const uint32_t ngroups = (n_chunks_e + group - 1) / group;
+            // (the sign counts of the second stream first: when the persistent wavefronts arrive in the middle of those
+            //  kernels, one of them is left waiting until the projection kernel drains - 2 of 3 runs, +0.25 ms)
+            if (sign_items) HIP_TRY(hipStreamWaitEvent(st, P->ev2[7], 0));
             HIP_TRY(hipEventRecord(P->ev[7], st));
             iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
                 P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks_e, group, P->erec.as<ElemRec>(), g,
