@@ -1907,6 +1907,7 @@ struct r2s_plan {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // second stream: sentinel sweep + sign pass run beside the iso-surface projection (fused SDF output)
     hipStream_t st2 = nullptr;
+    hipStream_t st3 = nullptr;   // bounding half-spaces (hex_planes_kernel), beside the chains of the other two during preparation
     hipEvent_t ev2[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -2054,6 +2055,7 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         (void)prio_lo;
         HIP_TRY(hipStreamCreateWithPriority(&P->st2, hipStreamNonBlocking, prio_hi));
+        HIP_TRY(hipStreamCreateWithFlags(&P->st3, hipStreamNonBlocking));
     }
     *out = P;
     return 0;
@@ -2076,6 +2078,7 @@ void r2s_plan_destroy(r2s_plan* P)
     for (int i = 0; i < 8; ++i)
         if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
     if (P->st2) (void)hipStreamDestroy(P->st2);
+    if (P->st3) (void)hipStreamDestroy(P->st3);
     delete P;
 }
 
@@ -2198,11 +2201,13 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     }
     HIP_TRY(hipEventRecord(P->ev2[1], P->st2));
     if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
-        // bounding half-spaces for the sign pass: behind the element records, on the second stream
-        // (after the sign counts instead, they run beside the start of the projection kernel: 4.27 instead of 4.13 ms)
-        HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[5], 0));
-        hex_planes_kernel<<<(unsigned)((nel * 6 + 255) / 256), 256, 0, P->st2>>>(P->erec.as<ElemRec>(), nel);
-        HIP_TRY(hipEventRecord(P->ev2[5], P->st2));   // from here on: "planes done"
+        // bounding half-spaces for the sign pass: behind the element records, on a stream of their own (only sign_project
+        // needs them; on the second stream in front of the sign counts they delay the projection kernel's launch by their
+        // 43 us, after the sign counts they run beside its start: 4.27 instead of 4.13 ms)
+        HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[5], 0));   // element records (first stream) before the sign counts
+        HIP_TRY(hipStreamWaitEvent(P->st3, P->ev2[5], 0));
+        hex_planes_kernel<<<(unsigned)((nel * 6 + 255) / 256), 256, 0, P->st3>>>(P->erec.as<ElemRec>(), nel);
+        HIP_TRY(hipEventRecord(P->ev2[5], P->st3));   // from here on: "planes done"
     }
     // HEX8 sign pass: which tiles are hot, how long their candidate lists get and the boxes of the inverse maps depend on
     // the element records only - counted here on the second stream, beside the boundary-face test and the work items of
