@@ -967,7 +967,8 @@ R2S_DEV void process_triangle(VoxState& s, const BandItem& T, const Rec& E, doub
 // TET4
 // =====================================================================================
 // One pre-gathered TET4 element with the factorisations its per-voxel tests need.
-struct alignas(16) TetRec {
+// (three parts so that elem_prep_kernel can leave the middle one out for the 97 % of the elements that are no iso items)
+struct alignas(16) TetGeom {
     double X[4][3];
     double r[4];
     double mn[3];
@@ -981,8 +982,11 @@ struct alignas(16) TetRec {
     int32_t sing3, sing4;
     int32_t blo[3], bhi[3];  // 1-based bin range of create_grid_tetrahedra_mapping_TET4 (:191-192)
     int32_t pad;
-    // per-element constants of the iso-surface projection (tet4_iso_constants): inverse of the edge matrix,
-    // density gradient and its square, and per face the segment {rho = rho_t} n face (start, direction, length^2)
+};
+// per-element constants of the iso-surface projection (tet4_iso_constants): inverse of the edge matrix,
+// density gradient and its square, and per face the segment {rho = rho_t} n face (start, direction, length^2).
+// Only computed and stored for elements the iso-surface passes through (class ISO).
+struct alignas(16) TetIso {
     double Ai[3][3];
     double gr[3];
     double g2;
@@ -990,15 +994,18 @@ struct alignas(16) TetRec {
     double sab[4][3];
     double sab2[4];
     int32_t segok[4];
-    // unit outward face normals fn[f] with two offsets each (tet4_face_planes): fn[f].x > fo[f] => the barycentric
-    // coordinate of face f is below -1e-6, so is_point_in_tetrahedron (tolerance 1e-10, SignDetection.jl:220-242)
-    // rejects the point; fn[f].x < fi[f] for all four faces => every coordinate is above +1e-6 and it accepts it.
-    // Only the points in between (a 2e-6 shell around the faces) need the 4x4 solve.  fo = +inf, fi = -inf for
-    // degenerate or flat elements (height / longest edge < 1e-3), which always take the solve.
+};
+// unit outward face normals fn[f] with two offsets each (tet4_face_planes): fn[f].x > fo[f] => the barycentric
+// coordinate of face f is below -1e-6, so is_point_in_tetrahedron (tolerance 1e-10, SignDetection.jl:220-242)
+// rejects the point; fn[f].x < fi[f] for all four faces => every coordinate is above +1e-6 and it accepts it.
+// Only the points in between (a 2e-6 shell around the faces) need the 4x4 solve.  fo = +inf, fi = -inf for
+// degenerate or flat elements (height / longest edge < 1e-3), which always take the solve.
+struct alignas(16) TetPlanes {
     double fn[4][3];
     double fo[4];
     double fi[4];
 };
+struct alignas(16) TetRec : TetGeom, TetIso, TetPlanes {};
 
 __device__ const int c_tet_isn[4][3] = {{0, 2, 1}, {0, 1, 3}, {1, 2, 3}, {0, 3, 2}};
 

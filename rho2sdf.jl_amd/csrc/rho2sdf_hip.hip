@@ -257,13 +257,21 @@ struct HexT {
     using Rec = ElemRec;
     static constexpr int NEN = 8, NES = 6, NSN = 4;
     static __device__ __forceinline__ int face(int sg, int a) { return c_hex_isn[sg][a]; }
-    static __device__ void finish(Rec& R, const GridDev&, double) { hex8_monomials(R); hex8_newton0(R); }   // + hex_planes_kernel
+    static __device__ void finish(Rec& R, const GridDev&, double, bool) { hex8_monomials(R); hex8_newton0(R); }   // + hex_planes_kernel
+    static __device__ __forceinline__ void store(Rec& D, const Rec& R, bool) { D = R; }
 };
 struct TetT {
     using Rec = TetRec;
     static constexpr int NEN = 4, NES = 4, NSN = 3;
     static __device__ __forceinline__ int face(int sg, int a) { return c_tet_isn[sg][a]; }
-    static __device__ void finish(Rec& R, const GridDev& g, double rho_t)
+    // (iso: the iso-surface passes through the element - only then are the projection constants needed)
+    static __device__ __forceinline__ void store(Rec& D, const Rec& R, bool iso)
+    {
+        static_cast<TetGeom&>(D) = R;
+        if (iso) static_cast<TetIso&>(D) = R;
+        static_cast<TetPlanes&>(D) = R;
+    }
+    static __device__ void finish(Rec& R, const GridDev& g, double rho_t, bool iso)
     {
         double A[3][3], T[4][4];
         for (int i = 0; i < 3; ++i) {   // FindLocalCoordinates.jl:124: hcat(x2-x1, x3-x1, x4-x1)
@@ -290,7 +298,7 @@ struct TetT {
             R.bhi[ax] = (int32_t)fmax(b, -2.0e9);
         }
         R.pad = 0;
-        tet4_iso_constants(R, rho_t);
+        if (iso) tet4_iso_constants(R, rho_t);
         tet4_face_planes(R);
     }
 };
@@ -350,11 +358,11 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
             return;
         }
     }
-    ET::finish(R, g, rho_t);
-    erec[el] = R;
     int c = CLS_SKIP;
     if (rmin >= rho_t) c = CLS_SOLID;
     else if (rmax > rho_t) c = CLS_ISO;
+    ET::finish(R, g, rho_t, c == CLS_ISO);
+    ET::store(erec[el], R, c == CLS_ISO);
     cls[el] = (uint8_t)c;
     fmask[el] = 0u;
     nitems[el] = (c == CLS_ISO) ? 1u : 0u;   // + the boundary-face triangles, added by face_mask_kernel
