@@ -369,23 +369,19 @@ int orc_inv_map_hex8(const double x[3], const double *Xe_flat /* 8*3 */, double 
 /*     goes to the box corner that comes closest to meeting it;         */
 /*   - backtracking on the L1 merit f + mu |c|.                         */
 /* ------------------------------------------------------------------ */
-#ifdef ORC_TIGHT
-#define ISO_MAXIT 400
-#else
-#define ISO_MAXIT 60
-#endif
-/* Step tolerance.  The iteration ends AFTER applying a step below it; with the exact Lagrangian Hessian the steps
- * shrink quadratically, so the final iterate is within ~1e-12 of the minimiser (1e-8 only added an iteration that
- * confirmed a step of ~1e-15: 4.26 -> 3.94 iterations per pair on the north-star mesh).  Measured against 1e-8 on
- * 149 000 pairs: largest relative change of a distance 3.3e-10, xi moves by more than 1e-9 in 2 pairs (linearly
- * converging Gauss-Newton cases on degenerate faces, where the distance is flat).  The reference stops its SLSQP at
- * xtol_rel = ftol_rel = 1e-5 (ComputeCoordsOnIso.jl:20-22). */
+#define ISO_MAXIT 200
+/* Step tolerance.  The iteration ends AFTER applying a step below it, and only a step of the CONVEX mode (exact
+ * Lagrangian Hessian positive definite on the face the QP ends on) may end it: those steps shrink quadratically, so
+ * the final iterate is within ~tol^2 of the minimiser.  (Round 2 also ended on small Gauss-Newton steps, which
+ * converge linearly - up to 1000 x the step away from the limit - and towards saddle points.)  The reference stops
+ * its SLSQP at xtol_rel = ftol_rel = 1e-5 (ComputeCoordsOnIso.jl:20-22). */
 #ifdef ORC_TIGHT
 #define ISO_TOL 1e-12
 #else
 #define ISO_TOL 1e-6
 #endif
 #define QP_PTOL 1e-12
+#define ISO_MAX_RESTORE 3
 
 typedef struct {
     double f, c;
@@ -408,7 +404,8 @@ static int qp_pattern(int pat, const double H[3][3], const double g[3], const do
                       double e, const double lo[3], const double hi[3], double d[3],
                       double *lam_out, double *q_out, int *kkt_out, int *next_pat)
 {
-    /* returns 0: pattern unusable, 2: primal infeasible, 1: primal feasible (kkt_out tells optimality);
+    /* returns 0: pattern unusable (the matrix is not positive definite on this face: its stationary point is no
+     * minimiser), 2: primal infeasible, 1: primal feasible (kkt_out tells optimality);
      * next_pat: the pattern an active-set step would try next (fix the most violated free variable /
      * release the fixed variable with the worst multiplier), -1 if none */
     static const int pw[3] = {1, 3, 9};
@@ -452,8 +449,12 @@ static int qp_pattern(int pat, const double H[3][3], const double g[3], const do
     v[1] = dot3(c01, c11, c12, b[0], b[1], b[2]) * rdet;
     v[2] = dot3(c02, c12, c22, b[0], b[1], b[2]) * rdet;
     double den = dot3(aa[0], aa[1], aa[2], u[0], u[1], u[2]);
-    if (!(den > 0.0)) return 0;
-    double lam = (dot3(aa[0], aa[1], aa[2], v[0], v[1], v[2]) - ep) / den;
+    /* vacuous equality: the constraint gradient has no component along the free variables (rho is constant on this
+     * face of the element - an iso-surface that coincides with an element face, as on 0/1 density fields).  The face
+     * problem is then unconstrained if the fixed variables meet the equality, infeasible otherwise. */
+    const int vac = (aa[0] == 0.0 && aa[1] == 0.0 && aa[2] == 0.0);
+    if (vac ? (ep != 0.0) : !(den > 0.0)) return 0;
+    double lam = vac ? 0.0 : (dot3(aa[0], aa[1], aa[2], v[0], v[1], v[2]) - ep) / den;
     int ok = 1;
     double worst = 0.0;
     for (int i = 0; i < 3; ++i) {
@@ -487,7 +488,7 @@ static int qp_pattern(int pat, const double H[3][3], const double g[3], const do
     int kkt = 1;
     worst = 0.0;
     for (int i = 0; i < 3; ++i) {
-        if (s[i]) {
+        if (s[i] && !(vac && a[i] != 0.0)) { /* (vacuous equality: its multiplier is free and absorbs z) */
             double z = fma(lam, a[i], Hd[i] + g[i]);
             double viol = (s[i] == 1) ? -z : z;
             if (s[i] == 1 && !(z >= 0.0)) kkt = 0;
@@ -512,6 +513,53 @@ static int spd3(const double H[3][3], double floor_)
     return (H[0][0] > floor_) && (m2 > floor_) && (det > floor_);
 }
 
+/* per-call statistics of the solver (research / tests: orc_iso_project_hex8_batch) */
+typedef struct {
+    int it, nonconvex, corner, restore, backtrack, reject, code; /* code 1: converged, 2: flat, 3: failed */
+} iso_stats;
+static iso_stats g_iso_stats;
+
+/* Restoration: the linearised constraint cannot be met anywhere in the element (|xi| <= 1), so first-order steps
+ * cannot reach the iso-surface from here (it only clips a corner region of the element, or the density has a saddle at
+ * the iterate).  An iso element has nodes on either side of the threshold; along the straight segment from the iterate
+ * to a node k on the OTHER side, rho - rho_t (a cubic in the segment parameter) changes sign, so the segment holds a
+ * feasible point: bracketed Newton finds the first root for every such node and the candidate with the smallest
+ * distance to x becomes the new iterate (ties: lowest node).  Returns 0 if no node lies on the other side. */
+static int iso_restore(const double x[3], const double Xe[16][3], const double re[16], double rt,
+                       const double xi[3], double c, double out[3])
+{
+    double bestf = INFINITY;
+    int found = 0;
+    for (int k = 0; k < 8; ++k) {
+        const double nd[3] = {(k & 1) ? 1.0 : -1.0, (k & 2) ? 1.0 : -1.0, (k & 4) ? 1.0 : -1.0};
+        const double ck = tri_eval_value(&re[8], 1, nd) - rt;
+        if ((c < 0.0) ? !(ck >= 0.0) : !(ck <= 0.0)) continue;
+        const double dir[3] = {nd[0] - xi[0], nd[1] - xi[1], nd[2] - xi[2]};
+        /* phi(t) = rho(xi + t dir) - rt, phi(0) = c, phi(1) = ck: signs differ (or ck = 0) */
+        double tl = 0.0, th = 1.0, t = 1.0, p[3] = {nd[0], nd[1], nd[2]};
+        if (ck != 0.0) {
+            t = 0.5;
+            for (int n = 0; n < 100; ++n) {
+                for (int i = 0; i < 3; ++i) p[i] = fma(t, dir[i], xi[i]);
+                const tri_eval tr = tri_eval_full(&re[8], 1, p);
+                const double ph = tr.v - rt;
+                if (ph == 0.0) break;
+                if ((ph < 0.0) == (c < 0.0)) tl = t; else th = t;
+                if (!(th - tl > 1e-15)) break;
+                const double dph = dot3(tr.d1, tr.d2, tr.d3, dir[0], dir[1], dir[2]);
+                double tn = t - ph / dph;
+                if (!(tn > tl && tn < th)) tn = 0.5 * (tl + th);
+                if (tn == t) break;
+                t = tn;
+            }
+            for (int i = 0; i < 3; ++i) p[i] = fmin(fmax(fma(t, dir[i], xi[i]), -1.0), 1.0);
+        }
+        const iso_fc fc = iso_eval_fc(x, Xe, re, rt, p);
+        if (fc.f < bestf) { bestf = fc.f; found = 1; out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; }
+    }
+    return found;
+}
+
 /* returns number of iterations used (ISO_MAXIT+1 if not converged) */
 static int iso_project_hex8(const double x[3], const double Xe[16][3], const double re[16], double rt, double xi[3]);
 int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, const double re_in[8],
@@ -526,12 +574,28 @@ int orc_iso_project_hex8(const double x[3], const double *Xe_flat /* 8*3 */, con
     return iso_project_hex8(x, Xe, re, rt, xi);
 }
 
+/* n independent (point, element) problems; stats: 7 ints per problem (iso_stats) or NULL */
+void orc_iso_project_hex8_batch(int64_t n, const double *x /* n*3 */, const double *Xe_flat /* n*8*3 */,
+                                const double *re_in /* n*8 */, const double *rt /* n */, double *xi /* n*3 */,
+                                int *stats /* n*7 or NULL */)
+{
+    for (int64_t p = 0; p < n; ++p) {
+        orc_iso_project_hex8(x + 3 * p, Xe_flat + 24 * p, re_in + 8 * p, rt[p], xi + 3 * p);
+        if (stats) memcpy(stats + 7 * p, &g_iso_stats, sizeof(iso_stats));
+    }
+}
+
 /* the solver proper; Xe/re carry the monomial coefficients in rows 8..15 */
 static int iso_project_hex8(const double x[3], const double Xe[16][3], const double re[16], double rt, double xi[3])
 {
     xi[0] = xi[1] = xi[2] = 0.0;
     double mu = 0.0, lam = 0.0, Delta = 2.0;
-    int pat = 0, restarted = 0;
+    int pat = 0, nrest = 0;
+    iso_stats st = {0, 0, 0, 0, 0, 0, 3};
+    double rtol = fabs(rt);
+    for (int k = 0; k < 8; ++k) rtol = fmax(rtol, fabs(re[k]));
+    rtol *= 1e-14;
+    double fbest = INFINITY, xbest[3] = {0.0, 0.0, 0.0};
     for (int it = 0; it < ISO_MAXIT; ++it) {
         double r[3], J[3][3], a[3], g[3], G[3][3], M2[3][3]; /* M2[i][q]: mixed derivatives of p_i */
         for (int i = 0; i < 3; ++i) {
@@ -544,10 +608,26 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
         tri_eval tr = tri_eval_full(&re[8], 1, xi);
         double c = tr.v - rt;
         a[0] = tr.d1; a[1] = tr.d2; a[2] = tr.d3;
+        /* rounding residue of the density field counts as zero: a constraint value or a gradient component of
+         * ~1e-16 (an iso-surface that runs along an element face) must not decide corner steps or multipliers */
+        if (fabs(c) <= rtol) c = 0.0;
+        for (int j = 0; j < 3; ++j)
+            if (fabs(a[j]) <= rtol) a[j] = 0.0;
+        /* the nearest iterate ON the iso-surface so far: what a run that fails hands back */
+        if (c == 0.0 && f < fbest) { fbest = f; xbest[0] = xi[0]; xbest[1] = xi[1]; xbest[2] = xi[2]; }
         for (int j = 0; j < 3; ++j) g[j] = -2.0 * dot3(r[0], r[1], r[2], J[0][j], J[1][j], J[2][j]);
         for (int i = 0; i < 3; ++i)
             for (int j = i; j < 3; ++j)
                 G[i][j] = G[j][i] = 2.0 * dot3(J[0][i], J[1][i], J[2][i], J[0][j], J[1][j], J[2][j]);
+        /* warm-start pattern: a variable the last QP fixed stays fixed only if it sits on the element's own bound
+         * now (a bound of the trust region says nothing about the next QP) */
+        {
+            const int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+            pat = 0;
+            if ((s[0] == 1 && xi[0] == -1.0) || (s[0] == 2 && xi[0] == 1.0)) pat += s[0];
+            if ((s[1] == 1 && xi[1] == -1.0) || (s[1] == 2 && xi[1] == 1.0)) pat += 3 * s[1];
+            if ((s[2] == 1 && xi[2] == -1.0) || (s[2] == 2 && xi[2] == 1.0)) pat += 9 * s[2];
+        }
         /* multiplier estimate for the Hessian: least squares over the variables
          * that were free in the last QP solution */
         {
@@ -578,98 +658,128 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
         double trG = G[0][0] + G[1][1] + G[2][2];
         double aa2 = dot3(a[0], a[1], a[2], a[0], a[1], a[2]);
         double sigma = 100.0 * trG / aa2;
-        int use_exact = 1, corner = 0, stop = 0; (void)use_exact;
-        double lam_new = lam, alpha = 1.0;
+        int convex = 1, corner = 0, stop = 0, stall = 0;
+        /* the penalty parameter of the merit function may shrink (towards twice the multiplier) only where the
+         * constraint is nearly met: halving it at infeasible iterates let a step that trades feasibility for distance
+         * undo the feasibility step before it (2-cycles between a box corner and the point it was reached from) */
+        const int near_feas = (fabs(c) <= 1e4 * rtol);
+        const double mu_keep = near_feas ? 0.5 : 1.0;
+        double lam_new = lam, alpha = 1.0, qstep = 0.0;
         double dGd = 0.0; /* curvature of f along a corner step (penalty parameter below) */
-        if (e >= mplus) {
+        if (e > mplus) {
             for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
             corner = 1;
-        } else if (e <= mminus) {
+        } else if (e < mminus) {
             for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
             corner = 1;
         }
         if (corner) {
+            /* how much of the constraint violation the linear model can remove anywhere in the element: next to
+             * nothing means that first-order steps are stuck (the density has a stationary point here or the
+             * iso-surface only clips a corner region the gradient does not point to) - straight to the restoration.
+             * The test does not depend on the stopping tolerance. */
+            double bp = 0.0, bm = 0.0;
+            for (int i = 0; i < 3; ++i) {
+                const double p = a[i] * (-1.0 - xi[i]), q = a[i] * (1.0 - xi[i]);
+                bp += fmax(p, q);
+                bm += fmin(p, q);
+            }
+            if ((e > 0.0) ? !(bp > 0.05 * e) : !(bm < 0.05 * e)) stall = 1;
             double Gd[3];
             for (int i = 0; i < 3; ++i) Gd[i] = dot3(G[i][0], G[i][1], G[i][2], d[0], d[1], d[2]);
             dGd = dot3(d[0], d[1], d[2], Gd[0], Gd[1], Gd[2]);
         } else {
-            /* convexified QP data: H' = H + sigma a a^T, g' = g - sigma e a (identical to (H,g) on
-             * the plane a.d = e).  Exact Lagrangian Hessian when H' is positive definite, else
-             * Gauss-Newton (always positive definite): the QP is strictly convex either way. */
-            double H[3][3], Hgn[3][3], gp[3];   /* both symmetric by construction */
-            const double se = sigma * e;
-            for (int i = 0; i < 3; ++i) {
-                const double sa = sigma * a[i];
-                for (int j = i; j < 3; ++j) Hgn[i][j] = Hgn[j][i] = fma(sa, a[j], G[i][j]);
-                gp[i] = fma(-se, a[i], g[i]);
-            }
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) H[i][j] = Hgn[i][j];
-            H[0][1] += S[0]; H[1][0] = H[0][1];
-            H[0][2] += S[1]; H[2][0] = H[0][2];
-            H[1][2] += S[2]; H[2][1] = H[1][2];
-            /* positive definite where the QP is going to be solved first: on the face of the box the last QP ended
-             * on (warm-start pattern).  Testing the whole 3x3 matrix sent iterates that sit on a face to the
-             * Gauss-Newton matrix although the exact one is definite along the face, and Gauss-Newton only converges
-             * linearly there (ratio ~ -0.9: 60 iterations and still 1e-5 away). */
-            double Hm[3][3];
-            {
+            /* QP data with the EXACT Lagrangian Hessian, convexified along the constraint normal:
+             * H = G + S + sigma a a^T, g' = g - sigma e a (identical to (G + S, g) on the plane a.d = e; positive
+             * definite on a face of the box exactly when G + S is positive definite on that face cut with the plane,
+             * provided sigma is large enough).  sigma = 100 tr(G) / |a|^2 first; where the matrix is not positive
+             * definite with it the test is repeated with 100 times that before the model is declared non-convex
+             * (weak constraint gradients - an iso-surface close to an element face - come with large multipliers, and
+             * then lam d2rho outgrows 100 tr(G)). */
+            double H[3][3], gp[3];
+            int stage = 0;
+            double sg = sigma;
+            for (;;) {
+                const double se = sg * e;
+                for (int i = 0; i < 3; ++i) {
+                    const double sa = sg * a[i];
+                    for (int j = i; j < 3; ++j) H[i][j] = H[j][i] = fma(sa, a[j], G[i][j]);
+                    gp[i] = fma(-se, a[i], g[i]);
+                }
+                H[0][1] += S[0]; H[1][0] = H[0][1];
+                H[0][2] += S[1]; H[2][0] = H[0][2];
+                H[1][2] += S[2]; H[2][1] = H[1][2];
+                /* convex mode while the matrix is positive definite on the faces the active-set walk visits, starting
+                 * with the face of the box the last QP ended on (warm-start pattern) */
+                double Hm[3][3];
                 const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
                 for (int i = 0; i < 3; ++i)
                     for (int j = 0; j < 3; ++j) Hm[i][j] = (sp[i] || sp[j]) ? ((i == j) ? 1.0 : 0.0) : H[i][j];
-            }
-            if (!spd3(Hm, 0.0)) {
-                use_exact = 0;
-                for (int i = 0; i < 3; ++i)
-                    for (int j = 0; j < 3; ++j) H[i][j] = Hgn[i][j];
+                convex = spd3(Hm, 0.0);
+                if (convex || stage) break;
+                stage = 1;
+                sg = 100.0 * sigma;
             }
             double q, dd[3], l2;
             int kkt, found = 0, nxt;
-            {
+            if (convex) {
                 /* active-set walk from the previous pattern: the first pattern that is primal
-                 * feasible and satisfies KKT is the minimiser of the strictly convex QP */
+                 * feasible and satisfies KKT is the minimiser of the QP when it is convex on the faces seen */
                 int p = pat;
                 for (int step = 0; step < 8 && p >= 0; ++step) {
                     int rc = qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt);
-                    if (rc == 0 && use_exact) {
-                        /* the walk left the warm-start face for one on which the exact matrix is not positive
-                         * definite: this iteration continues with Gauss-Newton, from the warm-start pattern */
-                        use_exact = 0;
-                        for (int i = 0; i < 3; ++i)
-                            for (int j = 0; j < 3; ++j) H[i][j] = Hgn[i][j];
+                    if (rc == 0 && !stage) {
+                        /* the walk left the warm-start face for one on which the matrix is not positive definite:
+                         * once more with the larger sigma, from the warm-start pattern */
+                        stage = 1;
+                        sg = 100.0 * sigma;
+                        const double se = sg * e;
+                        for (int i = 0; i < 3; ++i) {
+                            const double sa = sg * a[i];
+                            for (int j = i; j < 3; ++j) H[i][j] = H[j][i] = fma(sa, a[j], G[i][j]);
+                            gp[i] = fma(-se, a[i], g[i]);
+                        }
+                        H[0][1] += S[0]; H[1][0] = H[0][1];
+                        H[0][2] += S[1]; H[2][0] = H[0][2];
+                        H[1][2] += S[2]; H[2][1] = H[1][2];
                         p = pat;
                         step = -1;
                         continue;
                     }
-                    if (rc == 0) break;
+                    if (rc == 0) { convex = 0; break; }
                     if (rc == 1 && kkt) {
                         found = 1;
                         pat = p;
                         d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
                         lam_new = l2;
+                        qstep = q;
                         break;
                     }
                     p = nxt;
                 }
             }
             if (!found) {
-                /* exhaustive fallback: patterns with 0, 1, 2 fixed variables (3 fixed cannot meet
-                 * the equality); first KKT pattern, failing that (rounding) the feasible one of
-                 * least value */
+                /* exhaustive search over the patterns with 0, 1, 2 fixed variables (3 fixed cannot meet the
+                 * equality).  Convex: first KKT pattern, failing that (rounding) the feasible one of least value.
+                 * Not convex: the stationary points of the faces on which the matrix is positive definite (the
+                 * others are no minimisers of their face: the minimum then lies on the face's boundary, which the
+                 * patterns with one more fixed variable cover) - the one of least value is the global minimiser of
+                 * the QP over the box cut with the trust region. */
                 static const int order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8,
                                               10, 11, 19, 20, 12, 15, 21, 24};
                 double bestq = INFINITY;
                 for (int ip = 0; ip < 19; ++ip) {
                     const int p = order[ip];
                     if (qp_pattern(p, H, gp, a, e, lo, hi, dd, &l2, &q, &kkt, &nxt) == 1) {
-                        if (kkt || q < bestq) {
+                        if ((convex && kkt) || q < bestq) {
                             bestq = q;
                             found = 1;
                             pat = p;
                             d[0] = dd[0]; d[1] = dd[1]; d[2] = dd[2];
                             lam_new = l2;
+                            qstep = q;
                         }
-                        if (kkt) break;
+                        if (convex && kkt) break;
                     }
                 }
             }
@@ -678,77 +788,134 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
                     d[i] = (e > 0.0) ? ((a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0))
                                      : ((a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0));
                 corner = 1;
+                convex = 1;
             }
             for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
         }
-        {
-            double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
-            if (!(dmax > ISO_TOL)) { /* converged (or stuck at an infeasible corner) */
-                stop = corner ? 2 : 1;
-            } else {
-                double ad = dot3(a[0], a[1], a[2], d[0], d[1], d[2]);
-                double pred_c = fabs(c) - fabs(c + ad);
-                double gd = dot3(g[0], g[1], g[2], d[0], d[1], d[2]);
-                double mu_t = corner ? mu : fmax(0.5 * mu, 2.0 * fabs(lam_new));
-                if (corner && pred_c > 0.0) {
-                    /* The linearised constraint cannot be met inside the trust region: the step only buys
-                     * feasibility, and the merit function has to pay for the growth of f it causes including its
-                     * curvature (mu >= (g.d + d.G.d / 2) / ((1 - 1/2) pred_c), Nocedal & Wright (18.36)).  With the
-                     * first-order part alone the line search cut such steps down to ~1e-3 and elements that the
-                     * iso-surface only clips near a corner ended the 60 iterations far from the surface. */
-                    const double need = 2.0 * fma(0.5, dGd, gd) / pred_c;
-                    if (need > mu_t) mu_t = need;
-                }
-                if (!(fma(-mu_t, pred_c, gd) < 0.0)) {
-                    if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
-                    else stop = 2; /* no descent on the merit function */
-                }
-                if (!stop) {
-                    mu = mu_t;
-                    double D = fma(-mu, pred_c, gd);
-                    double phi0 = fma(mu, fabs(c), f);
-                    for (int ls = 0; ls < 30; ++ls) {
-                        double xt[3];
-                        for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(fma(alpha, d[i], xi[i]), -1.0), 1.0);
-                        iso_fc t = iso_eval_fc(x, Xe, re, rt, xt);
-                        if (fma(mu, fabs(t.c), t.f) <= fma(1e-4 * alpha, D, phi0)) break;
-                        alpha *= 0.5;
+        st.corner += corner;
+        st.nonconvex += !convex;
+        const double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+        const double ad = dot3(a[0], a[1], a[2], d[0], d[1], d[2]);
+        const double pred_c = fabs(c) - fabs(c + ad);
+        if (stall) {
+            stop = 2;
+        } else if (!convex) {
+            /* Trust-region step of the non-convex model (negative curvature of the Lagrangian along the iso-surface:
+             * the iterate is near a saddle point or a maximum of the distance).  One trial at the full step, accepted
+             * on actual against predicted reduction of the L1 merit function; a rejected step shrinks the region. */
+            double mu_t = fmax(mu_keep * mu, 2.0 * fabs(lam_new));
+            double pred = fma(mu_t, pred_c, -qstep);
+            if (!(pred > 0.0)) {
+                if (pred_c > 0.0) { mu_t = 2.0 * qstep / pred_c; pred = qstep; }
+                else stop = near_feas ? 3 : 2; /* feasible and the model offers no decrease: second-order point */
+            }
+            if (!stop && !(pred > 1e-14 * f)) stop = 3; /* no negative curvature worth a step: second-order point */
+            if (!stop) {
+                mu = mu_t;
+                double xt[3];
+                for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + d[i], -1.0), 1.0);
+                iso_fc t = iso_eval_fc(x, Xe, re, rt, xt);
+                const double phi0 = fma(mu, fabs(c), f);
+                if (!(phi0 - fma(mu, fabs(t.c), t.f) >= 1e-4 * pred)) {
+                    /* second-order correction (see the convex mode below), then rejection */
+                    const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+                    double den = 0.0, d2[3] = {d[0], d[1], d[2]};
+                    int ok = 0;
+                    for (int i = 0; i < 3; ++i)
+                        if (!sp[i]) den = fma(a[i], a[i], den);
+                    if (den > 0.0) {
+                        const double sc = -t.c / den;
+                        for (int i = 0; i < 3; ++i) {
+                            if (!sp[i]) d2[i] = fma(sc, a[i], d[i]);
+                            xt[i] = fmin(fmax(xi[i] + d2[i], -1.0), 1.0);
+                        }
+                        iso_fc t2 = iso_eval_fc(x, Xe, re, rt, xt);
+                        ok = (phi0 - fma(mu, fabs(t2.c), t2.f) >= 1e-4 * pred);
                     }
+                    if (ok) { d[0] = d2[0]; d[1] = d2[1]; d[2] = d2[2]; }
+                    else { alpha = 0.0; st.reject++; }
+                }
+            }
+        } else if (!(dmax > ISO_TOL)) { /* converged (a feasible vertex of the box counts), or stuck at an infeasible corner */
+            stop = (corner && !near_feas) ? 2 : 1;
+        } else {
+            double gd = dot3(g[0], g[1], g[2], d[0], d[1], d[2]);
+            double mu_t = corner ? mu : fmax(mu_keep * mu, 2.0 * fabs(lam_new));
+            if (corner && pred_c > 0.0) {
+                /* The linearised constraint cannot be met inside the trust region: the step only buys
+                 * feasibility, and the merit function has to pay for the growth of f it causes including its
+                 * curvature (mu >= (g.d + d.G.d / 2) / ((1 - 1/2) pred_c), Nocedal & Wright (18.36)). */
+                const double need = 2.0 * fma(0.5, dGd, gd) / pred_c;
+                if (need > mu_t) mu_t = need;
+            }
+            if (!(fma(-mu_t, pred_c, gd) < 0.0)) {
+                if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
+                else stop = (near_feas && !corner) ? 4 : 2; /* no descent on the merit function; from a feasible
+                                                            * point: the QP step is rounding noise - converged */
+            }
+            if (!stop) {
+                mu = mu_t;
+                double D = fma(-mu, pred_c, gd);
+                double phi0 = fma(mu, fabs(c), f);
+                for (int ls = 0; ls < 30; ++ls) {
+                    double xt[3];
+                    for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(fma(alpha, d[i], xi[i]), -1.0), 1.0);
+                    iso_fc t = iso_eval_fc(x, Xe, re, rt, xt);
+                    if (fma(mu, fabs(t.c), t.f) <= fma(1e-4 * alpha, D, phi0)) break;
+                    if (ls == 0 && !corner) {
+                        /* second-order correction: the full step fails on the curvature of the iso-surface (the merit
+                         * function sees rho leave rho_t by O(|d|^2)); the least-norm move of the free variables that
+                         * cancels rho(xi + d) - rho_t to first order is added and the trial repeated (Maratos effect:
+                         * without it steps along a strongly curved iso-surface shrink to ~1e-4 and crawl) */
+                        const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+                        double den = 0.0;
+                        for (int i = 0; i < 3; ++i)
+                            if (!sp[i]) den = fma(a[i], a[i], den);
+                        if (den > 0.0) {
+                            const double sc = -t.c / den;
+                            double d2[3];
+                            for (int i = 0; i < 3; ++i) {
+                                d2[i] = sp[i] ? d[i] : fma(sc, a[i], d[i]);
+                                xt[i] = fmin(fmax(xi[i] + d2[i], -1.0), 1.0);
+                            }
+                            iso_fc t2 = iso_eval_fc(x, Xe, re, rt, xt);
+                            if (fma(mu, fabs(t2.c), t2.f) <= fma(1e-4, D, phi0)) {
+                                d[0] = d2[0]; d[1] = d2[1]; d[2] = d2[2];
+                                st.reject++; /* (counted as corrected steps in convex mode) */
+                                break;
+                            }
+                        }
+                    }
+                    alpha *= 0.5;
+                    st.backtrack++;
                 }
             }
         }
-        {
-            double dm = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
-            Delta = (alpha < 1.0) ? alpha * dm : fmin(2.0, fmax(Delta, 2.0 * dm));
-        }
+        Delta = (alpha < 1.0) ? ((alpha > 0.0) ? alpha * dmax : 0.25 * dmax) : fmin(2.0, fmax(Delta, 2.0 * dmax));
 #ifdef ISO_DEBUG
-        printf("it %d xi %.6f %.6f %.6f f %.3e c %.3e d %.3e %.3e %.3e alpha %.3e pat %d corner %d ex %d lam %.3e mu %.3e\n",
-               it, xi[0], xi[1], xi[2], f, c, d[0], d[1], d[2], alpha, pat, corner, use_exact, lam, mu);
+        printf("it %d xi %.6f %.6f %.6f f %.3e c %.3e d %.3e %.3e %.3e alpha %.3e pat %d corner %d cvx %d lam %.3e mu %.3e stop %d\n",
+               it, xi[0], xi[1], xi[2], f, c, d[0], d[1], d[2], alpha, pat, corner, convex, lam, mu, stop);
 #endif
+        st.it = it + 1;
         if (stop == 2) {
-            if (!restarted && fabs(c) > 1e-10) {
-                /* Stuck at a point that does not satisfy the constraint (the local linearisations led into a
-                 * corner of the element where rho never reaches rho_t) although the element holds the iso-surface
-                 * elsewhere: one more attempt, from half-way to the node whose density lies farthest on the other
-                 * side of the threshold.  On the reference's own meshes this rescues 40 % (chapadlo) to 90 %
-                 * (cantilever beam) of the projections that ended infeasible. */
-                double best = -INFINITY;
-                int kb = 0;
-                for (int k = 0; k < 8; ++k) {
-                    const double xc[3] = {(k & 1) ? 1.0 : -1.0, (k & 2) ? 1.0 : -1.0, (k & 4) ? 1.0 : -1.0};
-                    const double rk = tri_eval_value(&re[8], 1, xc);
-                    const double score = (c < 0.0) ? rk : -rk;
-                    if (score > best) { best = score; kb = k; }
-                }
-                xi[0] = (kb & 1) ? 0.5 : -0.5; xi[1] = (kb & 2) ? 0.5 : -0.5; xi[2] = (kb & 4) ? 0.5 : -0.5;
-                mu = 0.0; Delta = 2.0; pat = 0; restarted = 1;
+            /* no descent / stuck at a point that does not satisfy the constraint */
+            double xr[3];
+            if (!near_feas && nrest < ISO_MAX_RESTORE && iso_restore(x, Xe, re, rt, xi, c, xr)) {
+                st.restore++;
+                xi[0] = xr[0]; xi[1] = xr[1]; xi[2] = xr[2];
+                mu = 0.0; Delta = 2.0; pat = 0; nrest++;
                 continue;
             }
+            g_iso_stats = st;
+            if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
             return ISO_MAXIT + 1;
         }
+        if (stop == 3 || stop == 4) { st.code = (stop == 3) ? 2 : 1; g_iso_stats = st; return it + 1; }
         for (int i = 0; i < 3; ++i) xi[i] = fmin(fmax(fma(alpha, d[i], xi[i]), -1.0), 1.0);
-        if (stop == 1) return it + 1;
+        if (stop == 1) { st.code = 1; g_iso_stats = st; return it + 1; }
     }
+    g_iso_stats = st;
+    if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
     return ISO_MAXIT + 1;
 }
 
