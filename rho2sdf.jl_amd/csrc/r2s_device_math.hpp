@@ -441,8 +441,11 @@ R2S_DEV int qp_pattern(int pat, const Sym3& H, const double g[3], const double a
     v[1] = dot3(c01, c11, c12, b[0], b[1], b[2]) * rdet;
     v[2] = dot3(c02, c12, c22, b[0], b[1], b[2]) * rdet;
     double den = dot3(aa[0], aa[1], aa[2], u[0], u[1], u[2]);
-    if (!(den > 0.0)) return 0;
-    double lam = (dot3(aa[0], aa[1], aa[2], v[0], v[1], v[2]) - ep) / den;
+    // vacuous equality: the constraint gradient has no component along the free variables (rho is constant on this
+    // face of the element); the face problem is unconstrained if the fixed variables meet the equality (see the oracle)
+    const bool vac = (aa[0] == 0.0 && aa[1] == 0.0 && aa[2] == 0.0);
+    if (vac ? (ep != 0.0) : !(den > 0.0)) return 0;
+    double lam = vac ? 0.0 : (dot3(aa[0], aa[1], aa[2], v[0], v[1], v[2]) - ep) / den;
     bool ok = true;
     double worst = 0.0;
     const int pw[3] = {1, 3, 9};
@@ -481,7 +484,7 @@ R2S_DEV int qp_pattern(int pat, const Sym3& H, const double g[3], const double a
     worst = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        if (s[i]) {
+        if (s[i] && !(vac && a[i] != 0.0)) {
             const double z = fma(lam, a[i], Hd[i] + g[i]);
             const double viol = (s[i] == 1) ? -z : z;
             if (s[i] == 1 && !(z >= 0.0)) kkt = false;
@@ -520,32 +523,381 @@ R2S_DEV void iso_eval_fc(const ER& E, const double x[3], double rt, const double
     c = rho - rt;
 }
 
-#define R2S_QP_WALK 8   // active-set steps before the exhaustive fallback
-#define R2S_ISO_MAXIT 60
-#define R2S_ISO_TOL 1e-6   // = the oracle's ISO_TOL (see the note there)
+#define R2S_QP_WALK 8       // active-set steps before the exhaustive search
+#define R2S_ISO_MAXIT 200   // = the oracle's ISO_MAXIT
+#define R2S_ISO_TOL 1e-6    // = the oracle's ISO_TOL (see the note there)
+#define R2S_ISO_MAX_RESTORE 3
 
-// ---- the SQP as a per-lane state machine ---------------------------------------------
-// The oracle's iso_project_hex8 (oracle/r2s_oracle.c) cut into phases so that the lanes of a wavefront can
-// sit in different phases / iterations / voxels (iso_project_hex*_kernel): every phase performs exactly
-// the IEEE operations of the corresponding part of that loop, in the same order (explicit fma / dot3 on
-// both sides, -ffp-contract=off), so the results are bit-identical.
-//   EVAL  fields, QP data, corner test            -> QP | POST
-//   QP    ONE active-set pattern (walk or exhaustive fallback) per visit -> QP | POST
-//   POST  step test, merit parameter               -> LS | UPD
-//   LS    ONE backtracking trial per visit         -> LS | UPD
-//   UPD   trust region, iterate update             -> EVAL | DONE
-enum { ISO_IDLE = 0, ISO_EVAL, ISO_QP, ISO_POST, ISO_LS, ISO_UPD, ISO_DONE };
+// H = G + S + sg a a^T (upper triangle), g' = g - sg e a: the QP data of the oracle's iso_project_hex8
+R2S_DEV void iso_qp_data(const double G[3][3], const double S[3], const double a[3], const double g[3], double sg,
+                         double e, Sym3& H, double gp[3])
+{
+    const double se = sg * e;
+    const double sa0 = sg * a[0], sa1 = sg * a[1], sa2 = sg * a[2];
+    H.a00 = fma(sa0, a[0], G[0][0]); H.a01 = fma(sa0, a[1], G[0][1]); H.a02 = fma(sa0, a[2], G[0][2]);
+    H.a11 = fma(sa1, a[1], G[1][1]); H.a12 = fma(sa1, a[2], G[1][2]);
+    H.a22 = fma(sa2, a[2], G[2][2]);
+    H.a01 += S[0];
+    H.a02 += S[1];
+    H.a12 += S[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gp[i] = fma(-se, a[i], g[i]);
+}
+
+// positive definite on the face of the box named by the pattern
+R2S_DEV bool iso_face_spd(const Sym3& H, int pat)
+{
+    const bool f0 = (pat % 3) != 0, f1 = ((pat / 3) % 3) != 0, f2 = (pat / 9) != 0;
+    return spd3(f0 ? 1.0 : H.a00, (f0 || f1) ? 0.0 : H.a01, (f0 || f2) ? 0.0 : H.a02,
+                f1 ? 1.0 : H.a11, (f1 || f2) ? 0.0 : H.a12, f2 ? 1.0 : H.a22);
+}
+
+// warm-start pattern: a variable the last QP fixed stays fixed only if it sits on the element's own bound now
+R2S_DEV int iso_clean_pattern(int pat, const double xi[3])
+{
+    const int s0 = pat % 3, s1 = (pat / 3) % 3, s2 = pat / 9;
+    int p = 0;
+    if ((s0 == 1 && xi[0] == -1.0) || (s0 == 2 && xi[0] == 1.0)) p += s0;
+    if ((s1 == 1 && xi[1] == -1.0) || (s1 == 2 && xi[1] == 1.0)) p += 3 * s1;
+    if ((s2 == 1 && xi[2] == -1.0) || (s2 == 2 && xi[2] == 1.0)) p += 9 * s2;
+    return p;
+}
+
+// ---- the complete solver, one lane = one (element, voxel) pair ------------------------------------------
+// Operation for operation the oracle's iso_project_hex8 (oracle/r2s_oracle.c): exact Lagrangian Hessian, convex
+// active-set QP or the global minimiser of the non-convex QP over the trust region, L1 merit with second-order
+// correction, restoration along nodal segments from stalls.  iso_straggler_kernel / iso_sweep_kernel run it for the
+// pairs the fast lane machine below hands over (anything but plain full Newton-SQP steps).
+template <class ER>
+R2S_DEV bool iso_restore(const ER& E, const double x[3], double rt, const double xi[3], double c, double out[3])
+{
+    double bestf = INFINITY;
+    bool found = false;
+    for (int k = 0; k < 8; ++k) {
+        const double nd[3] = {(k & 1) ? 1.0 : -1.0, (k & 2) ? 1.0 : -1.0, (k & 4) ? 1.0 : -1.0};
+        const double ck = tri_eval_value(R2S_CR(E), nd) - rt;
+        if ((c < 0.0) ? !(ck >= 0.0) : !(ck <= 0.0)) continue;
+        const double dir[3] = {nd[0] - xi[0], nd[1] - xi[1], nd[2] - xi[2]};
+        double tl = 0.0, th = 1.0, t = 1.0, p[3] = {nd[0], nd[1], nd[2]};
+        if (ck != 0.0) {
+            t = 0.5;
+            for (int n = 0; n < 100; ++n) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) p[i] = fma(t, dir[i], xi[i]);
+                const TriEval tr = tri_eval_full(R2S_CR(E), p);
+                const double ph = tr.v - rt;
+                if (ph == 0.0) break;
+                if ((ph < 0.0) == (c < 0.0)) tl = t; else th = t;
+                if (!(th - tl > 1e-15)) break;
+                const double dph = dot3(tr.d1, tr.d2, tr.d3, dir[0], dir[1], dir[2]);
+                double tn = t - ph / dph;
+                if (!(tn > tl && tn < th)) tn = 0.5 * (tl + th);
+                if (tn == t) break;
+                t = tn;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) p[i] = fmin(fmax(fma(t, dir[i], xi[i]), -1.0), 1.0);
+        }
+        double fk, ckk;
+        iso_eval_fc(E, x, rt, p, fk, ckk);
+        if (fk < bestf) { bestf = fk; found = true; out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; }
+    }
+    return found;
+}
+
+template <class ER>
+R2S_DEV void iso_project_full(const ER& E, double rmax_abs, const double x[3], double rt, double xi[3])
+{
+    xi[0] = xi[1] = xi[2] = 0.0;
+    double mu = 0.0, lam = 0.0, Delta = 2.0;
+    int pat = 0, nrest = 0;
+    const double rtol = fmax(fabs(rt), rmax_abs) * 1e-14;
+    double fbest = INFINITY, xbest[3] = {0.0, 0.0, 0.0};
+    for (int it = 0; it < R2S_ISO_MAXIT; ++it) {
+        double r[3], J[3][3], a[3], g[3], G[3][3], M2[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const TriEval t = tri_eval_full(R2S_CX(E, i), xi);
+            r[i] = x[i] - t.v;
+            J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
+            M2[i][0] = t.m12; M2[i][1] = t.m13; M2[i][2] = t.m23;
+        }
+        const double f = dot3(r[0], r[1], r[2], r[0], r[1], r[2]);
+        const TriEval tr = tri_eval_full(R2S_CR(E), xi);
+        double c = tr.v - rt;
+        a[0] = tr.d1; a[1] = tr.d2; a[2] = tr.d3;
+        if (fabs(c) <= rtol) c = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (fabs(a[j]) <= rtol) a[j] = 0.0;
+        if (c == 0.0 && f < fbest) { fbest = f; xbest[0] = xi[0]; xbest[1] = xi[1]; xbest[2] = xi[2]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g[j] = -2.0 * dot3(r[0], r[1], r[2], J[0][j], J[1][j], J[2][j]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i; j < 3; ++j)
+                G[i][j] = G[j][i] = 2.0 * dot3(J[0][i], J[1][i], J[2][i], J[0][j], J[1][j], J[2][j]);
+        pat = iso_clean_pattern(pat, xi);
+        {
+            double num = 0.0, den = 0.0;
+            const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (!sp[i]) { num = fma(a[i], g[i], num); den = fma(a[i], a[i], den); }
+            lam = (den > 0.0) ? -num / den : 0.0;
+        }
+        double S[3];
+        {
+            const double mr[3] = {tr.m12, tr.m13, tr.m23};
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                S[q] = fma(lam, mr[q], -2.0 * dot3(r[0], r[1], r[2], M2[0][q], M2[1][q], M2[2][q]));
+        }
+        double lo[3], hi[3], d[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lo[i] = fmax(-1.0 - xi[i], -Delta);
+            hi[i] = fmin(1.0 - xi[i], Delta);
+        }
+        const double e = -c;
+        double mplus = 0.0, mminus = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double p = a[i] * lo[i], q = a[i] * hi[i];
+            mplus += fmax(p, q);
+            mminus += fmin(p, q);
+        }
+        const double trG = G[0][0] + G[1][1] + G[2][2];
+        const double aa2 = dot3(a[0], a[1], a[2], a[0], a[1], a[2]);
+        const double sigma = 100.0 * trG / aa2;
+        bool convex = true, corner = false, stall = false;
+        int stop = 0;
+        const bool near_feas = (fabs(c) <= 1e4 * rtol);
+        const double mu_keep = near_feas ? 0.5 : 1.0;
+        double lam_new = lam, alpha = 1.0, qstep = 0.0, dGd = 0.0;
+        if (e > mplus) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0);
+            corner = true;
+        } else if (e < mminus) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) d[i] = (a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0);
+            corner = true;
+        }
+        if (corner) {
+            double bp = 0.0, bm = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double p = a[i] * (-1.0 - xi[i]), q = a[i] * (1.0 - xi[i]);
+                bp += fmax(p, q);
+                bm += fmin(p, q);
+            }
+            if ((e > 0.0) ? !(bp > 0.05 * e) : !(bm < 0.05 * e)) stall = true;
+            double Gd[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Gd[i] = dot3(G[i][0], G[i][1], G[i][2], d[0], d[1], d[2]);
+            dGd = dot3(d[0], d[1], d[2], Gd[0], Gd[1], Gd[2]);
+        } else {
+            Sym3 H;
+            double gp[3];
+            int stage = 0;
+            double sg = sigma;
+            for (;;) {
+                iso_qp_data(G, S, a, g, sg, e, H, gp);
+                convex = iso_face_spd(H, pat);
+                if (convex || stage) break;
+                stage = 1;
+                sg = 100.0 * sigma;
+            }
+            QpOut o;
+            bool found = false;
+            if (convex) {
+                int p = pat;
+                for (int step = 0; step < R2S_QP_WALK && p >= 0; ++step) {
+                    const int rc = qp_pattern(p, H, gp, a, e, lo, hi, o);
+                    if (rc == 0 && !stage) {
+                        stage = 1;
+                        sg = 100.0 * sigma;
+                        iso_qp_data(G, S, a, g, sg, e, H, gp);
+                        p = pat;
+                        step = -1;
+                        continue;
+                    }
+                    if (rc == 0) { convex = false; break; }
+                    if (rc == 1 && o.kkt) {
+                        found = true;
+                        pat = p;
+                        d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
+                        lam_new = o.lam;
+                        qstep = o.q;
+                        break;
+                    }
+                    p = o.next;
+                }
+            }
+            if (!found) {
+                double bestq = INFINITY;
+                for (int ip = 0; ip < 19; ++ip) {
+                    const int p = c_pat_order[ip];
+                    if (qp_pattern(p, H, gp, a, e, lo, hi, o) == 1) {
+                        if ((convex && o.kkt) || o.q < bestq) {
+                            bestq = o.q;
+                            found = true;
+                            pat = p;
+                            d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2];
+                            lam_new = o.lam;
+                            qstep = o.q;
+                        }
+                        if (convex && o.kkt) break;
+                    }
+                }
+            }
+            if (!found) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    d[i] = (e > 0.0) ? ((a[i] > 0.0) ? hi[i] : ((a[i] < 0.0) ? lo[i] : 0.0))
+                                     : ((a[i] > 0.0) ? lo[i] : ((a[i] < 0.0) ? hi[i] : 0.0));
+                corner = true;
+                convex = true;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
+        }
+        const double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+        const double ad = dot3(a[0], a[1], a[2], d[0], d[1], d[2]);
+        const double pred_c = fabs(c) - fabs(c + ad);
+        if (stall) {
+            stop = 2;
+        } else if (!convex) {
+            double mu_t = fmax(mu_keep * mu, 2.0 * fabs(lam_new));
+            double pred = fma(mu_t, pred_c, -qstep);
+            if (!(pred > 0.0)) {
+                if (pred_c > 0.0) { mu_t = 2.0 * qstep / pred_c; pred = qstep; }
+                else stop = near_feas ? 3 : 2;
+            }
+            if (!stop && !(pred > 1e-14 * f)) stop = 3;
+            if (!stop) {
+                mu = mu_t;
+                double xt[3], ft, ct;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(xi[i] + d[i], -1.0), 1.0);
+                iso_eval_fc(E, x, rt, xt, ft, ct);
+                const double phi0 = fma(mu, fabs(c), f);
+                if (!(phi0 - fma(mu, fabs(ct), ft) >= 1e-4 * pred)) {
+                    const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+                    double den = 0.0, d2[3] = {d[0], d[1], d[2]};
+                    bool ok = false;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (!sp[i]) den = fma(a[i], a[i], den);
+                    if (den > 0.0) {
+                        const double sc = -ct / den;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            if (!sp[i]) d2[i] = fma(sc, a[i], d[i]);
+                            xt[i] = fmin(fmax(xi[i] + d2[i], -1.0), 1.0);
+                        }
+                        double f2, c2;
+                        iso_eval_fc(E, x, rt, xt, f2, c2);
+                        ok = (phi0 - fma(mu, fabs(c2), f2) >= 1e-4 * pred);
+                    }
+                    if (ok) { d[0] = d2[0]; d[1] = d2[1]; d[2] = d2[2]; }
+                    else alpha = 0.0;
+                }
+            }
+        } else if (!(dmax > R2S_ISO_TOL)) {
+            stop = (corner && !near_feas) ? 2 : 1;
+        } else {
+            const double gd = dot3(g[0], g[1], g[2], d[0], d[1], d[2]);
+            double mu_t = corner ? mu : fmax(mu_keep * mu, 2.0 * fabs(lam_new));
+            if (corner && pred_c > 0.0) {
+                const double need = 2.0 * fma(0.5, dGd, gd) / pred_c;
+                if (need > mu_t) mu_t = need;
+            }
+            if (!(fma(-mu_t, pred_c, gd) < 0.0)) {
+                if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
+                else stop = (near_feas && !corner) ? 4 : 2;
+            }
+            if (!stop) {
+                mu = mu_t;
+                const double D = fma(-mu, pred_c, gd);
+                const double phi0 = fma(mu, fabs(c), f);
+                for (int ls = 0; ls < 30; ++ls) {
+                    double xt[3], ft, ct;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(fma(alpha, d[i], xi[i]), -1.0), 1.0);
+                    iso_eval_fc(E, x, rt, xt, ft, ct);
+                    if (fma(mu, fabs(ct), ft) <= fma(1e-4 * alpha, D, phi0)) break;
+                    if (ls == 0 && !corner) {
+                        const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+                        double den = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            if (!sp[i]) den = fma(a[i], a[i], den);
+                        if (den > 0.0) {
+                            const double sc = -ct / den;
+                            double d2[3];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                d2[i] = sp[i] ? d[i] : fma(sc, a[i], d[i]);
+                                xt[i] = fmin(fmax(xi[i] + d2[i], -1.0), 1.0);
+                            }
+                            double f2, c2;
+                            iso_eval_fc(E, x, rt, xt, f2, c2);
+                            if (fma(mu, fabs(c2), f2) <= fma(1e-4, D, phi0)) {
+                                d[0] = d2[0]; d[1] = d2[1]; d[2] = d2[2];
+                                break;
+                            }
+                        }
+                    }
+                    alpha *= 0.5;
+                }
+            }
+        }
+        Delta = (alpha < 1.0) ? ((alpha > 0.0) ? alpha * dmax : 0.25 * dmax) : fmin(2.0, fmax(Delta, 2.0 * dmax));
+        if (stop == 2) {
+            double xr[3];
+            if (!near_feas && nrest < R2S_ISO_MAX_RESTORE && iso_restore(E, x, rt, xi, c, xr)) {
+                xi[0] = xr[0]; xi[1] = xr[1]; xi[2] = xr[2];
+                mu = 0.0; Delta = 2.0; pat = 0; nrest++;
+                continue;
+            }
+            if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
+            return;
+        }
+        if (stop == 3 || stop == 4) return;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xi[i] = fmin(fmax(fma(alpha, d[i], xi[i]), -1.0), 1.0);
+        if (stop == 1) return;
+    }
+    if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
+}
+
+// ---- the fast path of the same solver as a per-lane state machine ---------------------------------------
+// iso_project_hex_pl_kernel runs the COMMON case of the iteration above with the lanes of a wavefront in
+// different phases / iterations / voxels: plain SQP steps - the QP convex on the faces the active-set walk visits
+// (first sigma), found within R2S_QP_WALK patterns, the full step accepted by the merit function at the first trial -
+// and feasibility steps into a corner of the trust region.  Every phase performs exactly the IEEE operations of the
+// corresponding part of iso_project_full, in the same order.  Anything else (non-convex model, second sigma, exhaustive
+// pattern search, rejected step, stall, more than R2S_ISO_FAST_IT iterations) ends in ISO_BAIL: the pair goes to the
+// straggler list and iso_project_full solves it from the start.  The fast path therefore never has to agree with the
+// complete solver beyond the point where it bails - and needs neither line-search nor pattern-search state.
+//   EVAL    fields, QP data, corner test            -> QP | FINISH | BAIL
+//   QP      ONE active-set pattern per visit        -> QP | FINISH | BAIL
+//   FINISH  step test, merit parameter, the full-step trial, trust region, iterate update -> EVAL | DONE | BAIL
+#define R2S_ISO_FAST_IT 16
+enum { ISO_IDLE = 0, ISO_EVAL, ISO_QP, ISO_FINISH, ISO_DONE, ISO_BAIL };
 
 struct IsoLane {
     double x[3];
     double xi[3], mu, Delta;
     Sym3 H;
     double a[3], g[3], d[3];
-    double se;   // sigma * e: the QP gradient g - se * a and the step bounds are rebuilt where they are needed
-                 // (a handful of operations) instead of occupying 16 registers between the phases
-    double f, c, lam_new, alpha, D, phi0, bestq;
-    int pat, it, p, step, ip, ls, stop, phase;
-    bool corner, found, fb, restarted;
+    double se;   // sigma * e (QP steps) or the curvature d.G.d of a corner step
+    double f, c, lam_new;
+    int pat, it, p, step, phase;
+    bool corner;
 };
 
 // step bounds of the current iterate: the box |xi| <= 1 cut with the trust region
@@ -564,12 +916,11 @@ R2S_DEV void iso_lane_start(IsoLane& s, const double x[3])
     s.xi[0] = s.xi[1] = s.xi[2] = 0.0;
     s.mu = 0.0; s.Delta = 2.0;
     s.pat = 0; s.it = 0;
-    s.restarted = false;
     s.phase = ISO_EVAL;
 }
 
 template <class ER>
-R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
+R2S_DEV void iso_lane_eval(const ER& E, double rt, double rtol, IsoLane& s)
 {
     double r[3], J[3][3], G[3][3], M2[3][3];
 #pragma unroll
@@ -581,8 +932,12 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
     }
     const double f = dot3(r[0], r[1], r[2], r[0], r[1], r[2]);
     const TriEval tr = tri_eval_full(R2S_CR(E), s.xi);
-    const double c = tr.v - rt;
+    double c = tr.v - rt;
     s.a[0] = tr.d1; s.a[1] = tr.d2; s.a[2] = tr.d3;
+    if (fabs(c) <= rtol) c = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (fabs(s.a[j]) <= rtol) s.a[j] = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) s.g[j] = -2.0 * dot3(r[0], r[1], r[2], J[0][j], J[1][j], J[2][j]);
 #pragma unroll
@@ -590,6 +945,7 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
 #pragma unroll
         for (int j = i; j < 3; ++j)
             G[i][j] = G[j][i] = 2.0 * dot3(J[0][i], J[1][i], J[2][i], J[0][j], J[1][j], J[2][j]);
+    s.pat = iso_clean_pattern(s.pat, s.xi);
     double lam;
     {
         double num = 0.0, den = 0.0;
@@ -612,7 +968,7 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
     double mplus = 0.0, mminus = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        double p = s.a[i] * lo[i], q = s.a[i] * hi[i];
+        const double p = s.a[i] * lo[i], q = s.a[i] * hi[i];
         mplus += fmax(p, q);
         mminus += fmin(p, q);
     }
@@ -620,200 +976,114 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, IsoLane& s)
     const double aa2 = dot3(s.a[0], s.a[1], s.a[2], s.a[0], s.a[1], s.a[2]);
     const double sigma = 100.0 * trG / aa2;
     s.corner = false;
-    s.stop = 0;
     s.lam_new = lam;
-    s.alpha = 1.0;
-    s.f = f; s.c = c;   // (e = -c is rebuilt where the QP needs it)
-    if (e >= mplus) {
+    s.f = f; s.c = c;
+    if (e > mplus) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0);
         s.corner = true;
-    } else if (e <= mminus) {
+    } else if (e < mminus) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? lo[i] : ((s.a[i] < 0.0) ? hi[i] : 0.0);
         s.corner = true;
     }
     if (s.corner) {
-        // curvature of f along the corner step, for the penalty parameter (iso_lane_post); bestq is free here
+        // how much of the violation the linear model can remove anywhere in the element (see the oracle)
+        double bp = 0.0, bm = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double p = s.a[i] * (-1.0 - s.xi[i]), q = s.a[i] * (1.0 - s.xi[i]);
+            bp += fmax(p, q);
+            bm += fmin(p, q);
+        }
+        const bool stall = (e > 0.0) ? !(bp > 0.05 * e) : !(bm < 0.05 * e);
         double Gd[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) Gd[i] = dot3(G[i][0], G[i][1], G[i][2], s.d[0], s.d[1], s.d[2]);
-        s.bestq = dot3(s.d[0], s.d[1], s.d[2], Gd[0], Gd[1], Gd[2]);
-        s.phase = ISO_POST;
+        s.se = dot3(s.d[0], s.d[1], s.d[2], Gd[0], Gd[1], Gd[2]);
+        s.phase = stall ? ISO_BAIL : ISO_FINISH;
     } else {
-        const double se = sigma * e;
-        s.se = se;
-        const double sa0 = sigma * s.a[0], sa1 = sigma * s.a[1], sa2 = sigma * s.a[2];
-        Sym3 Hgn;   // Gauss-Newton + sigma a a^T
-        Hgn.a00 = fma(sa0, s.a[0], G[0][0]); Hgn.a01 = fma(sa0, s.a[1], G[0][1]); Hgn.a02 = fma(sa0, s.a[2], G[0][2]);
-        Hgn.a11 = fma(sa1, s.a[1], G[1][1]); Hgn.a12 = fma(sa1, s.a[2], G[1][2]);
-        Hgn.a22 = fma(sa2, s.a[2], G[2][2]);
-        s.H = Hgn;
-        s.H.a01 += S[0];
-        s.H.a02 += S[1];
-        s.H.a12 += S[2];
-        // positive definite on the face of the box the last QP ended on (warm-start pattern) - see the oracle
-        const bool f0 = (s.pat % 3) != 0, f1 = ((s.pat / 3) % 3) != 0, f2 = (s.pat / 9) != 0;
-        const bool ex = spd3(f0 ? 1.0 : s.H.a00, (f0 || f1) ? 0.0 : s.H.a01, (f0 || f2) ? 0.0 : s.H.a02,
-                             f1 ? 1.0 : s.H.a11, (f1 || f2) ? 0.0 : s.H.a12, f2 ? 1.0 : s.H.a22);
-        // While the active-set walk runs with the exact matrix (ip = 1), the off-diagonals of the Gauss-Newton
-        // matrix wait in D, phi0 and lam_new: those three are dead between EVAL and the end of the walk (POST
-        // writes D and phi0, the QP writes lam_new when it is done) and the state has no registers to spare.
-        s.ip = ex ? 1 : 0;
-        s.D = Hgn.a01; s.phi0 = Hgn.a02; s.lam_new = Hgn.a12;
-        if (!ex) s.H = Hgn;
+        double gp[3];
+        iso_qp_data(G, S, s.a, s.g, sigma, e, s.H, gp);
+        s.se = sigma * e;
         s.p = s.pat;
         s.step = 0;
-        s.found = false;
-        s.fb = false;
-        s.phase = ISO_QP;
+        s.phase = iso_face_spd(s.H, s.pat) ? ISO_QP : ISO_BAIL;
     }
 }
 
 R2S_DEV void iso_lane_qp(IsoLane& s)
 {
     QpOut o;
-    const int p = s.fb ? c_pat_order[s.ip] : s.p;
     double lo[3], hi[3], gp[3];
     iso_lane_bounds(s, lo, hi);
 #pragma unroll
     for (int i = 0; i < 3; ++i) gp[i] = fma(-s.se, s.a[i], s.g[i]);
     const double e = -s.c;
-    const int rc = qp_pattern(p, s.H, gp, s.a, e, lo, hi, o);
-    bool done = false;
-    if (!s.fb) {
+    const int rc = qp_pattern(s.p, s.H, gp, s.a, e, lo, hi, o);
+    if (rc == 1 && o.kkt) {
         // active-set walk: the first primal feasible KKT pattern is the minimiser
-        if (rc == 1 && o.kkt) {
-            s.found = true;
-            s.pat = p;
-            s.d[0] = o.d[0]; s.d[1] = o.d[1]; s.d[2] = o.d[2];
-            s.lam_new = o.lam;
-            done = true;
-        } else if (rc == 0 && s.ip) {
-            // the walk left the warm-start face for one on which the exact matrix is not positive definite: this
-            // iteration continues with Gauss-Newton (same diagonal), from the warm-start pattern
-            s.ip = 0;
-            s.H.a01 = s.D;
-            s.H.a02 = s.phi0;
-            s.H.a12 = s.lam_new;
-            s.p = s.pat;
-            s.step = 0;
-        } else {
-            bool to_fb = (rc == 0);
-            if (!to_fb) {
-                s.p = o.next;
-                s.step += 1;
-                to_fb = !(s.step < R2S_QP_WALK && s.p >= 0);
-            }
-            if (to_fb) { s.fb = true; s.ip = 0; s.bestq = INFINITY; }
-        }
+        s.pat = s.p;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.d[i] = fmin(fmax(o.d[i], lo[i]), hi[i]);
+        s.lam_new = o.lam;
+        s.phase = ISO_FINISH;
+    } else if (rc == 0) {
+        s.phase = ISO_BAIL;   // second sigma / non-convex model: the complete solver's business
     } else {
-        // exhaustive fallback, one pattern per visit
-        if (rc == 1) {
-            if (o.kkt || o.q < s.bestq) {
-                s.bestq = o.q;
-                s.found = true;
-                s.pat = p;
-                s.d[0] = o.d[0]; s.d[1] = o.d[1]; s.d[2] = o.d[2];
-                s.lam_new = o.lam;
-            }
-            if (o.kkt) done = true;
-        }
-        s.ip += 1;
-        if (s.ip == 19) done = true;
-    }
-    if (done) {
-        if (!s.found) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                s.d[i] = (e > 0.0) ? ((s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0))
-                                     : ((s.a[i] > 0.0) ? lo[i] : ((s.a[i] < 0.0) ? hi[i] : 0.0));
-            s.corner = true;
-            s.bestq = 0.0;   // (numerically degenerate QP: the penalty rule of corner steps without its curvature term)
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) s.d[i] = fmin(fmax(s.d[i], lo[i]), hi[i]);
-        s.phase = ISO_POST;
+        s.p = o.next;
+        s.step += 1;
+        if (!(s.step < R2S_QP_WALK && s.p >= 0)) s.phase = ISO_BAIL;   // exhaustive search
     }
 }
 
-R2S_DEV void iso_lane_post(IsoLane& s)
+template <class ER>
+R2S_DEV void iso_lane_finish(const ER& E, double rt, double rtol, IsoLane& s)
 {
     const double dmax = fmax(fabs(s.d[0]), fmax(fabs(s.d[1]), fabs(s.d[2])));
+    const bool near_feas = (fabs(s.c) <= 1e4 * rtol);
     if (!(dmax > R2S_ISO_TOL)) {
-        s.stop = s.corner ? 2 : 1;
+        if (s.corner && !near_feas) { s.phase = ISO_BAIL; return; }   // stuck off the iso-surface: restoration
     } else {
         const double ad = dot3(s.a[0], s.a[1], s.a[2], s.d[0], s.d[1], s.d[2]);
         const double pred_c = fabs(s.c) - fabs(s.c + ad);
         const double gd = dot3(s.g[0], s.g[1], s.g[2], s.d[0], s.d[1], s.d[2]);
-        double mu_t = s.corner ? s.mu : fmax(0.5 * s.mu, 2.0 * fabs(s.lam_new));
+        const double mu_keep = near_feas ? 0.5 : 1.0;
+        double mu_t = s.corner ? s.mu : fmax(mu_keep * s.mu, 2.0 * fabs(s.lam_new));
         if (s.corner && pred_c > 0.0) {
             // a step that only buys feasibility: the merit function pays for the growth of f including its curvature
-            const double need = 2.0 * fma(0.5, s.bestq, gd) / pred_c;
+            const double need = 2.0 * fma(0.5, s.se, gd) / pred_c;
             if (need > mu_t) mu_t = need;
         }
         if (!(fma(-mu_t, pred_c, gd) < 0.0)) {
             if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
-            else s.stop = 2;
-        }
-        if (!s.stop) {
-            s.mu = mu_t;
-            s.D = fma(-s.mu, pred_c, gd);
-            s.phi0 = fma(s.mu, fabs(s.c), s.f);
-            s.ls = 0;
-        }
-    }
-    s.phase = s.stop ? ISO_UPD : ISO_LS;
-}
-
-template <class ER>
-R2S_DEV void iso_lane_ls(const ER& E, double rt, IsoLane& s)
-{
-    double xt[3], ft, ct;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(fma(s.alpha, s.d[i], s.xi[i]), -1.0), 1.0);
-    iso_eval_fc(E, s.x, rt, xt, ft, ct);
-    if (fma(s.mu, fabs(ct), ft) <= fma(1e-4 * s.alpha, s.D, s.phi0)) {
-        s.phase = ISO_UPD;
-    } else {
-        s.alpha *= 0.5;
-        s.ls += 1;
-        if (s.ls == 30) s.phase = ISO_UPD;
-    }
-}
-
-template <class ER>
-R2S_DEV void iso_lane_update(const ER& E, IsoLane& s)
-{
-    const double dm = fmax(fabs(s.d[0]), fmax(fabs(s.d[1]), fabs(s.d[2])));
-    s.Delta = (s.alpha < 1.0) ? s.alpha * dm : fmin(2.0, fmax(s.Delta, 2.0 * dm));
-    if (s.stop == 2) {
-        if (!s.restarted && fabs(s.c) > 1e-10) {
-            // stuck at a point that does not satisfy the constraint: one more attempt from half-way to the node whose
-            // density lies farthest on the other side of the threshold (see the oracle)
-            double best = -INFINITY;
-            int kb = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double xc[3] = {(k & 1) ? 1.0 : -1.0, (k & 2) ? 1.0 : -1.0, (k & 4) ? 1.0 : -1.0};
-                const double rk = tri_eval_value(R2S_CR(E), xc);
-                const double score = (s.c < 0.0) ? rk : -rk;
-                if (score > best) { best = score; kb = k; }
+            else {
+                // no descent on the merit function: from a feasible point the QP step is rounding noise (converged,
+                // the iterate stays); otherwise restoration
+                s.phase = (near_feas && !s.corner) ? ISO_DONE : ISO_BAIL;
+                return;
             }
-            s.xi[0] = (kb & 1) ? 0.5 : -0.5; s.xi[1] = (kb & 2) ? 0.5 : -0.5; s.xi[2] = (kb & 4) ? 0.5 : -0.5;
-            s.mu = 0.0; s.Delta = 2.0; s.pat = 0; s.restarted = true;
-            s.it += 1;
-            s.phase = (s.it == R2S_ISO_MAXIT) ? ISO_DONE : ISO_EVAL;
-            return;
         }
-        s.phase = ISO_DONE;
+        s.mu = mu_t;
+        const double D = fma(-s.mu, pred_c, gd);
+        const double phi0 = fma(s.mu, fabs(s.c), s.f);
+        double xt[3], ft, ct;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(fma(1.0, s.d[i], s.xi[i]), -1.0), 1.0);
+        iso_eval_fc(E, s.x, rt, xt, ft, ct);
+        if (!(fma(s.mu, fabs(ct), ft) <= fma(1e-4 * 1.0, D, phi0))) { s.phase = ISO_BAIL; return; }   // correction / back-tracking
+        s.Delta = fmin(2.0, fmax(s.Delta, 2.0 * dmax));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.xi[i] = xt[i];
+        s.it += 1;
+        s.phase = (s.it == R2S_ISO_FAST_IT) ? ISO_BAIL : ISO_EVAL;
         return;
     }
+    // converged: the last (tiny) step is applied
+    s.Delta = fmin(2.0, fmax(s.Delta, 2.0 * dmax));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) s.xi[i] = fmin(fmax(fma(s.alpha, s.d[i], s.xi[i]), -1.0), 1.0);
-    if (s.stop == 1) { s.phase = ISO_DONE; return; }
-    s.it += 1;
-    s.phase = (s.it == R2S_ISO_MAXIT) ? ISO_DONE : ISO_EVAL;
+    for (int i = 0; i < 3; ++i) s.xi[i] = fmin(fmax(fma(1.0, s.d[i], s.xi[i]), -1.0), 1.0);
+    s.phase = ISO_DONE;
 }
 
 // running minimum of one voxel: WriteValue / update_distance_parallel!

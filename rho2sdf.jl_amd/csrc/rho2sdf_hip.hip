@@ -965,7 +965,18 @@ struct IsoElemLds {
     double C[8][3];
     double Cr[8];
     double X[8][3];
+    double rtol;   // 1e-14 max(|rho_t|, max |nodal density|): rounding residue of the density field (see the oracle)
+    int32_t el;
 };
+
+// a pair the fast lane machine hands over to the complete solver (iso_straggler_kernel)
+struct alignas(8) IsoStraggler {
+    double x[3];
+    uint64_t slot;
+    uint32_t el;
+    uint32_t pad;
+};
+#define R2S_ISO_UNSOLVED (-1.0)   // result slot of a handed-over pair until the complete solver has been there
 #define R2S_ISO_SLOTS 4
 #ifndef R2S_ISO_QP2_MIN
 #define R2S_ISO_QP2_MIN 24
@@ -1015,7 +1026,8 @@ extern "C" int r2s_debug_iso_stats(unsigned long long* out, int reset)
 __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
     const BandItem* __restrict__ items, uint32_t nitems, const uint32_t* __restrict__ chunk_off, uint32_t nchunks,
     uint32_t group, const ElemRec* __restrict__ erec, GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
-    double* __restrict__ res_xp, uint32_t* __restrict__ counter, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ abort_flag)
+    double* __restrict__ res_xp, uint32_t* __restrict__ counter, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ abort_flag,
+    IsoStraggler* __restrict__ strag, uint32_t strag_cap, uint32_t* __restrict__ strag_cnt /* [0] entries, [1] overflow */)
 {
     if (*abort_flag) return;   // speculated sizes of this call did not hold (run_impl)
     __shared__ IsoElemLds slots[R2S_ISO_SLOTS];
@@ -1042,10 +1054,34 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
     int eslot = 0;
 
     for (;;) {
-        const uint64_t m_done = __ballot(s.phase == ISO_DONE);
-        const uint64_t m_busy = __ballot(s.phase != ISO_DONE && s.phase != ISO_IDLE);
+        const uint64_t m_done = __ballot(s.phase == ISO_DONE || s.phase == ISO_BAIL);
+        const uint64_t m_busy = __ballot(s.phase != ISO_DONE && s.phase != ISO_BAIL && s.phase != ISO_IDLE);
         if (m_busy == 0 || __popcll(m_done) >= R2S_ISO_REFILL_MIN) {
             ISO_STAT(6, s.phase == ISO_DONE)
+            ISO_STAT(8, s.phase == ISO_BAIL)
+            if (s.phase == ISO_BAIL) {
+                // not a plain Newton-SQP run: the complete solver takes the pair from the start (iso_straggler_kernel);
+                // one atomic per wavefront reserves the list entries
+                const uint64_t m_bail = __ballot(true);
+                const uint32_t nb = (uint32_t)__popcll(m_bail);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_bail >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_bail, 0u));
+                uint32_t base = 0;
+                if (rank == 0) base = atomicAdd(&strag_cnt[0], nb);
+                base = __builtin_amdgcn_readfirstlane(base);   // (the first active lane is the one with rank 0)
+                const uint32_t idx = base + rank;
+                if (idx < strag_cap) {
+                    IsoStraggler e;
+                    e.x[0] = s.x[0]; e.x[1] = s.x[1]; e.x[2] = s.x[2];
+                    e.slot = (uint64_t)my;
+                    e.el = (uint32_t)slots[eslot].el;
+                    e.pad = 0;
+                    strag[idx] = e;
+                } else {
+                    strag_cnt[1] = 1u;   // list full: iso_sweep_kernel finds the pair by its result slot
+                }
+                res[my] = R2S_ISO_UNSOLVED;
+                s.phase = ISO_IDLE;
+            }
             if (s.phase == ISO_DONE) {
 #ifdef R2S_ISO_STATS
                 atomicAdd(&g_iso_stats[16 + (s.it / 4 > 15 ? 15 : s.it / 4)], 1ull);
@@ -1131,6 +1167,11 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
                         if (lane < 24) dst[lane] = src[offsetof(ElemRec, C) / 8 + lane];
                         else if (lane < 32) dst[lane] = src[offsetof(ElemRec, Cr) / 8 + (lane - 24)];
                         else if (lane < 56) dst[lane] = src[offsetof(ElemRec, X) / 8 + (lane - 32)];
+                        else if (lane == 56) {
+                            const ElemRec& R = erec[T.el];
+                            slots[fs].rtol = fmax(fabs(rho_t), fmax(fabs(R.rmax), fabs(R.rmin))) * 1e-14;
+                            slots[fs].el = T.el;
+                        }
                         __syncthreads();
                         cur_slot = fs;
                         dec = box_decode_make((uint32_t)T.dim[0], (uint32_t)T.dim[1], (uint32_t)T.dim[2]);
@@ -1177,29 +1218,104 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
         {
             const IsoElemLds& E = slots[eslot];
             ISO_STAT(0, s.phase == ISO_EVAL)
-            if (s.phase == ISO_EVAL) iso_lane_eval(E, rho_t, s);
-#ifdef R2S_ISO_STATS
-            if (s.phase == ISO_QP) dbg_qp += 1;
-            if (s.phase == ISO_LS) dbg_ls += 1;
-#endif
+            if (s.phase == ISO_EVAL) iso_lane_eval(E, rho_t, E.rtol, s);
             ISO_STAT(1, s.phase == ISO_QP)
             if (s.phase == ISO_QP) iso_lane_qp(s);
             // lanes whose active set changed need another pattern: worth a second visit in this trip only when
-            // many of them do (23 % on average; an unconditional second visit costs what it saves)
+            // many of them do (an unconditional second visit costs what it saves)
             if (__popcll(__ballot(s.phase == ISO_QP)) >= R2S_ISO_QP2_MIN) {
                 ISO_STAT(7, s.phase == ISO_QP)
                 if (s.phase == ISO_QP) iso_lane_qp(s);
             }
-            ISO_STAT(2, s.phase == ISO_POST)
-            if (s.phase == ISO_POST) iso_lane_post(s);
-            ISO_STAT(3, s.phase == ISO_LS)
-            if (s.phase == ISO_LS) iso_lane_ls(E, rho_t, s);
-            ISO_STAT(4, s.phase == ISO_UPD)
-            if (s.phase == ISO_UPD) iso_lane_update(E, s);
+            ISO_STAT(2, s.phase == ISO_FINISH)
+            if (s.phase == ISO_FINISH) iso_lane_finish(E, rho_t, E.rtol, s);
             ISO_STAT(5, true)
 #ifdef R2S_ISO_STATS
             if (s.phase != ISO_IDLE) dbg_trips += 1;
 #endif
+        }
+    }
+}
+
+// The pairs the fast path handed over, compacted: one lane per pair runs the complete solver (iso_project_full) from
+// xi = 0 - the oracle's iteration operation for operation - and writes the pair's result slot.
+__global__ void __launch_bounds__(64) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
+                                                           const uint32_t* __restrict__ strag_cnt, const ElemRec* __restrict__ erec,
+                                                           double rho_t, double* __restrict__ res, double* __restrict__ res_xp,
+                                                           const uint32_t* __restrict__ abort_flag)
+{
+    if (*abort_flag) return;
+    const uint32_t n = min(strag_cnt[0], strag_cap);
+    for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
+        const IsoStraggler e = strag[i];
+        const ElemRec& E = erec[e.el];
+        double xi[3];
+        iso_project_full(E, fmax(fabs(E.rmax), fabs(E.rmin)), e.x, rho_t, xi);
+        double N[8], xp[3];
+        hex8_shape(xi, N);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t = fma(E.X[k][q], N[k], t);
+            xp[q] = t;
+        }
+        res[e.slot] = norm3(e.x[0] - xp[0], e.x[1] - xp[1], e.x[2] - xp[2]);
+        if (res_xp) {
+            res_xp[3 * e.slot] = xp[0];
+            res_xp[3 * e.slot + 1] = xp[1];
+            res_xp[3 * e.slot + 2] = xp[2];
+        }
+    }
+}
+
+// Only when the straggler list overflowed (a mesh on which more than ~6 % of the pairs leave the fast path - tiny grids
+// are sized so that it cannot happen): every pair of every item is visited item-major and the slots still marked
+// unsolved are worked off in place.  Slow (a wavefront waits for its few unsolved lanes), rare, correct.
+__global__ void __launch_bounds__(256) iso_sweep_kernel(const BandItem* __restrict__ items, uint32_t nitems,
+                                                        const uint32_t* __restrict__ chunk_off, uint32_t nchunks,
+                                                        const uint32_t* __restrict__ perm, const ElemRec* __restrict__ erec,
+                                                        GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
+                                                        double* __restrict__ res_xp, const uint32_t* __restrict__ strag_cnt,
+                                                        const uint32_t* __restrict__ abort_flag)
+{
+    if (*abort_flag || strag_cnt[1] == 0u) return;
+    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t c = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6); c < nchunks; c += nw) {
+        uint32_t lo = 0, hi = nitems;   // last work-order position with chunk_off[pos] <= c
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (chunk_off[mid] <= c) lo = mid; else hi = mid;
+        }
+        const BandItem& T = items[perm[lo]];
+        const uint32_t local = (c - chunk_off[lo]) * 64u + lane;
+        const uint32_t bx = T.dim[0], by = T.dim[1], bz = T.dim[2];
+        if (local >= bx * by * bz) continue;
+        const int li = local % bx, lj = (local / bx) % by, lk = local / (bx * by);
+        const TileBox tb = tile_box(T.lo, T.dim);
+        const size_t slot = tile_slot(T.store_off, tb, T.lo[0] + li, T.lo[1] + lj, T.lo[2] + lk);
+        if (res[slot] != R2S_ISO_UNSOLVED) continue;
+        double x[3], xi[3];
+        x[0] = grid_coord(g, 0, T.lo[0] + li);
+        x[1] = grid_coord(g, 1, T.lo[1] + lj);
+        x[2] = grid_coord(g, 2, slab_global_k(sl, T.lo[2] + lk));
+        const ElemRec& E = erec[T.el];
+        iso_project_full(E, fmax(fabs(E.rmax), fabs(E.rmin)), x, rho_t, xi);
+        double N[8], xp[3];
+        hex8_shape(xi, N);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t = fma(E.X[k][q], N[k], t);
+            xp[q] = t;
+        }
+        res[slot] = norm3(x[0] - xp[0], x[1] - xp[1], x[2] - xp[2]);
+        if (res_xp) {
+            res_xp[3 * slot] = xp[0];
+            res_xp[3 * slot + 1] = xp[1];
+            res_xp[3 * slot + 2] = xp[2];
         }
     }
 }
@@ -1895,7 +2011,7 @@ struct r2s_plan {
     int n_cu = 256;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
-    DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], scan_tmp2[3], nchunks, chunk_off, iso_res, iso_res_xp;
+    DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], scan_tmp2[3], nchunks, chunk_off, iso_res, iso_res_xp, strag;
     DevBuf perm, wchunks, hardflag;   // work order of the persistent projection kernel (HEX8)
     DevBuf sbox, s_nchunks, s_chunk_off, sres;   // item-major inverse maps of the sign pass (HEX8)
     DevBuf nstore, store_off, s_nstore, s_store_off;   // storage (tile) chunk counts / offsets
@@ -2076,7 +2192,7 @@ void r2s_plan_destroy(r2s_plan* P)
     DevBuf* all[] = {&P->deg, &P->ine_ptr, &P->ine, &P->cursor, &P->erec, &P->cls, &P->fmask, &P->nitems,
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
                      &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any, &P->active_sonly, &P->active_lean, &P->active_tri, &P->tri,
-                     &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp,
+                     &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp, &P->strag,
                      &P->perm, &P->wchunks, &P->hardflag, &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres, &P->nstore, &P->store_off, &P->s_nstore, &P->s_store_off,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2], &P->scan_tmp2[0], &P->scan_tmp2[1], &P->scan_tmp2[2]};
     for (DevBuf* b : all) b->release();
@@ -2092,6 +2208,30 @@ void r2s_plan_destroy(r2s_plan* P)
 
 
 }  // extern "C"
+
+// entries of the straggler list for `n_store` storage chunks (64 result slots each): 1/16 of the slots, but never
+// fewer than min(slots, 2^20) - small grids cannot overflow whatever the mesh does
+static uint32_t iso_straggler_cap(uint32_t n_store)
+{
+    static const int cap_env = getenv("R2S_ISO_STRAGGLER_CAP") ? atoi(getenv("R2S_ISO_STRAGGLER_CAP")) : 0;   // test hook: force the overflow path
+    if (cap_env > 0) return (uint32_t)cap_env;
+    const uint64_t slots = 64ull * std::max<uint32_t>(n_store, 1u);
+    return (uint32_t)std::max<uint64_t>(slots / 16, std::min<uint64_t>(slots, 1ull << 20));
+}
+
+// behind iso_project_hex_pl_kernel on the same stream: the complete solver on the handed-over pairs, then the sweep
+// that only does something when the list overflowed (both sized without knowing the count: nothing waits for it)
+static void iso_stragglers(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32_t n_chunks, uint32_t strag_cap,
+                           const GridDev& g, const SlabInfo& s, double rho_t, double* res_xp, uint32_t* counters,
+                           const uint32_t* abort_flag)
+{
+    const uint32_t waves = (uint32_t)P->n_cu * 8u;
+    iso_straggler_kernel<<<waves, 64, 0, st>>>(P->strag.as<IsoStraggler>(), strag_cap, counters + 12, P->erec.as<ElemRec>(),
+                                               rho_t, P->iso_res.as<double>(), res_xp, abort_flag);
+    iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(),
+                                                             n_chunks, P->perm.as<uint32_t>(), P->erec.as<ElemRec>(), g, s, rho_t,
+                                                             P->iso_res.as<double>(), res_xp, counters + 12, abort_flag);
+}
 
 template <class ET>
 static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* dIEN, int64_t nel,
@@ -2329,9 +2469,13 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             //  kernels, one of them is left waiting until the projection kernel drains - 2 of 3 runs, +0.25 ms)
             if (sign_items) HIP_TRY(hipStreamWaitEvent(st, P->ev2[7], 0));
             HIP_TRY(hipEventRecord(P->ev[7], st));
+            const uint32_t strag_cap = iso_straggler_cap(n_store_e);
+            ENSURE(P->strag, sizeof(IsoStraggler) * (size_t)strag_cap);
             iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
                 P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks_e, group, P->erec.as<ElemRec>(), g,
-                s, rho_t, P->iso_res.as<double>(), nullptr, counters + 8, P->perm.as<uint32_t>(), abort_flag);
+                s, rho_t, P->iso_res.as<double>(), nullptr, counters + 8, P->perm.as<uint32_t>(), abort_flag,
+                P->strag.as<IsoStraggler>(), strag_cap, counters + 12);
+            iso_stragglers(P, st, n_items, n_chunks_e, strag_cap, g, s, rho_t, nullptr, counters, abort_flag);
             HIP_TRY(hipEventRecord(P->ev[6], st));
             HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[6], 0));
             // (the sentinel sweep on a third stream right here, beside the binning: its wavefronts delay the first short
@@ -2516,10 +2660,14 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
                 // the sweep has to get its wavefronts placed before this kernel fills every SIMD for 3 ms (it is released
                 // once the second stream has reached the sweep; high priority does the rest)
                 if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[0], 0));
+                const uint32_t strag_cap = iso_straggler_cap(n_store);
+                ENSURE(P->strag, sizeof(IsoStraggler) * (size_t)strag_cap);
+                double* const res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
                 iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
                     P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
-                    s, rho_t, P->iso_res.as<double>(), (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr, counters + 8,
-                    P->perm.as<uint32_t>(), abort_flag);
+                    s, rho_t, P->iso_res.as<double>(), res_xp, counters + 8, P->perm.as<uint32_t>(), abort_flag,
+                    P->strag.as<IsoStraggler>(), strag_cap, counters + 12);
+                iso_stragglers(P, st, n_items, n_chunks, strag_cap, g, s, rho_t, res_xp, counters, abort_flag);
             }
             if (!early_iso) HIP_TRY(hipEventRecord(P->ev[6], st));
             if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[4], 0));   // (the sweep precedes it on that stream)

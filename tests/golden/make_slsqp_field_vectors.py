@@ -9,8 +9,10 @@ and order stay the reference's.  Two solver settings:
   tight acc = 1e-15  converged
 Like the reference (ComputeCoordsOnIso.jl:79-86) the result of a solve is used whatever its status.
 
+Fixtures: the reference's 1hex_el input (test/runtests.jl:51-86, N = 15), cantilever_beam_vfrac_03, chapadlo.
 Writes tests/golden/slsqp_fields.npz: <fixture>_{ref,tight} = dist[ngp] (1e10 = untouched), <fixture>_pairs = number
-of pairs, <fixture>_fail_{ref,tight} = solves that did not report success.  Needs scipy; ~10 min on 8 cores."""
+of pairs, <fixture>_fail_{ref,tight} = solves that did not report success, <fixture>_{ref,tight}_offsurface = voxels whose
+value is the distance to an SLSQP result that does not satisfy the constraint.  Needs scipy; ~15 min on 8 cores."""
 import multiprocessing as mp
 import os
 import sys
@@ -59,15 +61,26 @@ def work(args):
     return out, ok
 
 
+def one_hex():
+    """the reference's 1hex_el input (test/runtests.jl:51-86)"""
+    X = 1.0 * S
+    IEN = np.arange(1, 9, dtype=np.int64)[None, :]
+    return X, IEN, np.array([1.0, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 1.0])
+
+
 def main():
     import __graft_entry__ as graft
     from conftest import load_fixture
     O = graft.load_oracle()
     res = {}
-    for name, rt in (("beam_vfrac_03", 0.5), ("chapadlo", 0.5)):
-        X, IEN, rho = load_fixture(name)
-        rn = O.dense_in_nodes(X, IEN, rho)
-        g, _ = O.auto_grid(X, IEN)
+    for name, rt in (("1hex_el", 0.5), ("beam_vfrac_03", 0.5), ("chapadlo", 0.5)):
+        if name == "1hex_el":
+            X, IEN, rn = one_hex()
+            g = O.grid_make(X.min(0), X.max(0), 15, 3)     # runtests.jl:54
+        else:
+            X, IEN, rho = load_fixture(name)
+            rn = O.dense_in_nodes(X, IEN, rho)
+            g, _ = O.auto_grid(X, IEN)
         with O.iso_pair_log(2_000_000) as log:
             O.eval_distances(X, IEN, rn, rt, g, 1.1, want_xp=False)
         n = log.n
@@ -86,7 +99,18 @@ def main():
                 d, _, _ = O.eval_distances(X, IEN, rn, rt, g, 1.1, want_xp=False)
             res[f"{name}_{tag}"] = d
             res[f"{name}_fail_{tag}"] = n - sum(p[1] for p in parts)
-            print(name, tag, "pairs", n, "not converged", res[f"{name}_fail_{tag}"], flush=True)
+            # voxels whose value comes from an SLSQP result that is NOT on the iso-surface (|rho - rho_t| > 1e-9): the
+            # reference uses whatever NLopt returns (ComputeCoordsOnIso.jl:79-86), but such a "distance" is to a point
+            # that does not belong to the surface - comparisons may want to set them apart
+            N = 0.125 * np.prod(1 + S[None] * xi[:, None, :], axis=2)
+            infeas = np.abs(np.einsum("nk,nk->n", N, rs) - rt) > 1e-9
+            dp = np.linalg.norm(pts - np.einsum("nk,nki->ni", N, Xes), axis=1)
+            bad = np.zeros(g.ngp, bool)
+            hit = infeas & (np.abs(dp - d[v]) <= 1e-12 * np.maximum(d[v], 1e-300))
+            bad[v[hit]] = True
+            res[f"{name}_{tag}_offsurface"] = np.flatnonzero(bad)
+            print(name, tag, "pairs", n, "not converged", res[f"{name}_fail_{tag}"], "results off the surface", int(infeas.sum()),
+                  "voxels decided by them", int(bad.sum()), flush=True)
     np.savez_compressed(os.path.join(HERE, "slsqp_fields.npz"), **res)
 
 
