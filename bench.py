@@ -210,6 +210,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and with it the check)")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the check runs whenever the oracle planes exist)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-pointer end-to-end leg (r2s_sdf: H2D + kernels + D2H)")
+    ap.add_argument("--no-build", action="store_true",
+                    help="load the built library as it is and exit non-zero when it is missing or stale (runs under "
+                         "rocprofv3 must not spawn make / hipcc: the profiler's preloaded library has initialised the GPU)")
     ap.add_argument("--partition", choices=["interleaved", "contiguous"], default="interleaved",
                     help="Z partition across GPUs (N > 1): interleaved 4-plane tile layers (balanced) or slabs")
     ap.add_argument("--stitch", choices=["sparse", "dense"], default="sparse",
@@ -231,7 +234,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    pkg = graft.build()
+    pkg = graft.load_built() if args.no_build else graft.build()
 
     # R2S_BENCH_REHEARSAL=1: functional rehearsal of the N > 1 path on ONE GPU (all ranks on cuda:0, gloo);
     # never used for reported numbers

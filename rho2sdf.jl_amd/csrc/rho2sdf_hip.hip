@@ -969,6 +969,11 @@ struct IsoElemLds {
     int32_t el;
 };
 
+struct IsoElemCoef {   // what the solvers read of an element: the monomial coefficients of the two trilinear maps
+    double C[8][3];
+    double Cr[8];
+};
+
 // a pair the fast lane machine hands over to the complete solver (iso_straggler_kernel)
 struct alignas(8) IsoStraggler {
     double x[3];
@@ -1058,7 +1063,7 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
         const uint64_t m_busy = __ballot(s.phase != ISO_DONE && s.phase != ISO_BAIL && s.phase != ISO_IDLE);
         if (m_busy == 0 || __popcll(m_done) >= R2S_ISO_REFILL_MIN) {
             ISO_STAT(6, s.phase == ISO_DONE)
-            ISO_STAT(8, s.phase == ISO_BAIL)
+            ISO_STAT(3, s.phase == ISO_BAIL)
             if (s.phase == ISO_BAIL) {
                 // not a plain Newton-SQP run: the complete solver takes the pair from the start (iso_straggler_kernel);
                 // one atomic per wavefront reserves the list entries
@@ -1239,7 +1244,7 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
 
 // The pairs the fast path handed over, compacted: one lane per pair runs the complete solver (iso_project_full) from
 // xi = 0 - the oracle's iteration operation for operation - and writes the pair's result slot.
-__global__ void __launch_bounds__(64) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
+__global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
                                                            const uint32_t* __restrict__ strag_cnt, const ElemRec* __restrict__ erec,
                                                            double rho_t, double* __restrict__ res, double* __restrict__ res_xp,
                                                            const uint32_t* __restrict__ abort_flag)
@@ -1249,8 +1254,16 @@ __global__ void __launch_bounds__(64) iso_straggler_kernel(const IsoStraggler* _
     for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
         const IsoStraggler e = strag[i];
         const ElemRec& E = erec[e.el];
+        // the solver's coefficients in registers: the 30-odd field evaluations of a run must not each wait for memory
+        // (one wavefront per SIMD, 64 different elements per wavefront: nothing hides that latency)
+        IsoElemCoef K;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            K.C[k][0] = E.C[k][0]; K.C[k][1] = E.C[k][1]; K.C[k][2] = E.C[k][2];
+            K.Cr[k] = E.Cr[k];
+        }
         double xi[3];
-        iso_project_full(E, fmax(fabs(E.rmax), fabs(E.rmin)), e.x, rho_t, xi);
+        iso_project_full(K, fmax(fabs(E.rmax), fabs(E.rmin)), e.x, rho_t, xi);
         double N[8], xp[3];
         hex8_shape(xi, N);
 #pragma unroll
@@ -1301,7 +1314,13 @@ __global__ void __launch_bounds__(256) iso_sweep_kernel(const BandItem* __restri
         x[1] = grid_coord(g, 1, T.lo[1] + lj);
         x[2] = grid_coord(g, 2, slab_global_k(sl, T.lo[2] + lk));
         const ElemRec& E = erec[T.el];
-        iso_project_full(E, fmax(fabs(E.rmax), fabs(E.rmin)), x, rho_t, xi);
+        IsoElemCoef K;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            K.C[k][0] = E.C[k][0]; K.C[k][1] = E.C[k][1]; K.C[k][2] = E.C[k][2];
+            K.Cr[k] = E.Cr[k];
+        }
+        iso_project_full(K, fmax(fabs(E.rmax), fabs(E.rmin)), x, rho_t, xi);
         double N[8], xp[3];
         hex8_shape(xi, N);
 #pragma unroll
@@ -2225,7 +2244,10 @@ static void iso_stragglers(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
                            const GridDev& g, const SlabInfo& s, double rho_t, double* res_xp, uint32_t* counters,
                            const uint32_t* abort_flag)
 {
-    const uint32_t waves = (uint32_t)P->n_cu * 8u;
+    // one 64-pair batch per wavefront as long as the list holds fewer than a million pairs (a wavefront takes as long as
+    // its slowest lane needs and executes the union of its lanes' branches: a second batch doubles that); the
+    // wavefronts beyond the count leave at once
+    const uint32_t waves = std::min<uint32_t>((strag_cap + 63u) / 64u, 16384u);
     iso_straggler_kernel<<<waves, 64, 0, st>>>(P->strag.as<IsoStraggler>(), strag_cap, counters + 12, P->erec.as<ElemRec>(),
                                                rho_t, P->iso_res.as<double>(), res_xp, abort_flag);
     iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(),

@@ -1,14 +1,13 @@
 """What stands between the oracle and the Julia reference, as numbers (VERDICT r1 "pin what can be pinned").
 
-1. the production oracle (step tolerances 1e-6 / 1e-7, 60 / 50 iterations) against its FROZEN tight build
-   (-DORC_TIGHT: 1e-12 / 1e-13, 400 / 200 iterations) on every fixture: sentinel sets and signs must be identical, and
-   the number of band voxels whose distance moves by more than 1e-6 is asserted - an edit of the production
-   tolerances or of the solver rules that trades accuracy for speed changes these counts;
+1. the production oracle (step tolerances 1e-6 / 1e-7) against its tight build (-DORC_TIGHT: 1e-12 / 1e-13) on every
+   fixture, the reference's 1hex_el input and distorted elements: sentinel sets and signs identical, and the LARGEST
+   relative change of a band distance is asserted (<= 1e-7; north_star asks 1e-6);
 2. find_local_coordinates: the single-start clamped Newton against 9-start L-BFGS-B vectors (the reference's problem
    statement, FindLocalCoordinates.jl:27-104) on strongly distorted hexahedra - the booleans the callers use;
 3. compute_coords_on_iso, TET4: the closed form against SLSQP vectors (ComputeCoordsOnIso.jl:90-181);
-4. evalDistances on the reference's own fixtures with every iso projection done by scipy's SLSQP (golden FIELDS,
-   tests/golden/make_slsqp_field_vectors.py): converged, and at the reference's own 1e-5 tolerances.
+4. evalDistances on the reference's 1hex_el input and two of its fixtures with every iso projection done by scipy's
+   SLSQP (golden FIELDS, tests/golden/make_slsqp_field_vectors.py): converged, and at the reference's own 1e-5 tolerances.
 The GPU path is bit-identical to the production oracle on these fixtures (tests/test_parity_gpu.py), so every count
 below is also the product's.
 """
@@ -115,34 +114,46 @@ def test_tet4_projection_against_slsqp(oracle):
     print(f"TET4 projection: {len(d['x'])} SLSQP vectors, max rel distance error {worst:.1e}")
 
 
-# fixture -> (band voxels, voxels beyond 1e-6 of the CONVERGED SLSQP field, beyond 1e-6 of the field at the reference's
-#             own 1e-5 tolerances, voxels on which the two SLSQP fields differ by more than 1e-6 between themselves)
-SLSQP_FIELD_COUNTS = {"beam_vfrac_03": (9298, 3, 931, 929), "chapadlo": (17875, 91, 1226, 1163)}
+# fixture -> (band voxels; against the CONVERGED SLSQP field, voxels SLSQP decides with a point ON the iso-surface only:
+#             product nearer by more than 1e-6 / farther by more than 1e-6; voxels beyond 1e-6 of the field at the
+#             reference's own 1e-5 tolerances (all voxels); voxels on which the two SLSQP fields differ by more than 1e-6)
+SLSQP_FIELD_COUNTS = {"1hex_el": (5832, 99, 0, 2253, 2162), "beam_vfrac_03": (9298, 3, 0, 931, 929),
+                      "chapadlo": (17875, 58, 11, 1226, 1163)}
 
 
 @pytest.mark.parametrize("name", sorted(SLSQP_FIELD_COUNTS))
 def test_fields_against_independent_slsqp(oracle, name):
-    """the whole evalDistances field of the reference's fixtures (automatic grid) with the iso projections by scipy's
-    SLSQP.  Converged SLSQP: the product differs on 12 of 9 298 (beam) and 89 of 17 875 (chapadlo) band voxels - pairs
-    where one of the two solvers ends in another local minimum or not on the constraint (the reference uses whatever
-    NLopt returns, ComputeCoordsOnIso.jl:79-86).  At the reference's own tolerances (1e-5) SLSQP itself is 1e-6 away
-    from its converged answer on 929 / 1 163 voxels: that, not the restatement, bounds parity with a Julia run."""
+    """the whole evalDistances field of the reference's 1hex_el input (runtests.jl:51-86) and of two fixtures
+    (automatic grid) with every iso projection by scipy's SLSQP (tests/golden/make_slsqp_field_vectors.py).
+    Converged SLSQP: wherever the product differs it has found a NEARER point of the iso-surface (1hex_el 99 voxels -
+    SLSQP stops on the saddle points the symmetric lattice points start towards -, beam 3) except 11 voxels of chapadlo
+    (other local minima, up to 9 %); round 2: 12 / 89 differing voxels on beam / chapadlo, up to 0.57 cell farther.
+    SLSQP results that are not on the surface (|rho - rho_t| > 1e-9: 47 voxels of chapadlo) are set apart - the
+    reference uses whatever NLopt returns (ComputeCoordsOnIso.jl:79-86), but a distance to a point off the surface is
+    no target.  At the reference's own tolerances (1e-5) SLSQP itself is 1e-6 away from its converged answer on
+    2 162 / 929 / 1 163 voxels: that, not the restatement, bounds parity with a Julia run."""
+    from test_oracle_drift import one_hex
     F = np.load(os.path.join(GOLD, "slsqp_fields.npz"))
-    X, IEN, rho = load_fixture(name)
-    rn = oracle.dense_in_nodes(X, IEN, rho)
-    g, _ = oracle.auto_grid(X, IEN)
+    if name == "1hex_el":
+        X, IEN, rn = one_hex()
+        g = oracle.grid_make(X.min(0), X.max(0), 15, 3)
+    else:
+        X, IEN, rho = load_fixture(name)
+        rn = oracle.dense_in_nodes(X, IEN, rho)
+        g, _ = oracle.auto_grid(X, IEN)
     d, _, _ = oracle.eval_distances(X, IEN, rn, 0.5, g, 1.1, want_xp=False)
-    band, n_tight, n_ref, n_self = SLSQP_FIELD_COUNTS[name]
+    band, n_near, n_far, n_ref, n_self = SLSQP_FIELD_COUNTS[name]
     real = d < 1e9
     assert int(real.sum()) == band
-    got = {}
-    for tag in ("tight", "ref"):
-        r = F[f"{name}_{tag}"]
-        assert np.array_equal(r == 1e10, d == 1e10)
-        rel = np.abs(d[real] - r[real]) / np.maximum(r[real], 1e-300)
-        got[tag] = int((rel > 1e-6).sum())
-    r1, r2 = F[f"{name}_ref"][real], F[f"{name}_tight"][real]
-    got["self"] = int((np.abs(r1 - r2) / np.maximum(r2, 1e-300) > 1e-6).sum())
-    print(f"{name}: {band} band voxels; beyond 1e-6 of converged SLSQP {got['tight']}, of SLSQP at 1e-5 {got['ref']}, "
-          f"SLSQP 1e-5 vs converged {got['self']}")
-    assert got["tight"] <= n_tight and got["ref"] <= n_ref + 5 and abs(got["self"] - n_self) <= 5
+    r = F[f"{name}_tight"]
+    assert np.array_equal(r == 1e10, d == 1e10) and np.array_equal(F[f"{name}_ref"] == 1e10, d == 1e10)
+    on = real.copy()
+    on[F[f"{name}_tight_offsurface"]] = False
+    rel = (d[on] - r[on]) / np.maximum(r[on], 1e-300)
+    near, far = int((rel < -1e-6).sum()), int((rel > 1e-6).sum())
+    rr = F[f"{name}_ref"]
+    ref = int((np.abs(d[real] - rr[real]) / np.maximum(rr[real], 1e-300) > 1e-6).sum())
+    self_ = int((np.abs(rr[real] - r[real]) / np.maximum(r[real], 1e-300) > 1e-6).sum())
+    print(f"{name}: {band} band voxels; vs converged SLSQP on the surface ({int(on.sum())} voxels): nearer {near}, farther {far}"
+          f" (max {rel.max():.2e}); beyond 1e-6 of SLSQP at 1e-5: {ref}; SLSQP 1e-5 vs converged: {self_}")
+    assert far <= n_far and abs(near - n_near) <= 3 and ref <= n_ref + 5 and abs(self_ - n_self) <= 5

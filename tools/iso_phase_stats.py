@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase visit / active-lane counts of iso_project_hex_pl_kernel on the NS workload.
 Needs a diagnostic build (adds -DR2S_ISO_STATS to the hipcc line of __graft_entry__.build) loaded through
-R2S_LIB_OVERRIDE=build_ab/stats.so python tools/iso_phase_stats.py"""
+R2S_LIB_OVERRIDE=diag/stats.so python tools/iso_phase_stats.py  (tools/build_diag.sh builds it)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
@@ -24,10 +24,13 @@ for _ in range(3):   # the last run is the one reported (allocations and first t
     st = plan.run(dX, dI, dR, 0.5, g, sdf=out)
     torch.cuda.synchronize()
 L.r2s_debug_iso_stats(buf, 1)
-names = ["EVAL", "QP", "POST", "LS", "UPD", "trip", "finish"]
+names = ["EVAL", "QP", "FINISH", "bail", "-", "trip", "done", "QP2"]
 for i, n in enumerate(names):
+    if n == "-":
+        continue
     v, l = buf[2 * i], buf[2 * i + 1]
     print(f"{n:7s} visits {v:10d} lanes {l:12d} util {l / max(1, 64 * v):.3f}")
+print("handed over to the complete solver: %d of %d pairs (%.2f %%)" % (buf[7], buf[13] + buf[7], 100.0 * buf[7] / max(1, buf[13] + buf[7])))
 print("pairs (finished lanes)", buf[13], "chunks", st["n_iso_chunks"])
 print("iterations/4 histogram", [buf[16 + i] for i in range(16)])
 print("log2(trips per pair) histogram", [buf[32 + i] for i in range(16)])

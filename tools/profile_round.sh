@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_kernel_stats.csv      kernel-trace --stats of `python3 bench.py` (same command as the bench line)
 #    gpurun_out/<tag>_traffic.json          FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes)
 #    gpurun_out/<tag>_valu_counters.json    SQ instruction / lane / FP64 counters per kernel (their own pass)
-# The library must be built beforehand (tools never build under the profiler).
+# The library must be built beforehand (nothing builds under the profiler: bench.py --no-build, tools use load_built).
 set -e
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_$TAG && mkdir -p $OUT/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/stats -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > $OUT/${TAG}_bench_under_trace.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/stats -- python3 $ROOT/bench.py --no-build --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > $OUT/${TAG}_bench_under_trace.json
 cp $(ls $OUT/prof_$TAG/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv
 echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_$TAG/fetch -- python3 $ROOT/tools/profile_modes.py --modes sdf --reps 2 > /dev/null
