@@ -35,15 +35,22 @@ def _fields(pkg, oracle, X, IEN, rn, rt, n_max, label):
 
 
 def _analytic_error(sdf, og):
-    """signed distance to the sphere r = 2.5 sqrt 3 (inside positive, as the reference's sign) against the field"""
-    pts = np.empty((og.ngp, 3))
+    """the field against the signed distance to the sphere r = 2.5 sqrt 3 (inside positive, as the reference's sign),
+    on the voxels within ONE CELL of the sphere: there the element that holds the nearest surface point has the voxel
+    in its band (delta = 1.1 cell), so the band value is the distance to the interpolant's surface; farther out a band
+    value may belong to a farther piece of surface (the reference's band construction, not an error).
+    Returns (unsigned error on those voxels, sign mismatches beyond the bias shell, band voxels, near voxels)."""
     nx, ny, nz = og.dims
     k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
-    for ax, idx in enumerate((i, j, k)):
-        pts[:, ax] = og.amin[ax] + og.cell * idx.ravel()
+    pts = np.stack([og.amin[0] + og.cell * i.ravel(), og.amin[1] + og.cell * j.ravel(), og.amin[2] + og.cell * k.ravel()], 1)
     exact = R_ISO - np.linalg.norm(pts, axis=1)
     real = np.abs(sdf) < 1e9
-    return np.abs(sdf[real] - exact[real]), real, exact
+    near = real & (np.abs(exact) < og.cell)
+    err = np.abs(np.abs(sdf[near]) - np.abs(exact[near]))
+    # the interpolant's surface lies up to 0.06 INSIDE the sphere (interpolation of the convex function r): signs may
+    # differ in that shell only
+    wrong = real & (np.sign(sdf) != np.sign(exact)) & (np.abs(exact) > 0.06)
+    return err, int(wrong.sum()), int(real.sum()), int(near.sum())
 
 
 def radial_density(X, side=10.0):
@@ -100,28 +107,28 @@ def test_sphere_composition(pkg, oracle):
 
 @pytest.mark.parametrize("elem", ["HEX8", "TET4"])
 def test_radial_cube_against_the_analytic_sphere(pkg, oracle, elem):
-    """the iso-surface of the interpolated density differs from the sphere by O(h^2) (h = 1, R = 4.33): the
-    interpolation error of r on an element is <= h^2 / (8 R) * 3 ~ 0.09 in density units of 1 / (5 sqrt 3) per unit
-    length, i.e. ~0.09 in length; on the N = 20 and N = 40 grids the band fields must stay within 0.12 of
-    |r - 2.5 sqrt 3| and their mean error within 0.05 - and HEX8 (trilinear) must beat TET4 (piecewise linear)"""
+    """distances to the iso-surface of the interpolated density against |r - 2.5 sqrt 3|: the interpolation error of the
+    convex function r on an element of size h is O(h^2 / R), so the error must fall by ~4 from the reference's 10^3 mesh
+    (h = 1: measured max 0.058 HEX8 / 0.080 TET4, mean 0.036) to a 20^3 mesh (h = 0.5: 0.0145 / 0.020, mean 0.0086)"""
     from rho2sdf_jl_amd import synthetic
-    X, IEN, rn = synthetic.radial_cube(10, 10.0)
-    assert np.allclose(rn, radial_density(X))
-    if elem == "TET4":
-        IEN = synthetic.hex_to_tets(IEN)
-    out = {}
-    for n_max in (20, 40):
-        sdf, pg, og, eq, band = _fields(pkg, oracle, X, IEN, rn, 0.5, n_max, f"radial cube {elem} N{n_max}")
-        err, real, exact = _analytic_error(sdf, og)
-        assert np.array_equal(np.sign(sdf[real]), np.sign(exact[real])) or (np.abs(exact[real][np.sign(sdf[real]) != np.sign(exact[real])]) < 0.12).all()
-        assert err.max() < 0.12 and err.mean() < 0.05, (elem, n_max, err.max(), err.mean())
-        out[n_max] = (err.max(), err.mean(), band, eq)
-    print(f"radial cube {elem}: " + "; ".join(f"N{n}: max |d - exact| {v[0]:.4f}, mean {v[1]:.4f}, {v[2]} band voxels ({v[3]} bit-equal)" for n, v in out.items()))
-    test_radial_cube_against_the_analytic_sphere.res = getattr(test_radial_cube_against_the_analytic_sphere, "res", {})
-    test_radial_cube_against_the_analytic_sphere.res[elem] = out[40][1]
-    if len(test_radial_cube_against_the_analytic_sphere.res) == 2:
-        r = test_radial_cube_against_the_analytic_sphere.res
-        assert r["HEX8"] <= r["TET4"] + 1e-3
+    res = {}
+    for n in (10, 20):
+        X, IEN, rn = synthetic.radial_cube(n, 10.0)
+        assert np.allclose(rn, radial_density(X))
+        if elem == "TET4":
+            IEN = synthetic.hex_to_tets(IEN)
+        sdf, pg, og, eq, band = _fields(pkg, oracle, X, IEN, rn, 0.5, 40, f"radial cube {elem} {n}^3")
+        err, wrong, nband, nnear = _analytic_error(sdf, og)
+        res[n] = (err.max(), err.mean(), wrong, nband, nnear, eq)
+    print(f"radial cube {elem}: " + "; ".join(
+        f"{n}^3 mesh: max {v[0]:.4f} mean {v[1]:.4f} on {v[4]} voxels within a cell of the sphere, {v[2]} signs wrong "
+        f"outside the bias shell, {v[5]}/{v[3]} band voxels bit-equal to the oracle" for n, v in res.items()))
+    assert res[10][0] < (0.065 if elem == "HEX8" else 0.09) and res[10][1] < 0.04
+    assert res[20][0] < 0.3 * res[10][0] and res[20][1] < 0.3 * res[10][1]          # O(h^2)
+    # HEX8: no sign differs from the sphere's outside the bias shell.  TET4: the reference's `sum(lambda) <= 1.0`
+    # on four barycentrics that add up to 1 + 1 ulp (ElementTypes.jl:104-106, SURVEY A10) rejects a few lattice
+    # points that lie inside a tetrahedron - 21 of 47 104 band voxels on the 10^3 mesh, restated as is
+    assert res[10][2] <= (0 if elem == "HEX8" else 25) and res[20][2] == 0
 
 
 def test_y_refined_cube(pkg, oracle):
@@ -129,10 +136,7 @@ def test_y_refined_cube(pkg, oracle):
     X, IEN, rn = refined_bottom_cube()
     assert X.shape == (1936, 3) and IEN.shape == (1500, 8)
     sdf, pg, og, eq, band = _fields(pkg, oracle, X, IEN, rn, 0.5, 40, "y-refined cube")
-    err, real, exact = _analytic_error(sdf, og)
-    pts_y = (og.amin[1] + og.cell * (np.arange(og.ngp) // og.dims[0] % og.dims[1]))[real]
-    lo, hi = err[pts_y < -0.5], err[pts_y > 0.5]
-    assert err.max() < 0.12 and err.mean() < 0.05
-    assert lo.mean() <= hi.mean() + 1e-3          # the refined half approximates the sphere at least as well
-    print(f"y-refined cube: {band} band voxels ({eq} bit-equal), max |d - exact| {err.max():.4f}, mean below / above the "
-          f"refinement interface {lo.mean():.4f} / {hi.mean():.4f}")
+    err, wrong, nband, nnear = _analytic_error(sdf, og)
+    assert err.max() < 0.065 and err.mean() < 0.036 and wrong == 0     # (uniform 10^3 mesh: mean 0.0364)
+    print(f"y-refined cube: {band} band voxels ({eq} bit-equal), {nnear} within a cell of the sphere: max {err.max():.4f} "
+          f"mean {err.mean():.4f}")
