@@ -528,6 +528,85 @@ R2S_DEV void iso_eval_fc(const ER& E, const double x[3], double rt, const double
 #define R2S_ISO_TOL 1e-6    // = the oracle's ISO_TOL (see the note there)
 #define R2S_ISO_MAX_RESTORE 3
 
+// qp_pattern for the patterns with TWO / ONE fixed variable(s) without the masked 3x3 machinery: the same IEEE operations
+// minus the ones whose operands the mask makes 0 or 1 (x * 1, x + 0 and 0 * finite are exact), so d, lam and q come out
+// bit for bit as from qp_pattern (checked against the oracle's qp_pattern on 7.2 M random pattern solves incl.
+// indefinite matrices, vanishing gradient components and degenerate bounds).  The non-convex search of
+// iso_project_full evaluates all 19 patterns in every such iteration; these cost a fifth of the generic form.
+// Return value as qp_pattern; kkt / next are not produced (the search takes the feasible pattern of least value).
+R2S_DEV int qp_fixed2(int k /* free */, int si, int sj, const Sym3& H, const double g[3], const double a[3], double e,
+                      const double lo[3], const double hi[3], QpOut& o)
+{
+    const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;   // the fixed ones, ascending
+    const double dBi = (si == 1) ? lo[i] : hi[i], dBj = (sj == 1) ? lo[j] : hi[j];
+    double ep = e;
+    ep = fma(-a[i], dBi, ep);
+    ep = fma(-a[j], dBj, ep);
+    double t = -g[k];
+    t = fma(-H(k, i), dBi, t);
+    t = fma(-H(k, j), dBj, t);
+    const double Hkk = H(k, k);
+    if (!(Hkk > 0.0)) return 0;
+    const double rdet = 1.0 / Hkk;
+    const double u = a[k] * rdet, v = t * rdet;
+    const double den = a[k] * u;
+    const bool vac = (a[k] == 0.0);
+    if (vac ? (ep != 0.0) : !(den > 0.0)) return 0;
+    const double lam = vac ? 0.0 : (a[k] * v - ep) / den;
+    const double dk = fma(-lam, u, v);
+    if (!(dk >= lo[k] - 1e-12 && dk <= hi[k] + 1e-12)) return 2;
+    o.d[i] = dBi; o.d[j] = dBj; o.d[k] = dk;
+    double q = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double Hd = dot3(H(r, 0), H(r, 1), H(r, 2), o.d[0], o.d[1], o.d[2]);
+        q = fma(o.d[r], fma(0.5, Hd, g[r]), q);
+    }
+    o.lam = lam;
+    o.q = q;
+    return 1;
+}
+
+R2S_DEV int qp_fixed1(int i /* fixed */, int si, const Sym3& H, const double g[3], const double a[3], double e,
+                      const double lo[3], const double hi[3], QpOut& o)
+{
+    const int j = (i == 0) ? 1 : 0, k = (i == 2) ? 1 : 2;   // the free ones, ascending
+    const double dBi = (si == 1) ? lo[i] : hi[i];
+    const double ep = fma(-a[i], dBi, e);
+    const double bj = fma(-H(j, i), dBi, -g[j]), bk = fma(-H(k, i), dBi, -g[k]);
+    const double Hjj = H(j, j), Hjk = H(j, k), Hkk = H(k, k);
+    // determinant and Sylvester minors of the masked matrix as qp_pattern rounds them (they differ with the position of
+    // the fixed variable: the cofactor of the unit diagonal entry is fma(Hjj, Hkk, -(Hjk Hjk)), the expansion along the
+    // first row of the other two cases is fma(Hjk, -Hjk, Hjj Hkk))
+    const double c2 = fma(Hjj, Hkk, -(Hjk * Hjk));
+    const double det = (i == 0) ? c2 : fma(Hjk, -Hjk, Hjj * Hkk);
+    const double m00 = (i == 0) ? 1.0 : Hjj;
+    const double c22 = (i == 2) ? c2 : Hjj;
+    if (!(m00 > 0.0 && c22 > 0.0 && det > 0.0)) return 0;
+    const double rdet = 1.0 / det;
+    const double uj = fma(-Hjk, a[k], Hkk * a[j]) * rdet;
+    const double uk = fma(Hjj, a[k], -Hjk * a[j]) * rdet;
+    const double vj = fma(-Hjk, bk, Hkk * bj) * rdet;
+    const double vk = fma(Hjj, bk, -Hjk * bj) * rdet;
+    const double den = fma(a[k], uk, a[j] * uj);
+    const bool vac = (a[j] == 0.0 && a[k] == 0.0);
+    if (vac ? (ep != 0.0) : !(den > 0.0)) return 0;
+    const double lam = vac ? 0.0 : (fma(a[k], vk, a[j] * vj) - ep) / den;
+    const double dj = fma(-lam, uj, vj), dk = fma(-lam, uk, vk);
+    if (!(dj >= lo[j] - 1e-12 && dj <= hi[j] + 1e-12)) return 2;
+    if (!(dk >= lo[k] - 1e-12 && dk <= hi[k] + 1e-12)) return 2;
+    o.d[i] = dBi; o.d[j] = dj; o.d[k] = dk;
+    double q = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double Hd = dot3(H(r, 0), H(r, 1), H(r, 2), o.d[0], o.d[1], o.d[2]);
+        q = fma(o.d[r], fma(0.5, Hd, g[r]), q);
+    }
+    o.lam = lam;
+    o.q = q;
+    return 1;
+}
+
 // H = G + S + sg a a^T (upper triangle), g' = g - sg e a: the QP data of the oracle's iso_project_hex8
 R2S_DEV void iso_qp_data(const double G[3][3], const double S[3], const double a[3], const double g[3], double sg,
                          double e, Sym3& H, double gp[3])
@@ -605,15 +684,18 @@ R2S_DEV bool iso_restore(const ER& E, const double x[3], double rt, const double
     return found;
 }
 
+// Returns the number of the last iteration (R2S_ISO_MAXIT + 1: cap).  Start state (xi, mu0, Delta0, pat0, it0): (0, 0, 2, 0, 0) for a run from the start, or the state at the beginning of
+// the iteration in which the fast lane machine gave up - the same thing, provided no earlier iterate was exactly
+// feasible (the run remembers the nearest feasible iterate for the case that it fails: IsoLane::seen).
 template <class ER>
-R2S_DEV void iso_project_full(const ER& E, double rmax_abs, const double x[3], double rt, double xi[3])
+R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], double rt, double xi[3], double mu0 = 0.0,
+                              double Delta0 = 2.0, int pat0 = 0, int it0 = 0)
 {
-    xi[0] = xi[1] = xi[2] = 0.0;
-    double mu = 0.0, lam = 0.0, Delta = 2.0;
-    int pat = 0, nrest = 0;
+    double mu = mu0, lam = 0.0, Delta = Delta0;
+    int pat = pat0, nrest = 0;
     const double rtol = fmax(fabs(rt), rmax_abs) * 1e-14;
     double fbest = INFINITY, xbest[3] = {0.0, 0.0, 0.0};
-    for (int it = 0; it < R2S_ISO_MAXIT; ++it) {
+    for (int it = it0; it < R2S_ISO_MAXIT; ++it) {
         double r[3], J[3][3], a[3], g[3], G[3][3], M2[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -740,7 +822,19 @@ R2S_DEV void iso_project_full(const ER& E, double rmax_abs, const double x[3], d
                 double bestq = INFINITY;
                 for (int ip = 0; ip < 19; ++ip) {
                     const int p = c_pat_order[ip];
-                    if (qp_pattern(p, H, gp, a, e, lo, hi, o) == 1) {
+                    int rc;
+                    if (convex || ip == 0) {
+                        rc = qp_pattern(p, H, gp, a, e, lo, hi, o);
+                    } else if (ip < 7) {   // one variable fixed
+                        const int s0 = p % 3, s1 = (p / 3) % 3, s2 = p / 9;
+                        const int i = s0 ? 0 : (s1 ? 1 : 2);
+                        rc = qp_fixed1(i, s0 + s1 + s2, H, gp, a, e, lo, hi, o);
+                    } else {               // two fixed
+                        const int s0 = p % 3, s1 = (p / 3) % 3, s2 = p / 9;
+                        const int k = !s0 ? 0 : (!s1 ? 1 : 2);
+                        rc = qp_fixed2(k, (k == 0) ? s1 : s0, (k == 2) ? s1 : s2, H, gp, a, e, lo, hi, o);
+                    }
+                    if (rc == 1) {
                         if ((convex && o.kkt) || o.q < bestq) {
                             bestq = o.q;
                             found = true;
@@ -864,14 +958,15 @@ R2S_DEV void iso_project_full(const ER& E, double rmax_abs, const double x[3], d
                 continue;
             }
             if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
-            return;
+            return it + 1;
         }
-        if (stop == 3 || stop == 4) return;
+        if (stop == 3 || stop == 4) return it + 1;
 #pragma unroll
         for (int i = 0; i < 3; ++i) xi[i] = fmin(fmax(fma(alpha, d[i], xi[i]), -1.0), 1.0);
-        if (stop == 1) return;
+        if (stop == 1) return it + 1;
     }
     if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
+    return R2S_ISO_MAXIT + 1;
 }
 
 // ---- the fast path of the same solver as a per-lane state machine ---------------------------------------
@@ -886,7 +981,9 @@ R2S_DEV void iso_project_full(const ER& E, double rmax_abs, const double x[3], d
 //   EVAL    fields, QP data, corner test            -> QP | FINISH | BAIL
 //   QP      ONE active-set pattern per visit        -> QP | FINISH | BAIL
 //   FINISH  step test, merit parameter, the full-step trial, trust region, iterate update -> EVAL | DONE | BAIL
+#ifndef R2S_ISO_FAST_IT
 #define R2S_ISO_FAST_IT 16
+#endif
 enum { ISO_IDLE = 0, ISO_EVAL, ISO_QP, ISO_FINISH, ISO_DONE, ISO_BAIL };
 
 struct IsoLane {
@@ -898,6 +995,7 @@ struct IsoLane {
     double f, c, lam_new;
     int pat, it, p, step, phase;
     bool corner;
+    bool seen;   // an EARLIER iterate of this run was exactly feasible (c == 0): a hand-over has to start from xi = 0 then
 };
 
 // step bounds of the current iterate: the box |xi| <= 1 cut with the trust region
@@ -916,6 +1014,7 @@ R2S_DEV void iso_lane_start(IsoLane& s, const double x[3])
     s.xi[0] = s.xi[1] = s.xi[2] = 0.0;
     s.mu = 0.0; s.Delta = 2.0;
     s.pat = 0; s.it = 0;
+    s.seen = false;
     s.phase = ISO_EVAL;
 }
 
@@ -1022,8 +1121,9 @@ R2S_DEV void iso_lane_qp(IsoLane& s)
     const double e = -s.c;
     const int rc = qp_pattern(s.p, s.H, gp, s.a, e, lo, hi, o);
     if (rc == 1 && o.kkt) {
-        // active-set walk: the first primal feasible KKT pattern is the minimiser
-        s.pat = s.p;
+        // active-set walk: the first primal feasible KKT pattern is the minimiser (s.p; it becomes the warm-start
+        // pattern when the step is accepted - until then xi, mu, Delta, pat are the state at the iteration's start,
+        // which is what a hand-over passes on)
 #pragma unroll
         for (int i = 0; i < 3; ++i) s.d[i] = fmin(fmax(o.d[i], lo[i]), hi[i]);
         s.lam_new = o.lam;
@@ -1064,15 +1164,17 @@ R2S_DEV void iso_lane_finish(const ER& E, double rt, double rtol, IsoLane& s)
                 return;
             }
         }
-        s.mu = mu_t;
-        const double D = fma(-s.mu, pred_c, gd);
-        const double phi0 = fma(s.mu, fabs(s.c), s.f);
+        const double D = fma(-mu_t, pred_c, gd);
+        const double phi0 = fma(mu_t, fabs(s.c), s.f);
         double xt[3], ft, ct;
 #pragma unroll
         for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(fma(1.0, s.d[i], s.xi[i]), -1.0), 1.0);
         iso_eval_fc(E, s.x, rt, xt, ft, ct);
-        if (!(fma(s.mu, fabs(ct), ft) <= fma(1e-4 * 1.0, D, phi0))) { s.phase = ISO_BAIL; return; }   // correction / back-tracking
+        if (!(fma(mu_t, fabs(ct), ft) <= fma(1e-4 * 1.0, D, phi0))) { s.phase = ISO_BAIL; return; }   // correction / back-tracking
+        s.mu = mu_t;
         s.Delta = fmin(2.0, fmax(s.Delta, 2.0 * dmax));
+        if (!s.corner) s.pat = s.p;
+        s.seen = s.seen || (s.c == 0.0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) s.xi[i] = xt[i];
         s.it += 1;

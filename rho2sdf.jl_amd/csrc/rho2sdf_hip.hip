@@ -632,7 +632,8 @@ __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, con
 // influence on the results (every pair writes its own slot).
 __global__ void __launch_bounds__(1024) work_order_kernel(const uint8_t* __restrict__ hard, const uint32_t* __restrict__ nchunks,
                                                           uint32_t nitems, uint32_t* __restrict__ perm,
-                                                          uint32_t* __restrict__ wchunks)
+                                                          uint32_t* __restrict__ wchunks, uint32_t split_rank,
+                                                          uint32_t* __restrict__ split_pos)
 {
     // counting sort over the 16 hardness ranks (rank 0 first); items that are not iso items carry rank 0 and no chunks
     __shared__ uint32_t cnt[16], base[16], cur[16];
@@ -643,6 +644,8 @@ __global__ void __launch_bounds__(1024) work_order_kernel(const uint8_t* __restr
     if (threadIdx.x == 0) {
         uint32_t b = 0;
         for (int q = 0; q < 16; ++q) { base[q] = b; b += cnt[q]; }
+        // work-order position of the first item of rank >= split_rank: where part B of the projection starts
+        *split_pos = (split_rank < 16u) ? base[split_rank] : nitems;
     }
     __syncthreads();
     for (uint32_t it = threadIdx.x; it < nitems; it += blockDim.x) {
@@ -979,7 +982,10 @@ struct alignas(8) IsoStraggler {
     double x[3];
     uint64_t slot;
     uint32_t el;
-    uint32_t pad;
+    int32_t it;       // state at the start of the iteration the fast path gave up in (0, 0, 2, 0, 0 = from the start)
+    double xi[3], mu, Delta;
+    int32_t pat;
+    int32_t pad;
 };
 #define R2S_ISO_UNSOLVED (-1.0)   // result slot of a handed-over pair until the complete solver has been there
 #define R2S_ISO_SLOTS 4
@@ -1028,13 +1034,22 @@ extern "C" int r2s_debug_iso_stats(unsigned long long* out, int reset)
 #else
 #define ISO_STAT(p, cond)
 #endif
-__global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
+template <int WPS>
+__global__ void __launch_bounds__(64, WPS) iso_project_hex_pl_kernel(
     const BandItem* __restrict__ items, uint32_t nitems, const uint32_t* __restrict__ chunk_off, uint32_t nchunks,
     uint32_t group, const ElemRec* __restrict__ erec, GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
     double* __restrict__ res_xp, uint32_t* __restrict__ counter, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ abort_flag,
-    IsoStraggler* __restrict__ strag, uint32_t strag_cap, uint32_t* __restrict__ strag_cnt /* [0] entries, [1] overflow */)
+    IsoStraggler* __restrict__ strag, uint32_t strag_cap, uint32_t* __restrict__ strag_cnt /* entries */,
+    uint32_t* __restrict__ strag_ovf, const uint32_t* __restrict__ split_pos, int part)
 {
     if (*abort_flag) return;   // speculated sizes of this call did not hold (run_impl)
+    // part 0: the chunks in front of the split (items of the hard ranks), part 1: the rest, part 2: everything.  The
+    // pairs part 0 hands over are solved (iso_straggler_kernel, third stream) while part 1 runs.
+    uint32_t c_lo = 0;
+    if (part != 2) {
+        const uint32_t cs = chunk_off[*split_pos];
+        if (part == 0) nchunks = cs; else c_lo = cs;
+    }
     __shared__ IsoElemLds slots[R2S_ISO_SLOTS];
     const uint32_t lane = threadIdx.x;
 #ifdef R2S_ISO_WAVE_END
@@ -1079,10 +1094,16 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
                     e.x[0] = s.x[0]; e.x[1] = s.x[1]; e.x[2] = s.x[2];
                     e.slot = (uint64_t)my;
                     e.el = (uint32_t)slots[eslot].el;
+                    const bool resume = !s.seen;
+                    e.it = resume ? s.it : 0;
+                    e.xi[0] = resume ? s.xi[0] : 0.0; e.xi[1] = resume ? s.xi[1] : 0.0; e.xi[2] = resume ? s.xi[2] : 0.0;
+                    e.mu = resume ? s.mu : 0.0;
+                    e.Delta = resume ? s.Delta : 2.0;
+                    e.pat = resume ? s.pat : 0;
                     e.pad = 0;
                     strag[idx] = e;
                 } else {
-                    strag_cnt[1] = 1u;   // list full: iso_sweep_kernel finds the pair by its result slot
+                    *strag_ovf = 1u;   // list full: iso_sweep_kernel finds the pair by its result slot
                 }
                 res[my] = R2S_ISO_UNSOLVED;
                 s.phase = ISO_IDLE;
@@ -1138,7 +1159,7 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
                     if (c >= c_end) {
                         uint32_t cc = 0;
                         if (lane == 0) cc = atomicAdd(counter, group);
-                        c = __builtin_amdgcn_readfirstlane(cc);
+                        c = c_lo + __builtin_amdgcn_readfirstlane(cc);
                         if (c >= nchunks) {
 #ifdef R2S_ISO_WAVE_END
                             if (!exhausted && lane == 0 && blockIdx.x < 4094) {
@@ -1242,15 +1263,31 @@ __global__ void __launch_bounds__(64 R2S_ISO_LB2) iso_project_hex_pl_kernel(
     }
 }
 
+#ifdef R2S_STRAG_DIAG   // diagnostic build only (tools/strag_diag.py)
+__device__ unsigned long long g_strag_diag[3 * 16384];
+extern "C" int r2s_debug_strag_diag(unsigned long long* out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strag_diag), sizeof(unsigned long long) * 3 * 16384) != hipSuccess) return 1;
+    static unsigned long long z[3 * 16384];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_strag_diag), z, sizeof z) != hipSuccess;
+}
+#endif
 // The pairs the fast path handed over, compacted: one lane per pair runs the complete solver (iso_project_full) from
 // xi = 0 - the oracle's iteration operation for operation - and writes the pair's result slot.
-__global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
+// WPS = 3: 168 registers (the rest spills) - the instantiation that runs BESIDE part 1 of the projection kernel, whose two
+// wavefronts per SIMD leave room for exactly that; WPS = 2 (no spills) when nothing runs beside it.
+template <int WPS>
+__global__ void __launch_bounds__(64, WPS) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
                                                            const uint32_t* __restrict__ strag_cnt, const ElemRec* __restrict__ erec,
                                                            double rho_t, double* __restrict__ res, double* __restrict__ res_xp,
                                                            const uint32_t* __restrict__ abort_flag)
 {
     if (*abort_flag) return;
     const uint32_t n = min(strag_cnt[0], strag_cap);
+#ifdef R2S_STRAG_DIAG
+    const unsigned long long t0 = wall_clock64();
+    int its_max = 0, its_sum = 0;
+#endif
     for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
         const IsoStraggler e = strag[i];
         const ElemRec& E = erec[e.el];
@@ -1262,8 +1299,13 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
             K.C[k][0] = E.C[k][0]; K.C[k][1] = E.C[k][1]; K.C[k][2] = E.C[k][2];
             K.Cr[k] = E.Cr[k];
         }
-        double xi[3];
-        iso_project_full(K, fmax(fabs(E.rmax), fabs(E.rmin)), e.x, rho_t, xi);
+        double xi[3] = {e.xi[0], e.xi[1], e.xi[2]};
+#ifdef R2S_STRAG_DIAG
+        const int its = iso_project_full(K, fmax(fabs(E.rmax), fabs(E.rmin)), e.x, rho_t, xi, e.mu, e.Delta, e.pat, e.it) - e.it;
+        its_max = its; its_sum = its;
+#else
+        iso_project_full(K, fmax(fabs(E.rmax), fabs(E.rmin)), e.x, rho_t, xi, e.mu, e.Delta, e.pat, e.it);
+#endif
         double N[8], xp[3];
         hex8_shape(xi, N);
 #pragma unroll
@@ -1280,6 +1322,16 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
             res_xp[3 * e.slot + 2] = xp[2];
         }
     }
+#ifdef R2S_STRAG_DIAG
+    {   // per wavefront: cycles, longest and summed SQP iterations of its lanes
+        for (int o = 32; o > 0; o >>= 1) { its_max = max(its_max, __shfl_xor(its_max, o)); its_sum += __shfl_xor(its_sum, o); }
+        if (threadIdx.x == 0 && blockIdx.x < 16384) {
+            g_strag_diag[3 * blockIdx.x] = wall_clock64() - t0;
+            g_strag_diag[3 * blockIdx.x + 1] = (unsigned long long)its_max;
+            g_strag_diag[3 * blockIdx.x + 2] = (unsigned long long)its_sum;
+        }
+    }
+#endif
 }
 
 // Only when the straggler list overflowed (a mesh on which more than ~6 % of the pairs leave the fast path - tiny grids
@@ -1292,7 +1344,7 @@ __global__ void __launch_bounds__(256) iso_sweep_kernel(const BandItem* __restri
                                                         double* __restrict__ res_xp, const uint32_t* __restrict__ strag_cnt,
                                                         const uint32_t* __restrict__ abort_flag)
 {
-    if (*abort_flag || strag_cnt[1] == 0u) return;
+    if (*abort_flag || *strag_cnt == 0u) return;   // (strag_cnt: the overflow flag)
     const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
     const int lane = threadIdx.x & 63;
     for (uint32_t c = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6); c < nchunks; c += nw) {
@@ -1309,7 +1361,7 @@ __global__ void __launch_bounds__(256) iso_sweep_kernel(const BandItem* __restri
         const TileBox tb = tile_box(T.lo, T.dim);
         const size_t slot = tile_slot(T.store_off, tb, T.lo[0] + li, T.lo[1] + lj, T.lo[2] + lk);
         if (res[slot] != R2S_ISO_UNSOLVED) continue;
-        double x[3], xi[3];
+        double x[3], xi[3] = {0.0, 0.0, 0.0};
         x[0] = grid_coord(g, 0, T.lo[0] + li);
         x[1] = grid_coord(g, 1, T.lo[1] + lj);
         x[2] = grid_coord(g, 2, slab_global_k(sl, T.lo[2] + lk));
@@ -2030,7 +2082,7 @@ struct r2s_plan {
     int n_cu = 256;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
-    DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], scan_tmp2[3], nchunks, chunk_off, iso_res, iso_res_xp, strag;
+    DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], scan_tmp2[3], nchunks, chunk_off, iso_res, iso_res_xp, strag, split_pos;
     DevBuf perm, wchunks, hardflag;   // work order of the persistent projection kernel (HEX8)
     DevBuf sbox, s_nchunks, s_chunk_off, sres;   // item-major inverse maps of the sign pass (HEX8)
     DevBuf nstore, store_off, s_nstore, s_store_off;   // storage (tile) chunk counts / offsets
@@ -2052,6 +2104,7 @@ struct r2s_plan {
     hipStream_t st2 = nullptr;
     hipStream_t st3 = nullptr;   // bounding half-spaces (hex_planes_kernel), beside the chains of the other two during preparation
     hipEvent_t ev2[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev3[2] = {nullptr, nullptr};   // part A of the HEX8 projection done / its stragglers done (third stream)
 };
 
 // exclusive scans of one or two (in1 != nullptr) arrays of n entries each
@@ -2190,6 +2243,7 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     HIP_TRY(hipHostGetDevicePointer((void**)&P->d_pinned, P->h_pinned, 0));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&P->ev3[i], hipEventDisableTiming));
     {
         // high priority: the short stages of the second stream (sentinel sweep, inverse maps of the sign pass,
         // sign-only gather) get wave slots ahead of the long persistent projection kernel.  Measured on the
@@ -2211,7 +2265,7 @@ void r2s_plan_destroy(r2s_plan* P)
     DevBuf* all[] = {&P->deg, &P->ine_ptr, &P->ine, &P->cursor, &P->erec, &P->cls, &P->fmask, &P->nitems,
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
                      &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any, &P->active_sonly, &P->active_lean, &P->active_tri, &P->tri,
-                     &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp, &P->strag,
+                     &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp, &P->strag, &P->split_pos,
                      &P->perm, &P->wchunks, &P->hardflag, &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres, &P->nstore, &P->store_off, &P->s_nstore, &P->s_store_off,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2], &P->scan_tmp2[0], &P->scan_tmp2[1], &P->scan_tmp2[2]};
     for (DevBuf* b : all) b->release();
@@ -2220,6 +2274,8 @@ void r2s_plan_destroy(r2s_plan* P)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
     for (int i = 0; i < 8; ++i)
         if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
+    for (int i = 0; i < 2; ++i)
+        if (P->ev3[i]) (void)hipEventDestroy(P->ev3[i]);
     if (P->st2) (void)hipStreamDestroy(P->st2);
     if (P->st3) (void)hipStreamDestroy(P->st3);
     delete P;
@@ -2238,21 +2294,69 @@ static uint32_t iso_straggler_cap(uint32_t n_store)
     return (uint32_t)std::max<uint64_t>(slots / 16, std::min<uint64_t>(slots, 1ull << 20));
 }
 
-// behind iso_project_hex_pl_kernel on the same stream: the complete solver on the handed-over pairs, then the sweep
-// that only does something when the list overflowed (both sized without knowing the count: nothing waits for it)
-static void iso_stragglers(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32_t n_chunks, uint32_t strag_cap,
+// The HEX8 projection on stream `st`: part A of the persistent fast-path kernel (items of the hard
+// ranks, handed out first), part B (the rest); the pairs A hands over are solved by the complete solver on the third
+// stream WHILE B runs (the 168-register instantiation fits beside B's two wavefronts per SIMD), B's own few behind it;
+// last the sweep that only does something when a list overflowed.  Nothing here waits for a count on the host.
+// counters: [8] / [9] chunk counters of A / B, [12] / [14] list entries of A / B, [13] overflow flag.
+static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32_t n_chunks, uint32_t n_store, uint32_t wps,
                            const GridDev& g, const SlabInfo& s, double rho_t, double* res_xp, uint32_t* counters,
                            const uint32_t* abort_flag)
 {
-    // one 64-pair batch per wavefront as long as the list holds fewer than a million pairs (a wavefront takes as long as
-    // its slowest lane needs and executes the union of its lanes' branches: a second batch doubles that); the
-    // wavefronts beyond the count leave at once
-    const uint32_t waves = std::min<uint32_t>((strag_cap + 63u) / 64u, 16384u);
-    iso_straggler_kernel<<<waves, 64, 0, st>>>(P->strag.as<IsoStraggler>(), strag_cap, counters + 12, P->erec.as<ElemRec>(),
-                                               rho_t, P->iso_res.as<double>(), res_xp, abort_flag);
-    iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(),
-                                                             n_chunks, P->perm.as<uint32_t>(), P->erec.as<ElemRec>(), g, s, rho_t,
-                                                             P->iso_res.as<double>(), res_xp, counters + 12, abort_flag);
+    static const int free_env = getenv("R2S_ISO_FREE") ? atoi(getenv("R2S_ISO_FREE")) : 0;   // tuning knob: fewer persistent wavefronts
+    static const bool split_env = getenv("R2S_ISO_SPLIT") && atoi(getenv("R2S_ISO_SPLIT"));   // experiment (measured: slower)
+    const uint32_t resident = (uint32_t)P->n_cu * 4u * wps - (uint32_t)std::min(std::max(free_env, 0), (int)P->n_cu * 4);
+    // chunks per fetch: 4 when every wavefront gets dozens of them (1-8: +-2 %), fewer for a small share of the grid
+    // (one rank of 4 / 8), where coarse groups leave wavefronts unevenly loaded (-15 % at 13 chunks/wave)
+    const uint32_t group = std::min(4u, std::max(1u, n_chunks / (resident * 12u)));
+    const uint32_t ngroups = (n_chunks + group - 1) / group;
+    const uint32_t cap = iso_straggler_cap(n_store);
+    ENSURE(P->strag, sizeof(IsoStraggler) * (size_t)cap);
+    IsoStraggler* const list = P->strag.as<IsoStraggler>();
+    const uint32_t grid = std::min(ngroups, resident);
+    const BandItem* items = P->items.as<BandItem>();
+    const uint32_t* chunk_off = P->chunk_off.as<uint32_t>();
+    const uint32_t* perm = P->perm.as<uint32_t>();
+    const ElemRec* erec = P->erec.as<ElemRec>();
+    double* res = P->iso_res.as<double>();
+    // two instantiations: 168 registers (3 wavefronts per SIMD, 48 B of scratch per lane) when the kernel has the GPU to
+    // itself, 2 per SIMD without scratch when it starts beside the binning (early launch, see run_impl)
+#define ISO_PL_LAUNCH(...)                                                                      \
+    do {                                                                                        \
+        if (wps >= 3) iso_project_hex_pl_kernel<3><<<grid, 64, 0, st>>>(__VA_ARGS__);           \
+        else iso_project_hex_pl_kernel<2><<<grid, 64, 0, st>>>(__VA_ARGS__);                    \
+    } while (0)
+    const bool split = split_env && n_chunks >= 8u * resident;   // (a small share of the grid: one part, nothing to hide behind)
+    const uint32_t waves_of = 16384u;
+    if (split) {
+        const uint32_t cap_a = cap - cap / 4, cap_b = cap / 4;
+        ISO_PL_LAUNCH(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
+                                                       counters + 8, perm, abort_flag, list, cap_a, counters + 12, counters + 13,
+                                                       P->split_pos.as<uint32_t>(), 0);
+        HIP_TRY(hipEventRecord(P->ev3[0], st));
+        ISO_PL_LAUNCH(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
+                                                       counters + 9, perm, abort_flag, list + cap_a, cap_b, counters + 14, counters + 13,
+                                                       P->split_pos.as<uint32_t>(), 1);
+        HIP_TRY(hipStreamWaitEvent(P->st3, P->ev3[0], 0));
+        iso_straggler_kernel<3><<<std::min<uint32_t>((cap_a + 63u) / 64u, waves_of), 64, 0, P->st3>>>(
+            list, cap_a, counters + 12, erec, rho_t, res, res_xp, abort_flag);
+        HIP_TRY(hipEventRecord(P->ev3[1], P->st3));
+        iso_straggler_kernel<2><<<std::min<uint32_t>((cap_b + 63u) / 64u, waves_of), 64, 0, st>>>(
+            list + cap_a, cap_b, counters + 14, erec, rho_t, res, res_xp, abort_flag);
+        HIP_TRY(hipStreamWaitEvent(st, P->ev3[1], 0));
+    } else {
+        ISO_PL_LAUNCH(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
+                                                       counters + 8, perm, abort_flag, list, cap, counters + 12, counters + 13,
+                                                       P->split_pos.as<uint32_t>(), 2);
+        // one 64-pair batch per wavefront as long as the list holds fewer than a million pairs (a wavefront takes as
+        // long as its slowest lane and executes the union of its lanes' branches); the wavefronts beyond the count
+        // leave at once
+        iso_straggler_kernel<2><<<std::min<uint32_t>((cap + 63u) / 64u, waves_of), 64, 0, st>>>(
+            list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag);
+    }
+    iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(items, n_items, chunk_off, n_chunks, perm, erec, g, s, rho_t, res, res_xp,
+                                                             counters + 13, abort_flag);
+    return 0;
 }
 
 template <class ET>
@@ -2448,8 +2552,11 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
             ENSURE(P->perm, sizeof(uint32_t) * (size_t)n_items);
             ENSURE(P->wchunks, sizeof(uint32_t) * (size_t)(n_items + 1));
+            ENSURE(P->split_pos, 64);
+            static const int split_rank_env = getenv("R2S_ISO_SPLIT_RANK") ? atoi(getenv("R2S_ISO_SPLIT_RANK")) : 3;   // tuning knob
             work_order_kernel<<<1, 1024, 0, st>>>(P->hardflag.as<uint8_t>(), P->nchunks.as<uint32_t>(), n_items,
-                                                  P->perm.as<uint32_t>(), P->wchunks.as<uint32_t>());
+                                                  P->perm.as<uint32_t>(), P->wchunks.as<uint32_t>(), (uint32_t)split_rank_env,
+                                                  P->split_pos.as<uint32_t>());
             work_counts = P->wchunks.as<uint32_t>();   // chunk_off then runs in work order (HEX8)
         }
         int rc = scan_exclusive2(P, work_counts, P->chunk_off.as<uint32_t>(), P->nstore.as<uint32_t>(),
@@ -2483,21 +2590,11 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             ENSURE(P->iso_res, sizeof(double) * 64 * (size_t)std::max<uint32_t>(n_store_e, 1));
             static const int wps_env = getenv("R2S_ISO_WPS") ? atoi(getenv("R2S_ISO_WPS")) : 0;   // tuning knob
             const uint32_t wps = (wps_env >= 1 && wps_env <= 3) ? (uint32_t)wps_env : 2u;
-            static const int free_env = getenv("R2S_ISO_FREE") ? atoi(getenv("R2S_ISO_FREE")) : 0;   // tuning knob: fewer persistent wavefronts
-            const uint32_t resident = (uint32_t)P->n_cu * 4u * wps - (uint32_t)std::min(std::max(free_env, 0), (int)P->n_cu * 4);
-            const uint32_t group = std::min(4u, std::max(1u, n_chunks_e / (resident * 12u)));
-            const uint32_t ngroups = (n_chunks_e + group - 1) / group;
             // (the sign counts of the second stream first: when the persistent wavefronts arrive in the middle of those
             //  kernels, one of them is left waiting until the projection kernel drains - 2 of 3 runs, +0.25 ms)
             if (sign_items) HIP_TRY(hipStreamWaitEvent(st, P->ev2[7], 0));
             HIP_TRY(hipEventRecord(P->ev[7], st));
-            const uint32_t strag_cap = iso_straggler_cap(n_store_e);
-            ENSURE(P->strag, sizeof(IsoStraggler) * (size_t)strag_cap);
-            iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
-                P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks_e, group, P->erec.as<ElemRec>(), g,
-                s, rho_t, P->iso_res.as<double>(), nullptr, counters + 8, P->perm.as<uint32_t>(), abort_flag,
-                P->strag.as<IsoStraggler>(), strag_cap, counters + 12);
-            iso_stragglers(P, st, n_items, n_chunks_e, strag_cap, g, s, rho_t, nullptr, counters, abort_flag);
+            { const int rc = iso_project_hex(P, st, n_items, n_chunks_e, n_store_e, wps, g, s, rho_t, nullptr, counters, abort_flag); if (rc) return rc; }
             HIP_TRY(hipEventRecord(P->ev[6], st));
             HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[6], 0));
             // (the sentinel sweep on a third stream right here, beside the binning: its wavefronts delay the first short
@@ -2669,27 +2766,15 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
             if (!early_iso) HIP_TRY(hipEventRecord(P->ev[7], st));
             if (want_dist && n_chunks && !early_iso) {
                 static const int wps_env = getenv("R2S_ISO_WPS") ? atoi(getenv("R2S_ISO_WPS")) : 0;   // tuning knob
-                const uint32_t wps = (wps_env >= 1 && wps_env <= 3) ? (uint32_t)wps_env : 3u;
-                static const int free_env = getenv("R2S_ISO_FREE") ? atoi(getenv("R2S_ISO_FREE")) : 0;   // tuning knob: wave slots left to the second stream
-                const uint32_t resident = (uint32_t)P->n_cu * 4u * wps - (uint32_t)std::min(std::max(free_env, 0), (int)P->n_cu * 4);   // CUs x SIMDs x waves/SIMD of this kernel
                 // (2 waves/SIMD, or 3 on only part of the SIMDs so that sign_project finds room beside them from the
                 // start: measured, no gain - the two kernels together are bound by their FP64 work either way)
-                // chunks per fetch: 4 when every wavefront gets dozens of them (1-8: +-2 %), fewer for a small share of
-                // the grid (one rank of 4 / 8), where coarse groups leave wavefronts unevenly loaded (-15 % at 13 chunks/wave)
-                const uint32_t group = std::min(4u, std::max(1u, n_chunks / (resident * 12u)));
-                const uint32_t ngroups = (n_chunks + group - 1) / group;
+                const uint32_t wps = (wps_env >= 1 && wps_env <= 3) ? (uint32_t)wps_env : 3u;
                 // (counters[8], the chunk counter, is zero since the start of the call)
                 // the sweep has to get its wavefronts placed before this kernel fills every SIMD for 3 ms (it is released
                 // once the second stream has reached the sweep; high priority does the rest)
                 if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[0], 0));
-                const uint32_t strag_cap = iso_straggler_cap(n_store);
-                ENSURE(P->strag, sizeof(IsoStraggler) * (size_t)strag_cap);
                 double* const res_xp = (mode & R2S_OUT_XP) ? P->iso_res_xp.as<double>() : nullptr;
-                iso_project_hex_pl_kernel<<<std::min(ngroups, resident), 64, 0, st>>>(
-                    P->items.as<BandItem>(), n_items, P->chunk_off.as<uint32_t>(), n_chunks, group, P->erec.as<ElemRec>(), g,
-                    s, rho_t, P->iso_res.as<double>(), res_xp, counters + 8, P->perm.as<uint32_t>(), abort_flag,
-                    P->strag.as<IsoStraggler>(), strag_cap, counters + 12);
-                iso_stragglers(P, st, n_items, n_chunks, strag_cap, g, s, rho_t, res_xp, counters, abort_flag);
+                { const int rc = iso_project_hex(P, st, n_items, n_chunks, n_store, wps, g, s, rho_t, res_xp, counters, abort_flag); if (rc) return rc; }
             }
             if (!early_iso) HIP_TRY(hipEventRecord(P->ev[6], st));
             if (fork) HIP_TRY(hipStreamWaitEvent(st, P->ev2[4], 0));   // (the sweep precedes it on that stream)

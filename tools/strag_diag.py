@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-wavefront duration / iteration counts of iso_straggler_kernel on the NS workload (diagnostic build:
+tools/build_diag.sh strag -DR2S_STRAG_DIAG; R2S_LIB_OVERRIDE=diag/strag.so python tools/strag_diag.py)"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft
+pkg = graft.load_built()
+import numpy as np, torch
+from rho2sdf_jl_amd import synthetic
+X, IEN, rn = synthetic.hex_mesh(46)
+g = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(512), 3)
+dev = torch.device("cuda:0")
+dX, dI, dR = (torch.from_numpy(t).to(dev) for t in (X, IEN, rn))
+out = torch.empty(g.ngp, dtype=torch.float64, device=dev)
+plan = pkg.DevicePlan(0)
+L = pkg._lib.lib()
+buf = (ctypes.c_ulonglong * (3 * 16384))()
+for _ in range(3):
+    L.r2s_debug_strag_diag(buf)
+    plan.run(dX, dI, dR, 0.5, g, sdf=out)
+    torch.cuda.synchronize()
+L.r2s_debug_strag_diag(buf)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 3).astype(np.int64)
+act = a[a[:, 2] > 0]
+print("active wavefronts", len(act), "pairs' iterations in all", act[:, 2].sum())
+cyc = act[:, 0] / 100.0   # wall_clock64 ticks at 100 MHz -> microseconds
+print("wavefront duration us: mean %.1f  median %.1f  p90 %.1f  p99 %.1f  max %.1f" % (cyc.mean(), np.median(cyc), np.percentile(cyc, 90), np.percentile(cyc, 99), cyc.max()))
+print("longest lane (iterations) per wavefront: mean %.1f max %d;  us per iteration of the longest lane: median %.1f" % (act[:, 1].mean(), act[:, 1].max(), np.median(cyc / np.maximum(act[:, 1], 1))))
+order = np.argsort(-cyc)[:8]
+print("slowest wavefronts (us, longest lane, sum):", [(round(float(cyc[i]), 1), int(act[i, 1]), int(act[i, 2])) for i in order])
