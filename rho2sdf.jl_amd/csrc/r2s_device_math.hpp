@@ -756,7 +756,7 @@ R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], do
         bool convex = true, corner = false, stall = false;
         int stop = 0;
         const bool near_feas = (fabs(c) <= 1e4 * rtol);
-        const double mu_keep = near_feas ? 0.5 : 1.0;
+        const double mu_keep = (fabs(c) <= 1e10 * rtol) ? 0.5 : 1.0;
         double lam_new = lam, alpha = 1.0, qstep = 0.0, dGd = 0.0;
         if (e > mplus) {
 #pragma unroll
@@ -1148,7 +1148,7 @@ R2S_DEV void iso_lane_finish(const ER& E, double rt, double rtol, IsoLane& s)
         const double ad = dot3(s.a[0], s.a[1], s.a[2], s.d[0], s.d[1], s.d[2]);
         const double pred_c = fabs(s.c) - fabs(s.c + ad);
         const double gd = dot3(s.g[0], s.g[1], s.g[2], s.d[0], s.d[1], s.d[2]);
-        const double mu_keep = near_feas ? 0.5 : 1.0;
+        const double mu_keep = (fabs(s.c) <= 1e10 * rtol) ? 0.5 : 1.0;
         double mu_t = s.corner ? s.mu : fmax(mu_keep * s.mu, 2.0 * fabs(s.lam_new));
         if (s.corner && pred_c > 0.0) {
             // a step that only buys feasibility: the merit function pays for the growth of f including its curvature
