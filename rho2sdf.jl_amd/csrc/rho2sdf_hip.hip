@@ -1280,7 +1280,7 @@ template <int WPS>
 __global__ void __launch_bounds__(64, WPS) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
                                                            const uint32_t* __restrict__ strag_cnt, const ElemRec* __restrict__ erec,
                                                            double rho_t, double* __restrict__ res, double* __restrict__ res_xp,
-                                                           const uint32_t* __restrict__ abort_flag)
+                                                           const uint32_t* __restrict__ abort_flag, uint32_t target_waves, int ppw_arg)
 {
     if (*abort_flag) return;
     const uint32_t n = min(strag_cnt[0], strag_cap);
@@ -1288,7 +1288,13 @@ __global__ void __launch_bounds__(64, WPS) iso_straggler_kernel(const IsoStraggl
     const unsigned long long t0 = wall_clock64();
     int its_max = 0, its_sum = 0;
 #endif
-    for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
+    // pairs per wavefront: a wavefront lasts as long as its slowest lane and executes the union of its lanes' branches,
+    // so fewer pairs per wavefront finish sooner as long as there are SIMDs to spare - 64 only when the list is long
+    // enough to give every SIMD two full wavefronts (a rank's share of a multi-GPU run has an eighth of the pairs and
+    // the same latency otherwise)
+    const uint32_t ppw = (ppw_arg > 0) ? (uint32_t)ppw_arg : min(64u, max(8u, (n + target_waves - 1u) / target_waves));
+    if (threadIdx.x >= ppw) return;
+    for (uint32_t i = blockIdx.x * ppw + threadIdx.x; i < n; i += gridDim.x * ppw) {
         const IsoStraggler e = strag[i];
         const ElemRec& E = erec[e.el];
         // the solver's coefficients in registers: the 30-odd field evaluations of a run must not each wait for memory
@@ -1324,11 +1330,10 @@ __global__ void __launch_bounds__(64, WPS) iso_straggler_kernel(const IsoStraggl
     }
 #ifdef R2S_STRAG_DIAG
     {   // per wavefront: cycles, longest and summed SQP iterations of its lanes
-        for (int o = 32; o > 0; o >>= 1) { its_max = max(its_max, __shfl_xor(its_max, o)); its_sum += __shfl_xor(its_sum, o); }
-        if (threadIdx.x == 0 && blockIdx.x < 16384) {
-            g_strag_diag[3 * blockIdx.x] = wall_clock64() - t0;
-            g_strag_diag[3 * blockIdx.x + 1] = (unsigned long long)its_max;
-            g_strag_diag[3 * blockIdx.x + 2] = (unsigned long long)its_sum;
+        if (blockIdx.x < 16384) {
+            atomicMax(&g_strag_diag[3 * blockIdx.x + 1], (unsigned long long)its_max);
+            atomicAdd(&g_strag_diag[3 * blockIdx.x + 2], (unsigned long long)its_sum);
+            if (threadIdx.x == 0) g_strag_diag[3 * blockIdx.x] = wall_clock64() - t0;
         }
     }
 #endif
@@ -2326,8 +2331,10 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
         if (wps >= 3) iso_project_hex_pl_kernel<3><<<grid, 64, 0, st>>>(__VA_ARGS__);           \
         else iso_project_hex_pl_kernel<2><<<grid, 64, 0, st>>>(__VA_ARGS__);                    \
     } while (0)
+    static const int ppw_env = getenv("R2S_STRAG_PPW") ? atoi(getenv("R2S_STRAG_PPW")) : 0;   // tuning knob: pairs per straggler wavefront
+    const uint32_t strag_target = (uint32_t)P->n_cu * 8u;   // two wavefronts per SIMD
     const bool split = split_env && n_chunks >= 8u * resident;   // (a small share of the grid: one part, nothing to hide behind)
-    const uint32_t waves_of = 16384u;
+    const uint32_t waves_of = 65536u;   // (>= list length / 8 for lists of up to half a million pairs; grid-stride beyond)
     if (split) {
         const uint32_t cap_a = cap - cap / 4, cap_b = cap / 4;
         ISO_PL_LAUNCH(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
@@ -2338,11 +2345,11 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
                                                        counters + 9, perm, abort_flag, list + cap_a, cap_b, counters + 14, counters + 13,
                                                        P->split_pos.as<uint32_t>(), 1);
         HIP_TRY(hipStreamWaitEvent(P->st3, P->ev3[0], 0));
-        iso_straggler_kernel<3><<<std::min<uint32_t>((cap_a + 63u) / 64u, waves_of), 64, 0, P->st3>>>(
-            list, cap_a, counters + 12, erec, rho_t, res, res_xp, abort_flag);
+        iso_straggler_kernel<3><<<std::min<uint32_t>((cap_a + 7u) / 8u, waves_of), 64, 0, P->st3>>>(
+            list, cap_a, counters + 12, erec, rho_t, res, res_xp, abort_flag, strag_target, ppw_env);
         HIP_TRY(hipEventRecord(P->ev3[1], P->st3));
-        iso_straggler_kernel<2><<<std::min<uint32_t>((cap_b + 63u) / 64u, waves_of), 64, 0, st>>>(
-            list + cap_a, cap_b, counters + 14, erec, rho_t, res, res_xp, abort_flag);
+        iso_straggler_kernel<2><<<std::min<uint32_t>((cap_b + 7u) / 8u, waves_of), 64, 0, st>>>(
+            list + cap_a, cap_b, counters + 14, erec, rho_t, res, res_xp, abort_flag, strag_target, ppw_env);
         HIP_TRY(hipStreamWaitEvent(st, P->ev3[1], 0));
     } else {
         ISO_PL_LAUNCH(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
@@ -2351,8 +2358,8 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
         // one 64-pair batch per wavefront as long as the list holds fewer than a million pairs (a wavefront takes as
         // long as its slowest lane and executes the union of its lanes' branches); the wavefronts beyond the count
         // leave at once
-        iso_straggler_kernel<2><<<std::min<uint32_t>((cap + 63u) / 64u, waves_of), 64, 0, st>>>(
-            list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag);
+        iso_straggler_kernel<2><<<std::min<uint32_t>((cap + 7u) / 8u, waves_of), 64, 0, st>>>(
+            list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, strag_target, ppw_env);
     }
     iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(items, n_items, chunk_off, n_chunks, perm, erec, g, s, rho_t, res, res_xp,
                                                              counters + 13, abort_flag);
