@@ -1294,6 +1294,9 @@ __global__ void __launch_bounds__(64, WPS) iso_straggler_kernel(const IsoStraggl
     // the same latency otherwise)
     const uint32_t ppw = (ppw_arg > 0) ? (uint32_t)ppw_arg : min(64u, max(8u, (n + target_waves - 1u) / target_waves));
     if (threadIdx.x >= ppw) return;
+    // (consecutive entries per wavefront: the list is in work order, neighbouring entries come from the same element and
+    //  need similar treatment - interleaving them over the wavefronts was measured: every wavefront then executes the
+    //  union of all kinds of runs in every iteration, 19 us per iteration instead of 14, the kernel 0.6 instead of 0.45 ms)
     for (uint32_t i = blockIdx.x * ppw + threadIdx.x; i < n; i += gridDim.x * ppw) {
         const IsoStraggler e = strag[i];
         const ElemRec& E = erec[e.el];
