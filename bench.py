@@ -47,8 +47,11 @@ def load_committed_profile(kernel):
         vfile = os.path.join(ROOT, "profiles", f"{rnd}_valu_counters.json")
         if not (os.path.exists(tfile) and os.path.exists(vfile)):
             continue
-        t = json.load(open(tfile))["kernels"].get(kernel)
-        v = json.load(open(vfile)).get(kernel)
+        def pick(d):   # templated kernels appear as name<args>: the instantiation with the most launches
+            c = [(k, x) for k, x in d.items() if k == kernel or k.startswith(kernel + "<")]
+            return max(c, key=lambda kx: kx[1].get("launches", 0))[1] if c else None
+        t = pick(json.load(open(tfile))["kernels"])
+        v = pick(json.load(open(vfile)))
         if not t or not v:
             continue
         traffic = None
