@@ -369,7 +369,9 @@ int orc_inv_map_hex8(const double x[3], const double *Xe_flat /* 8*3 */, double 
 /*     goes to the box corner that comes closest to meeting it;         */
 /*   - backtracking on the L1 merit f + mu |c|.                         */
 /* ------------------------------------------------------------------ */
-#define ISO_MAXIT 200
+#define ISO_MAXIT 100
+#define ISO_MAX_NONCONVEX 48 /* iterations on a non-convex model per run: converging runs were seen to need <= 30 (<= 47 iterations in
+                                all); runs beyond that go round in not-quite-periodic cycles on nearly degenerate elements */
 /* Step tolerance.  The iteration ends AFTER applying a step below it, and only a step of the CONVEX mode (exact
  * Lagrangian Hessian positive definite on the face the QP ends on) may end it: those steps shrink quadratically, so
  * the final iterate is within ~tol^2 of the minimiser.  (Round 2 also ended on small Gauss-Newton steps, which
@@ -597,8 +599,23 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
     for (int k = 0; k < 8; ++k) rtol = fmax(rtol, fabs(re[k]));
     rtol *= 1e-14;
     double fbest = INFINITY, xbest[3] = {0.0, 0.0, 0.0};
+    double sx[3] = {0.0, 0.0, 0.0}, smu = -1.0, sDelta = -1.0; /* cycle detection: state at iteration 16, 32, 64, 128 */
+    int spat = -1;
     for (int it = 0; it < ISO_MAXIT; ++it) {
         double r[3], J[3][3], a[3], g[3], G[3][3], M2[3][3]; /* M2[i][q]: mixed derivatives of p_i */
+        /* The iteration is a deterministic map of (xi, mu, Delta, pattern): a state that comes back will come back for
+         * ever (nearly degenerate elements - an iso-surface within 1e-4 of an element face - send feasibility steps,
+         * restorations and QP steps round in cycles of period 3-9).  Brent's scheme: remember the state at iterations
+         * 16, 32, 64, 128 and stop as failed when it recurs, instead of running to the cap (the slowest lane sets the
+         * run time of the device's straggler launch: 200 iterations of one pair were 3 ms). */
+        if (it > 16 && xi[0] == sx[0] && xi[1] == sx[1] && xi[2] == sx[2] && mu == smu && Delta == sDelta && pat == spat) {
+            st.it = it; g_iso_stats = st;
+            if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
+            return ISO_MAXIT + 1;
+        }
+        if (it == 16 || it == 32 || it == 64 || it == 128) {
+            sx[0] = xi[0]; sx[1] = xi[1]; sx[2] = xi[2]; smu = mu; sDelta = Delta; spat = pat;
+        }
         for (int i = 0; i < 3; ++i) {
             tri_eval t = tri_eval_full(&Xe[8][i], 3, xi);
             r[i] = x[i] - t.v;
@@ -797,6 +814,11 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
         }
         st.corner += corner;
         st.nonconvex += !convex;
+        if (st.nonconvex > ISO_MAX_NONCONVEX) {
+            st.it = it + 1; g_iso_stats = st;
+            if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
+            return ISO_MAXIT + 1;
+        }
         const double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
         const double ad = dot3(a[0], a[1], a[2], d[0], d[1], d[2]);
         const double pred_c = fabs(c) - fabs(c + ad);

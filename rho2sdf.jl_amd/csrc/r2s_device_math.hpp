@@ -524,7 +524,8 @@ R2S_DEV void iso_eval_fc(const ER& E, const double x[3], double rt, const double
 }
 
 #define R2S_QP_WALK 8       // active-set steps before the exhaustive search
-#define R2S_ISO_MAXIT 200   // = the oracle's ISO_MAXIT
+#define R2S_ISO_MAXIT 100   // = the oracle's ISO_MAXIT
+#define R2S_ISO_MAX_NONCONVEX 48   // = the oracle's ISO_MAX_NONCONVEX
 #define R2S_ISO_TOL 1e-6    // = the oracle's ISO_TOL (see the note there)
 #define R2S_ISO_MAX_RESTORE 3
 
@@ -695,8 +696,17 @@ R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], do
     int pat = pat0, nrest = 0;
     const double rtol = fmax(fabs(rt), rmax_abs) * 1e-14;
     double fbest = INFINITY, xbest[3] = {0.0, 0.0, 0.0};
+    double sx[3] = {0.0, 0.0, 0.0}, smu = -1.0, sDelta = -1.0;   // cycle detection (see the oracle): the state at 16, 32, 64, 128
+    int spat = -1, n_nonconvex = 0;   // (a hand-over has seen no non-convex model: the fast path gives up at the first)
     for (int it = it0; it < R2S_ISO_MAXIT; ++it) {
         double r[3], J[3][3], a[3], g[3], G[3][3], M2[3][3];
+        if (it > 16 && xi[0] == sx[0] && xi[1] == sx[1] && xi[2] == sx[2] && mu == smu && Delta == sDelta && pat == spat) {
+            if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
+            return R2S_ISO_MAXIT + 1;
+        }
+        if (it == 16 || it == 32 || it == 64 || it == 128) {   // (a hand-over starts at it0 <= R2S_ISO_FAST_IT = 16: no snapshot is missed)
+            sx[0] = xi[0]; sx[1] = xi[1]; sx[2] = xi[2]; smu = mu; sDelta = Delta; spat = pat;
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const TriEval t = tri_eval_full(R2S_CX(E, i), xi);
@@ -857,6 +867,10 @@ R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], do
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) d[i] = fmin(fmax(d[i], lo[i]), hi[i]);
+        }
+        if (!convex && ++n_nonconvex > R2S_ISO_MAX_NONCONVEX) {
+            if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
+            return R2S_ISO_MAXIT + 1;
         }
         const double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
         const double ad = dot3(a[0], a[1], a[2], d[0], d[1], d[2]);

@@ -2361,8 +2361,13 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
         // one 64-pair batch per wavefront as long as the list holds fewer than a million pairs (a wavefront takes as
         // long as its slowest lane and executes the union of its lanes' branches); the wavefronts beyond the count
         // leave at once
-        iso_straggler_kernel<2><<<std::min<uint32_t>((cap + 7u) / 8u, waves_of), 64, 0, st>>>(
-            list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, strag_target, ppw_env);
+        static const int swps_env = getenv("R2S_STRAG_WPS") ? atoi(getenv("R2S_STRAG_WPS")) : 0;   // tuning knob
+        if (swps_env == 3)
+            iso_straggler_kernel<3><<<std::min<uint32_t>((cap + 7u) / 8u, waves_of), 64, 0, st>>>(
+                list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, strag_target * 3u / 2u, ppw_env);
+        else
+            iso_straggler_kernel<2><<<std::min<uint32_t>((cap + 7u) / 8u, waves_of), 64, 0, st>>>(
+                list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, strag_target, ppw_env);
     }
     iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(items, n_items, chunk_off, n_chunks, perm, erec, g, s, rho_t, res, res_xp,
                                                              counters + 13, abort_flag);

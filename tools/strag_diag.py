@@ -7,8 +7,14 @@ import __graft_entry__ as graft
 pkg = graft.load_built()
 import numpy as np, torch
 from rho2sdf_jl_amd import synthetic
-X, IEN, rn = synthetic.hex_mesh(46)
-g = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(512), 3)
+if len(sys.argv) > 1 and sys.argv[1] == "chapadlo256":      # BASELINE config 4 on the reference's 87 x 166 x 257 grid
+    d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "chapadlo.npz"))
+    X, IEN = d["X"], d["IEN"].astype(np.int64)
+    rn = pkg.DenseInNodes(pkg.Mesh(X, IEN), d["rho"], device=0)
+    g = pkg.Grid(X.min(0), X.max(0), 249, 3)
+else:
+    X, IEN, rn = synthetic.hex_mesh(46)
+    g = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(512), 3)
 dev = torch.device("cuda:0")
 dX, dI, dR = (torch.from_numpy(t).to(dev) for t in (X, IEN, rn))
 out = torch.empty(g.ngp, dtype=torch.float64, device=dev)
@@ -26,5 +32,6 @@ print("active wavefronts", len(act), "pairs' iterations in all", act[:, 2].sum()
 cyc = act[:, 0] / 100.0   # wall_clock64 ticks at 100 MHz -> microseconds
 print("wavefront duration us: mean %.1f  median %.1f  p90 %.1f  p99 %.1f  max %.1f" % (cyc.mean(), np.median(cyc), np.percentile(cyc, 90), np.percentile(cyc, 99), cyc.max()))
 print("longest lane (iterations) per wavefront: mean %.1f max %d;  us per iteration of the longest lane: median %.1f" % (act[:, 1].mean(), act[:, 1].max(), np.median(cyc / np.maximum(act[:, 1], 1))))
+print("histogram of the longest lane per wavefront (iterations):", np.bincount(np.minimum(act[:, 1], 60) // 5).tolist())
 order = np.argsort(-cyc)[:8]
 print("slowest wavefronts (us, longest lane, sum):", [(round(float(cyc[i]), 1), int(act[i, 1]), int(act[i, 2])) for i in order])
