@@ -116,7 +116,13 @@ int r2s_eval_distances(const double *X, int64_t nnp, const int64_t *IEN, int64_t
                        const r2s_params *params, double *dist_out, double *xp_out, r2s_stats *stats);
 
 /* Sign_Detection(mesh, grid, points, rho_n, rho_t) -> signs in {-1,+1}
- *                                         src/SignedDistances/SignDetection.jl:275-283 */
+ *                                         src/SignedDistances/SignDetection.jl:275-283
+ * HEX8 precondition of one shortcut: a lattice point inside the convex inner region of an element whose nodal densities
+ * all lie on one side of rho_t gets that element's answer without a Newton solve, which equals the reference's ordered
+ * walk (SignDetection.jl:41-68) on a CONFORMING mesh (no other element holds the point with a smaller max|xi|).  On
+ * overlapping / non-conforming meshes - where the reference's own result depends on which of the overlapping elements
+ * comes first - set the environment variable R2S_SIGN_NO_INNER=1: every candidate pair then runs its inverse map
+ * (tests/test_parity_gpu.py::test_overlapping_elements_without_the_inner_region_shortcut). */
 int r2s_sign_detection(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel,
                        const double *rho_n, double rho_t, const r2s_grid *grid,
                        const r2s_params *params, double *signs_out, r2s_stats *stats);
@@ -142,7 +148,8 @@ typedef struct {
     int32_t rbf_smooth;                  /* 1 = rbf_grid :same, 2 = :fine */
     int32_t remove_artifacts;            /* 1 */
     int32_t device;                      /* -1 = current */
-    int32_t n_gpus;                      /* > 1: raw SDF on devices 0..n_gpus-1 (tile layers gathered on device 0 over xGMI) */
+    int32_t n_gpus;                      /* > 1: devices 0..n_gpus-1: raw SDF on interleaved tile layers, then components and RBF smoothing
+                                            slab-distributed (planes move between devices as peer copies over xGMI; nothing is gathered on one device) */
     int32_t skip_rbf;                    /* 1: stop after artifact removal (fine_sdf_out may be NULL) */
     int32_t true_min;                    /* r2s_params.true_min for the raw SDF */
     int32_t reserved[4];
@@ -190,8 +197,10 @@ void r2s_plan_destroy(r2s_plan *plan);
 /* One pass of the hot path over the Z-slab of grid planes [k_begin, k_end):
  * all inputs/outputs are device pointers; outputs hold (k_end-k_begin)*(N1+1)*(N2+1)
  * voxels in the reference's x-fastest order.  Work is enqueued on `stream`
- * (hipStream_t as void*, NULL = default stream) and the call returns after the
- * stream has been synchronised (sizes of the bin lists are read back). */
+ * (hipStream_t as void*, NULL = default stream).  The FIRST call for a set of shapes waits for the stream twice in the
+ * middle (item and list sizes are read back); later calls with the same shapes enqueue everything in one go from the
+ * sizes of the previous call (a device-side check falls back to the waiting way when they do not hold) and wait once,
+ * at the end, when `stats` is requested or an earlier speculated size has to be confirmed. */
 int r2s_plan_run_dev(r2s_plan *plan, const double *dX, int64_t nnp, const int64_t *dIEN, int64_t nel,
                      const double *d_rho_n, double rho_t, const r2s_grid *grid,
                      const r2s_params *params, int64_t k_begin, int64_t k_end, int32_t mode,
@@ -329,8 +338,9 @@ void r2s_free_vtu_mesh(r2s_vtu_mesh *mesh);
  * r2s_import_vtu (release with r2s_free_vtu_mesh).  v7.3 (HDF5) files are refused. */
 int r2s_import_mat(const char *filename, r2s_vtu_mesh *out);
 
-/* frees the process-wide work buffers the library keeps between calls (the materialised RBF matrix of the CG:
- * up to a quarter of the device memory, see r2s_post.hip) */
+/* frees what the library keeps between calls: the per-device host sessions of the host-pointer entry points (plan,
+ * device copies of the mesh, output volumes, pinned staging buffers) and the shared work buffers of the smoothing stage.
+ * Must not run concurrently with any other call of the library (it destroys the sessions other calls lock). */
 void r2s_release_cache(void);
 
 #ifdef __cplusplus

@@ -12,8 +12,10 @@
 //
 // n_gpus > 1 (r2s_params.n_gpus): single process, one host thread per device, interleaved 4-plane tile layers
 // (r2s_params.zstride/zphase); every device sends its layers straight to their place in the caller's array over
-// its own PCIe link, so the host result needs no device-side stitching.  r2s_rho2sdf gathers the layers on device
-// 0 by peer copies over xGMI (hipMemcpyPeerAsync) and post-processes there.
+// its own PCIe link, so the host result needs no device-side stitching.  r2s_rho2sdf moves the layers to contiguous
+// Z-slabs (plane-wise peer copies over xGMI, hipMemcpyPeerAsync) and post-processes SLAB-DISTRIBUTED (components with an
+// interface merge, RBF smoothing with halo exchange - r2s_post.hip); nothing is gathered on one device.
+// r2s_release_cache destroys the sessions: it must not run concurrently with any other call (see the header).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -370,7 +370,7 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
 
 // bounding half-spaces of the inflated elements (ElemRec::pn / po, used by sign_project_kernel only): one thread
 // per (element, face), on the second stream - off the critical path of the mesh preparation
-__global__ void hex_planes_kernel(ElemRec* __restrict__ erec, int64_t nel)
+__global__ void hex_planes_kernel(ElemRec* __restrict__ erec, int64_t nel, int no_inner)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t el = gid / 6;
@@ -380,7 +380,9 @@ __global__ void hex_planes_kernel(ElemRec* __restrict__ erec, int64_t nel)
     hex8_plane(erec[el], f >> 1, f & 1, n, po, pin);
     erec[el].pn[f][0] = n[0]; erec[el].pn[f][1] = n[1]; erec[el].pn[f][2] = n[2];
     erec[el].po[f] = po;
-    erec[el].pi[f] = pin;
+    // no_inner (R2S_SIGN_NO_INNER=1): no inner region, every candidate pair of the sign pass runs its Newton solve - the
+    // shortcut assumes a CONFORMING mesh (include/rho2sdf_hip.h, r2s_sign_detection)
+    erec[el].pi[f] = no_inner ? -INFINITY : pin;
 }
 
 // boundary faces (sdfOnDensityField.jl:511-519): a face is on the boundary when exactly one element (this one)
@@ -2495,7 +2497,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         // 43 us, after the sign counts they run beside its start: 4.27 instead of 4.13 ms)
         HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[5], 0));   // element records (first stream) before the sign counts
         HIP_TRY(hipStreamWaitEvent(P->st3, P->ev2[5], 0));
-        hex_planes_kernel<<<(unsigned)((nel * 6 + 255) / 256), 256, 0, P->st3>>>(P->erec.as<ElemRec>(), nel);
+        static const int no_inner_env = getenv("R2S_SIGN_NO_INNER") ? atoi(getenv("R2S_SIGN_NO_INNER")) : 0;
+        hex_planes_kernel<<<(unsigned)((nel * 6 + 255) / 256), 256, 0, P->st3>>>(P->erec.as<ElemRec>(), nel, no_inner_env);
         HIP_TRY(hipEventRecord(P->ev2[5], P->st3));   // from here on: "planes done"
     }
     // HEX8 sign pass: which tiles are hot, how long their candidate lists get and the boxes of the inverse maps depend on

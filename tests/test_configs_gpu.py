@@ -195,8 +195,8 @@ def test_host_entry_points_reuse_their_session(pkg, oracle, pinned):
 @pytest.mark.parametrize("G", [2, 3, 8])
 def test_single_process_fan_out(pkg, oracle, G, monkeypatch):
     """r2s_params.n_gpus / r2s_options.n_gpus: ONE call fans out over G devices (one host thread each, interleaved
-    tile layers, every device's layers sent straight to their place in the caller's array; r2s_rho2sdf gathers them
-    on device 0 by peer copies).  A one-GPU box has one device, so the test hook R2S_MULTI_OVERSUBSCRIBE maps the G
+    tile layers, every device's layers sent straight to their place in the caller's array; r2s_rho2sdf moves them to
+    contiguous slabs by peer copies and post-processes slab-distributed).  A one-GPU box has one device, so the test hook R2S_MULTI_OVERSUBSCRIBE maps the G
     logical devices onto it (separate sessions, plans and buffers): the partition, the threads and the copies are the
     ones an 8-GPU node runs.  Results must equal the single-device call bit for bit."""
     from rho2sdf_jl_amd import synthetic

@@ -145,6 +145,35 @@ def test_straggler_list_overflow(pkg, oracle):
     print(r.stdout.strip())
 
 
+def test_overlapping_elements_without_the_inner_region_shortcut(pkg, oracle):
+    """two copies of a 3^3 block shifted by 0.37 of an element against each other, the second with other densities: a
+    NON-conforming mesh of overlapping elements.  The sign pass's inner-region shortcut assumes a conforming mesh
+    (include/rho2sdf_hip.h); with R2S_SIGN_NO_INNER=1 every candidate pair runs its inverse map and the ordered walk of
+    SignDetection.jl:41-68 must come out exactly as the oracle's (run in a child: the switch is read once per process)"""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import __graft_entry__ as graft
+        from conftest import block_mesh
+        pkg = graft.load_built(); O = graft.load_oracle()
+        X1, I1 = block_mesh([3, 3, 3])
+        X2 = X1 + 0.37 * (2.0 / 3.0) * np.array([1.0, 0.6, -0.8])
+        X = np.vstack([X1, X2]); IEN = np.vstack([I1, I1 + len(X1)])
+        rng = np.random.default_rng(5)
+        rn = np.concatenate([np.clip(1.2 - np.linalg.norm(X1, axis=1), 0, 1), rng.uniform(0.0, 1.0, len(X2))])
+        pg = pkg.Grid(X.min(0), X.max(0), 30, 3); og = O.grid_make(X.min(0), X.max(0), 30, 3)
+        s = pkg.Sign_Detection(pkg.Mesh(X, IEN), pg, rn, 0.5)
+        so = O.sign_detection(X, IEN, rn, 0.5, og)
+        assert np.array_equal(s, so), int((s != so).sum())
+        print("overlapping mesh: signs equal,", int((so > 0).sum()), "of", so.size, "positive")
+    ''') % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, R2S_SIGN_NO_INNER="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout.strip())
+
+
 def test_synthetic_jittered_hex(pkg, oracle):
     """north-star mesh family at a size the oracle finishes in seconds: 12^3 HEX8, 64^3 grid"""
     from rho2sdf_jl_amd import synthetic
