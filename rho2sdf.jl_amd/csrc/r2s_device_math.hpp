@@ -396,7 +396,7 @@ R2S_DEV int qp_pattern(int pat, const Sym3& H, const double g[3], const double a
                        const double lo[3], const double hi[3], QpOut& o)
 {
     o.next = -1;
-    const int s[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+    const int s[3] = {pat & 3, (pat >> 2) & 3, pat >> 4};   // two bits per variable: 0 free, 1 at the lower, 2 at the upper bound
     double dB[3], aa[3], b[3], M[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -448,7 +448,7 @@ R2S_DEV int qp_pattern(int pat, const Sym3& H, const double g[3], const double a
     double lam = vac ? 0.0 : (dot3(aa[0], aa[1], aa[2], v[0], v[1], v[2]) - ep) / den;
     bool ok = true;
     double worst = 0.0;
-    const int pw[3] = {1, 3, 9};
+    const int pw[3] = {1, 4, 16};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         if (s[i]) {
@@ -467,10 +467,10 @@ R2S_DEV int qp_pattern(int pat, const Sym3& H, const double g[3], const double a
         // two variables fixed already: fixing the violated third one leaves no freedom for the equality,
         // so the walk restarts from the violated bound alone
         const int np = o.next;
-        if (np >= 0 && (np % 3) && ((np / 3) % 3) && (np / 9)) {
+        if (np >= 0 && (np & 3) && ((np >> 2) & 3) && (np >> 4)) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                if (!s[i]) o.next = ((np / pw[i]) % 3) * pw[i];
+                if (!s[i]) o.next = np & (3 << (2 * i));
         }
         return 2;
     }
@@ -498,7 +498,9 @@ R2S_DEV int qp_pattern(int pat, const Sym3& H, const double g[3], const double a
     return 1;
 }
 
-static __constant__ int c_pat_order[19] = {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8, 10, 11, 19, 20, 12, 15, 21, 24};
+// the oracle's search order {0, 1, 2, 3, 6, 9, 18, 4, 5, 7, 8, 10, 11, 19, 20, 12, 15, 21, 24} (base-3 digits there) in the
+// device's pattern code: two bits per variable (decoding a digit is an AND instead of a division by 3 / 9)
+static __constant__ int c_pat_order[19] = {0, 1, 2, 4, 8, 16, 32, 5, 6, 9, 10, 17, 18, 33, 34, 20, 24, 36, 40};
 
 R2S_DEV bool spd3(double h00, double h01, double h02, double h11, double h12, double h22)
 {
@@ -627,7 +629,7 @@ R2S_DEV void iso_qp_data(const double G[3][3], const double S[3], const double a
 // positive definite on the face of the box named by the pattern
 R2S_DEV bool iso_face_spd(const Sym3& H, int pat)
 {
-    const bool f0 = (pat % 3) != 0, f1 = ((pat / 3) % 3) != 0, f2 = (pat / 9) != 0;
+    const bool f0 = (pat & 3) != 0, f1 = ((pat >> 2) & 3) != 0, f2 = (pat >> 4) != 0;
     return spd3(f0 ? 1.0 : H.a00, (f0 || f1) ? 0.0 : H.a01, (f0 || f2) ? 0.0 : H.a02,
                 f1 ? 1.0 : H.a11, (f1 || f2) ? 0.0 : H.a12, f2 ? 1.0 : H.a22);
 }
@@ -635,11 +637,11 @@ R2S_DEV bool iso_face_spd(const Sym3& H, int pat)
 // warm-start pattern: a variable the last QP fixed stays fixed only if it sits on the element's own bound now
 R2S_DEV int iso_clean_pattern(int pat, const double xi[3])
 {
-    const int s0 = pat % 3, s1 = (pat / 3) % 3, s2 = pat / 9;
+    const int s0 = pat & 3, s1 = (pat >> 2) & 3, s2 = pat >> 4;
     int p = 0;
     if ((s0 == 1 && xi[0] == -1.0) || (s0 == 2 && xi[0] == 1.0)) p += s0;
-    if ((s1 == 1 && xi[1] == -1.0) || (s1 == 2 && xi[1] == 1.0)) p += 3 * s1;
-    if ((s2 == 1 && xi[2] == -1.0) || (s2 == 2 && xi[2] == 1.0)) p += 9 * s2;
+    if ((s1 == 1 && xi[1] == -1.0) || (s1 == 2 && xi[1] == 1.0)) p += 4 * s1;
+    if ((s2 == 1 && xi[2] == -1.0) || (s2 == 2 && xi[2] == 1.0)) p += 16 * s2;
     return p;
 }
 
@@ -733,7 +735,7 @@ R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], do
         pat = iso_clean_pattern(pat, xi);
         {
             double num = 0.0, den = 0.0;
-            const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+            const int sp[3] = {pat & 3, (pat >> 2) & 3, pat >> 4};
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 if (!sp[i]) { num = fma(a[i], g[i], num); den = fma(a[i], a[i], den); }
@@ -836,11 +838,11 @@ R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], do
                     if (convex || ip == 0) {
                         rc = qp_pattern(p, H, gp, a, e, lo, hi, o);
                     } else if (ip < 7) {   // one variable fixed
-                        const int s0 = p % 3, s1 = (p / 3) % 3, s2 = p / 9;
+                        const int s0 = p & 3, s1 = (p >> 2) & 3, s2 = p >> 4;
                         const int i = s0 ? 0 : (s1 ? 1 : 2);
                         rc = qp_fixed1(i, s0 + s1 + s2, H, gp, a, e, lo, hi, o);
                     } else {               // two fixed
-                        const int s0 = p % 3, s1 = (p / 3) % 3, s2 = p / 9;
+                        const int s0 = p & 3, s1 = (p >> 2) & 3, s2 = p >> 4;
                         const int k = !s0 ? 0 : (!s1 ? 1 : 2);
                         rc = qp_fixed2(k, (k == 0) ? s1 : s0, (k == 2) ? s1 : s2, H, gp, a, e, lo, hi, o);
                     }
@@ -893,7 +895,7 @@ R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], do
                 iso_eval_fc(E, x, rt, xt, ft, ct);
                 const double phi0 = fma(mu, fabs(c), f);
                 if (!(phi0 - fma(mu, fabs(ct), ft) >= 1e-4 * pred)) {
-                    const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+                    const int sp[3] = {pat & 3, (pat >> 2) & 3, pat >> 4};
                     double den = 0.0, d2[3] = {d[0], d[1], d[2]};
                     bool ok = false;
 #pragma unroll
@@ -938,7 +940,7 @@ R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], do
                     iso_eval_fc(E, x, rt, xt, ft, ct);
                     if (fma(mu, fabs(ct), ft) <= fma(1e-4 * alpha, D, phi0)) break;
                     if (ls == 0 && !corner) {
-                        const int sp[3] = {pat % 3, (pat / 3) % 3, pat / 9};
+                        const int sp[3] = {pat & 3, (pat >> 2) & 3, pat >> 4};
                         double den = 0.0;
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
@@ -1062,7 +1064,7 @@ R2S_DEV void iso_lane_eval(const ER& E, double rt, double rtol, IsoLane& s)
     double lam;
     {
         double num = 0.0, den = 0.0;
-        const int sp[3] = {s.pat % 3, (s.pat / 3) % 3, s.pat / 9};
+        const int sp[3] = {s.pat & 3, (s.pat >> 2) & 3, s.pat >> 4};
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (!sp[i]) { num = fma(s.a[i], s.g[i], num); den = fma(s.a[i], s.a[i], den); }
