@@ -634,8 +634,7 @@ __global__ void item_build_kernel(const typename ET::Rec* __restrict__ erec, con
 // influence on the results (every pair writes its own slot).
 __global__ void __launch_bounds__(1024) work_order_kernel(const uint8_t* __restrict__ hard, const uint32_t* __restrict__ nchunks,
                                                           uint32_t nitems, uint32_t* __restrict__ perm,
-                                                          uint32_t* __restrict__ wchunks, uint32_t split_rank,
-                                                          uint32_t* __restrict__ split_pos)
+                                                          uint32_t* __restrict__ wchunks)
 {
     // counting sort over the 16 hardness ranks (rank 0 first); items that are not iso items carry rank 0 and no chunks
     __shared__ uint32_t cnt[16], base[16], cur[16];
@@ -646,8 +645,6 @@ __global__ void __launch_bounds__(1024) work_order_kernel(const uint8_t* __restr
     if (threadIdx.x == 0) {
         uint32_t b = 0;
         for (int q = 0; q < 16; ++q) { base[q] = b; b += cnt[q]; }
-        // work-order position of the first item of rank >= split_rank: where part B of the projection starts
-        *split_pos = (split_rank < 16u) ? base[split_rank] : nitems;
     }
     __syncthreads();
     for (uint32_t it = threadIdx.x; it < nitems; it += blockDim.x) {
@@ -1042,16 +1039,9 @@ __global__ void __launch_bounds__(64, WPS) iso_project_hex_pl_kernel(
     uint32_t group, const ElemRec* __restrict__ erec, GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
     double* __restrict__ res_xp, uint32_t* __restrict__ counter, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ abort_flag,
     IsoStraggler* __restrict__ strag, uint32_t strag_cap, uint32_t* __restrict__ strag_cnt /* entries */,
-    uint32_t* __restrict__ strag_ovf, const uint32_t* __restrict__ split_pos, int part)
+    uint32_t* __restrict__ strag_ovf)
 {
     if (*abort_flag) return;   // speculated sizes of this call did not hold (run_impl)
-    // part 0: the chunks in front of the split (items of the hard ranks), part 1: the rest, part 2: everything.  The
-    // pairs part 0 hands over are solved (iso_straggler_kernel, third stream) while part 1 runs.
-    uint32_t c_lo = 0;
-    if (part != 2) {
-        const uint32_t cs = chunk_off[*split_pos];
-        if (part == 0) nchunks = cs; else c_lo = cs;
-    }
     __shared__ IsoElemLds slots[R2S_ISO_SLOTS];
     const uint32_t lane = threadIdx.x;
 #ifdef R2S_ISO_WAVE_END
@@ -1161,7 +1151,7 @@ __global__ void __launch_bounds__(64, WPS) iso_project_hex_pl_kernel(
                     if (c >= c_end) {
                         uint32_t cc = 0;
                         if (lane == 0) cc = atomicAdd(counter, group);
-                        c = c_lo + __builtin_amdgcn_readfirstlane(cc);
+                        c = __builtin_amdgcn_readfirstlane(cc);
                         if (c >= nchunks) {
 #ifdef R2S_ISO_WAVE_END
                             if (!exhausted && lane == 0 && blockIdx.x < 4094) {
@@ -1276,10 +1266,7 @@ extern "C" int r2s_debug_strag_diag(unsigned long long* out)
 #endif
 // The pairs the fast path handed over, compacted: one lane per pair runs the complete solver (iso_project_full) from
 // xi = 0 - the oracle's iteration operation for operation - and writes the pair's result slot.
-// WPS = 3: 168 registers (the rest spills) - the instantiation that runs BESIDE part 1 of the projection kernel, whose two
-// wavefronts per SIMD leave room for exactly that; WPS = 2 (no spills) when nothing runs beside it.
-template <int WPS>
-__global__ void __launch_bounds__(64, WPS) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
+__global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
                                                            const uint32_t* __restrict__ strag_cnt, const ElemRec* __restrict__ erec,
                                                            double rho_t, double* __restrict__ res, double* __restrict__ res_xp,
                                                            const uint32_t* __restrict__ abort_flag, uint32_t target_waves, int ppw_arg)
@@ -2092,7 +2079,7 @@ struct r2s_plan {
     int n_cu = 256;
     DevBuf deg, ine_ptr, ine, cursor, erec, cls, fmask, nitems, item_off, items;
     DevBuf band_cnt, band_off, band_raw, band_ent, sign_cnt, sign_off, sign_raw, sign_ent;
-    DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], scan_tmp2[3], nchunks, chunk_off, iso_res, iso_res_xp, strag, split_pos;
+    DevBuf active, active_sign, active_any, active_sonly, active_lean, active_tri, tri, hot, counters, scan_tmp[3], scan_tmp2[3], nchunks, chunk_off, iso_res, iso_res_xp, strag;
     DevBuf perm, wchunks, hardflag;   // work order of the persistent projection kernel (HEX8)
     DevBuf sbox, s_nchunks, s_chunk_off, sres;   // item-major inverse maps of the sign pass (HEX8)
     DevBuf nstore, store_off, s_nstore, s_store_off;   // storage (tile) chunk counts / offsets
@@ -2114,7 +2101,6 @@ struct r2s_plan {
     hipStream_t st2 = nullptr;
     hipStream_t st3 = nullptr;   // bounding half-spaces (hex_planes_kernel), beside the chains of the other two during preparation
     hipEvent_t ev2[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev3[2] = {nullptr, nullptr};   // part A of the HEX8 projection done / its stragglers done (third stream)
 };
 
 // exclusive scans of one or two (in1 != nullptr) arrays of n entries each
@@ -2253,7 +2239,6 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     HIP_TRY(hipHostGetDevicePointer((void**)&P->d_pinned, P->h_pinned, 0));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&P->ev3[i], hipEventDisableTiming));
     {
         // high priority: the short stages of the second stream (sentinel sweep, inverse maps of the sign pass,
         // sign-only gather) get wave slots ahead of the long persistent projection kernel.  Measured on the
@@ -2275,7 +2260,7 @@ void r2s_plan_destroy(r2s_plan* P)
     DevBuf* all[] = {&P->deg, &P->ine_ptr, &P->ine, &P->cursor, &P->erec, &P->cls, &P->fmask, &P->nitems,
                      &P->item_off, &P->items, &P->band_cnt, &P->band_off, &P->band_raw, &P->band_ent,
                      &P->sign_cnt, &P->sign_off, &P->sign_raw, &P->sign_ent, &P->active, &P->active_sign, &P->active_any, &P->active_sonly, &P->active_lean, &P->active_tri, &P->tri,
-                     &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp, &P->strag, &P->split_pos,
+                     &P->hot, &P->counters, &P->nchunks, &P->chunk_off, &P->iso_res, &P->iso_res_xp, &P->strag,
                      &P->perm, &P->wchunks, &P->hardflag, &P->sbox, &P->s_nchunks, &P->s_chunk_off, &P->sres, &P->nstore, &P->store_off, &P->s_nstore, &P->s_store_off,
                      &P->scan_tmp[0], &P->scan_tmp[1], &P->scan_tmp[2], &P->scan_tmp2[0], &P->scan_tmp2[1], &P->scan_tmp2[2]};
     for (DevBuf* b : all) b->release();
@@ -2284,8 +2269,6 @@ void r2s_plan_destroy(r2s_plan* P)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
     for (int i = 0; i < 8; ++i)
         if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
-    for (int i = 0; i < 2; ++i)
-        if (P->ev3[i]) (void)hipEventDestroy(P->ev3[i]);
     if (P->st2) (void)hipStreamDestroy(P->st2);
     if (P->st3) (void)hipStreamDestroy(P->st3);
     delete P;
@@ -2304,17 +2287,14 @@ static uint32_t iso_straggler_cap(uint32_t n_store)
     return (uint32_t)std::max<uint64_t>(slots / 16, std::min<uint64_t>(slots, 1ull << 20));
 }
 
-// The HEX8 projection on stream `st`: part A of the persistent fast-path kernel (items of the hard
-// ranks, handed out first), part B (the rest); the pairs A hands over are solved by the complete solver on the third
-// stream WHILE B runs (the 168-register instantiation fits beside B's two wavefronts per SIMD), B's own few behind it;
-// last the sweep that only does something when a list overflowed.  Nothing here waits for a count on the host.
-// counters: [8] / [9] chunk counters of A / B, [12] / [14] list entries of A / B, [13] overflow flag.
+// The HEX8 projection on stream `st`: the persistent fast-path kernel, behind it the complete
+// solver on the pairs it handed over, last the sweep that only does something when the list overflowed.  Nothing here
+// waits for a count on the host.  counters: [8] chunk counter, [12] list entries, [13] overflow flag.
 static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32_t n_chunks, uint32_t n_store, uint32_t wps,
                            const GridDev& g, const SlabInfo& s, double rho_t, double* res_xp, uint32_t* counters,
                            const uint32_t* abort_flag)
 {
     static const int free_env = getenv("R2S_ISO_FREE") ? atoi(getenv("R2S_ISO_FREE")) : 0;   // tuning knob: fewer persistent wavefronts
-    static const bool split_env = getenv("R2S_ISO_SPLIT") && atoi(getenv("R2S_ISO_SPLIT"));   // experiment (measured: slower)
     const uint32_t resident = (uint32_t)P->n_cu * 4u * wps - (uint32_t)std::min(std::max(free_env, 0), (int)P->n_cu * 4);
     // chunks per fetch: 4 when every wavefront gets dozens of them (1-8: +-2 %), fewer for a small share of the grid
     // (one rank of 4 / 8), where coarse groups leave wavefronts unevenly loaded (-15 % at 13 chunks/wave)
@@ -2331,46 +2311,17 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
     double* res = P->iso_res.as<double>();
     // two instantiations: 168 registers (3 wavefronts per SIMD, 48 B of scratch per lane) when the kernel has the GPU to
     // itself, 2 per SIMD without scratch when it starts beside the binning (early launch, see run_impl)
-#define ISO_PL_LAUNCH(...)                                                                      \
-    do {                                                                                        \
-        if (wps >= 3) iso_project_hex_pl_kernel<3><<<grid, 64, 0, st>>>(__VA_ARGS__);           \
-        else iso_project_hex_pl_kernel<2><<<grid, 64, 0, st>>>(__VA_ARGS__);                    \
-    } while (0)
+    if (wps >= 3)
+        iso_project_hex_pl_kernel<3><<<grid, 64, 0, st>>>(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
+                                                          counters + 8, perm, abort_flag, list, cap, counters + 12, counters + 13);
+    else
+        iso_project_hex_pl_kernel<2><<<grid, 64, 0, st>>>(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
+                                                          counters + 8, perm, abort_flag, list, cap, counters + 12, counters + 13);
     static const int ppw_env = getenv("R2S_STRAG_PPW") ? atoi(getenv("R2S_STRAG_PPW")) : 0;   // tuning knob: pairs per straggler wavefront
-    const uint32_t strag_target = (uint32_t)P->n_cu * 8u;   // two wavefronts per SIMD
-    const bool split = split_env && n_chunks >= 8u * resident;   // (a small share of the grid: one part, nothing to hide behind)
-    const uint32_t waves_of = 65536u;   // (>= list length / 8 for lists of up to half a million pairs; grid-stride beyond)
-    if (split) {
-        const uint32_t cap_a = cap - cap / 4, cap_b = cap / 4;
-        ISO_PL_LAUNCH(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
-                                                       counters + 8, perm, abort_flag, list, cap_a, counters + 12, counters + 13,
-                                                       P->split_pos.as<uint32_t>(), 0);
-        HIP_TRY(hipEventRecord(P->ev3[0], st));
-        ISO_PL_LAUNCH(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
-                                                       counters + 9, perm, abort_flag, list + cap_a, cap_b, counters + 14, counters + 13,
-                                                       P->split_pos.as<uint32_t>(), 1);
-        HIP_TRY(hipStreamWaitEvent(P->st3, P->ev3[0], 0));
-        iso_straggler_kernel<3><<<std::min<uint32_t>((cap_a + 7u) / 8u, waves_of), 64, 0, P->st3>>>(
-            list, cap_a, counters + 12, erec, rho_t, res, res_xp, abort_flag, strag_target, ppw_env);
-        HIP_TRY(hipEventRecord(P->ev3[1], P->st3));
-        iso_straggler_kernel<2><<<std::min<uint32_t>((cap_b + 7u) / 8u, waves_of), 64, 0, st>>>(
-            list + cap_a, cap_b, counters + 14, erec, rho_t, res, res_xp, abort_flag, strag_target, ppw_env);
-        HIP_TRY(hipStreamWaitEvent(st, P->ev3[1], 0));
-    } else {
-        ISO_PL_LAUNCH(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
-                                                       counters + 8, perm, abort_flag, list, cap, counters + 12, counters + 13,
-                                                       P->split_pos.as<uint32_t>(), 2);
-        // one 64-pair batch per wavefront as long as the list holds fewer than a million pairs (a wavefront takes as
-        // long as its slowest lane and executes the union of its lanes' branches); the wavefronts beyond the count
-        // leave at once
-        static const int swps_env = getenv("R2S_STRAG_WPS") ? atoi(getenv("R2S_STRAG_WPS")) : 0;   // tuning knob
-        if (swps_env == 3)
-            iso_straggler_kernel<3><<<std::min<uint32_t>((cap + 7u) / 8u, waves_of), 64, 0, st>>>(
-                list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, strag_target * 3u / 2u, ppw_env);
-        else
-            iso_straggler_kernel<2><<<std::min<uint32_t>((cap + 7u) / 8u, waves_of), 64, 0, st>>>(
-                list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, strag_target, ppw_env);
-    }
+    // 8-64 pairs per wavefront (chosen on the device from the count): enough wavefronts for the shortest list, grid-stride
+    // beyond half a million pairs; the wavefronts beyond the count leave at once
+    iso_straggler_kernel<<<std::min<uint32_t>((cap + 7u) / 8u, 65536u), 64, 0, st>>>(list, cap, counters + 12, erec, rho_t, res, res_xp,
+                                                                                    abort_flag, (uint32_t)P->n_cu * 8u, ppw_env);
     iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(items, n_items, chunk_off, n_chunks, perm, erec, g, s, rho_t, res, res_xp,
                                                              counters + 13, abort_flag);
     return 0;
@@ -2570,11 +2521,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         if constexpr (std::is_same<typename ET::Rec, ElemRec>::value) {
             ENSURE(P->perm, sizeof(uint32_t) * (size_t)n_items);
             ENSURE(P->wchunks, sizeof(uint32_t) * (size_t)(n_items + 1));
-            ENSURE(P->split_pos, 64);
-            static const int split_rank_env = getenv("R2S_ISO_SPLIT_RANK") ? atoi(getenv("R2S_ISO_SPLIT_RANK")) : 3;   // tuning knob
             work_order_kernel<<<1, 1024, 0, st>>>(P->hardflag.as<uint8_t>(), P->nchunks.as<uint32_t>(), n_items,
-                                                  P->perm.as<uint32_t>(), P->wchunks.as<uint32_t>(), (uint32_t)split_rank_env,
-                                                  P->split_pos.as<uint32_t>());
+                                                  P->perm.as<uint32_t>(), P->wchunks.as<uint32_t>());
             work_counts = P->wchunks.as<uint32_t>();   // chunk_off then runs in work order (HEX8)
         }
         int rc = scan_exclusive2(P, work_counts, P->chunk_off.as<uint32_t>(), P->nstore.as<uint32_t>(),
