@@ -537,10 +537,12 @@ R2S_DEV void iso_eval_fc(const ER& E, const double x[3], double rt, const double
 // indefinite matrices, vanishing gradient components and degenerate bounds).  The non-convex search of
 // iso_project_full evaluates all 19 patterns in every such iteration; these cost a fifth of the generic form.
 // Return value as qp_pattern; kkt / next are not produced (the search takes the feasible pattern of least value).
-R2S_DEV int qp_fixed2(int k /* free */, int si, int sj, const Sym3& H, const double g[3], const double a[3], double e,
-                      const double lo[3], const double hi[3], QpOut& o)
+template <int k /* free */>
+R2S_DEV int qp_fixed2_t(int si, int sj, const Sym3& H, const double g[3], const double a[3], double e,
+                        const double lo[3], const double hi[3], QpOut& o)
 {
-    const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;   // the fixed ones, ascending
+    constexpr int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;   // the fixed ones, ascending (compile-time indices: no
+                                                                // array of the caller is indexed dynamically = no scratch)
     const double dBi = (si == 1) ? lo[i] : hi[i], dBj = (sj == 1) ? lo[j] : hi[j];
     double ep = e;
     ep = fma(-a[i], dBi, ep);
@@ -570,10 +572,19 @@ R2S_DEV int qp_fixed2(int k /* free */, int si, int sj, const Sym3& H, const dou
     return 1;
 }
 
-R2S_DEV int qp_fixed1(int i /* fixed */, int si, const Sym3& H, const double g[3], const double a[3], double e,
+R2S_DEV int qp_fixed2(int k, int si, int sj, const Sym3& H, const double g[3], const double a[3], double e,
                       const double lo[3], const double hi[3], QpOut& o)
 {
-    const int j = (i == 0) ? 1 : 0, k = (i == 2) ? 1 : 2;   // the free ones, ascending
+    if (k == 0) return qp_fixed2_t<0>(si, sj, H, g, a, e, lo, hi, o);
+    if (k == 1) return qp_fixed2_t<1>(si, sj, H, g, a, e, lo, hi, o);
+    return qp_fixed2_t<2>(si, sj, H, g, a, e, lo, hi, o);
+}
+
+template <int i /* fixed */>
+R2S_DEV int qp_fixed1_t(int si, const Sym3& H, const double g[3], const double a[3], double e,
+                        const double lo[3], const double hi[3], QpOut& o)
+{
+    constexpr int j = (i == 0) ? 1 : 0, k = (i == 2) ? 1 : 2;   // the free ones, ascending
     const double dBi = (si == 1) ? lo[i] : hi[i];
     const double ep = fma(-a[i], dBi, e);
     const double bj = fma(-H(j, i), dBi, -g[j]), bk = fma(-H(k, i), dBi, -g[k]);
@@ -608,6 +619,14 @@ R2S_DEV int qp_fixed1(int i /* fixed */, int si, const Sym3& H, const double g[3
     o.lam = lam;
     o.q = q;
     return 1;
+}
+
+R2S_DEV int qp_fixed1(int i, int si, const Sym3& H, const double g[3], const double a[3], double e,
+                      const double lo[3], const double hi[3], QpOut& o)
+{
+    if (i == 0) return qp_fixed1_t<0>(si, H, g, a, e, lo, hi, o);
+    if (i == 1) return qp_fixed1_t<1>(si, H, g, a, e, lo, hi, o);
+    return qp_fixed1_t<2>(si, H, g, a, e, lo, hi, o);
 }
 
 // H = G + S + sg a a^T (upper triangle), g' = g - sg e a: the QP data of the oracle's iso_project_hex8
@@ -983,6 +1002,393 @@ R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], do
     }
     if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
     return R2S_ISO_MAXIT + 1;
+}
+
+// ---- the complete solver as a per-lane state machine -----------------------------------------------------
+// iso_straggler_kernel: the handed-over pairs are worked off by persistent wavefronts with lane refill, like the fast
+// path, but every rule of iso_project_full is there - as phases, so that a trip costs what its lanes' phases cost (a
+// plain iteration: one trip of ~900 instructions) instead of the union of all branches of the straight-line solver
+// (~2 800 per wavefront-iteration).  Each phase performs exactly the IEEE operations of the corresponding part of
+// iso_project_full, in the same order.
+//   EVAL  cycle test, fields, QP data (first sigma, then the second), corner / stall test   -> QP | ENUM | POST
+//   QP    ONE active-set pattern of the walk per visit                                       -> QP | EVAL (second sigma) | ENUM | POST
+//   ENUM  the whole 19-pattern search (convex: first KKT pattern; non-convex: least value)  -> POST
+//   POST  caps, step test, merit parameter; the non-convex trial with its correction        -> LS | UPD
+//   LS    ONE back-tracking trial per visit (the first with the second-order correction)    -> LS | UPD
+//   UPD   trust region, restoration, iterate update                                          -> EVAL | DONE
+enum { FS_IDLE = 0, FS_EVAL, FS_QP, FS_ENUM, FS_POST, FS_LS, FS_UPD, FS_DONE };
+
+struct IsoFullLane {
+    double x[3];
+    double xi[3], mu, Delta;
+    double fbest, xbest[3];
+    double sx[3], smu, sDelta;
+    Sym3 H;
+    double a[3], g[3], d[3];
+    double se;       // sg * e of the QP data, or the curvature d.G.d of a corner step
+    double f, c, lam_new, qstep, dmax;
+    double alpha, D, phi0;
+    int pat, it, nrest, n_nc, spat;
+    int p, step, ls, phase, stop;
+    bool corner, convex, stall, stage2, force2;
+};
+
+R2S_DEV void iso_full_start(IsoFullLane& s, const double x[3], const double xi[3], double mu, double Delta, int pat, int it)
+{
+    s.x[0] = x[0]; s.x[1] = x[1]; s.x[2] = x[2];
+    s.xi[0] = xi[0]; s.xi[1] = xi[1]; s.xi[2] = xi[2];
+    s.mu = mu; s.Delta = Delta; s.pat = pat; s.it = it;
+    s.nrest = 0; s.n_nc = 0;
+    s.fbest = INFINITY; s.xbest[0] = s.xbest[1] = s.xbest[2] = 0.0;
+    s.sx[0] = s.sx[1] = s.sx[2] = 0.0; s.smu = -1.0; s.sDelta = -1.0; s.spat = -1;
+    s.force2 = false;
+    s.phase = FS_EVAL;
+}
+
+R2S_DEV void iso_full_fail(IsoFullLane& s)
+{
+    if (s.fbest < INFINITY) { s.xi[0] = s.xbest[0]; s.xi[1] = s.xbest[1]; s.xi[2] = s.xbest[2]; }
+    s.phase = FS_DONE;
+}
+
+template <class ER>
+R2S_DEV void iso_full_eval(const ER& E, double rt, double rtol, IsoFullLane& s)
+{
+    if (s.it > 16 && s.xi[0] == s.sx[0] && s.xi[1] == s.sx[1] && s.xi[2] == s.sx[2] && s.mu == s.smu && s.Delta == s.sDelta &&
+        s.pat == s.spat && !s.force2) {
+        iso_full_fail(s);
+        return;
+    }
+    if ((s.it == 16 || s.it == 32 || s.it == 64 || s.it == 128) && !s.force2) {
+        s.sx[0] = s.xi[0]; s.sx[1] = s.xi[1]; s.sx[2] = s.xi[2]; s.smu = s.mu; s.sDelta = s.Delta; s.spat = s.pat;
+    }
+    double r[3], J[3][3], G[3][3], M2[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const TriEval t = tri_eval_full(R2S_CX(E, i), s.xi);
+        r[i] = s.x[i] - t.v;
+        J[i][0] = t.d1; J[i][1] = t.d2; J[i][2] = t.d3;
+        M2[i][0] = t.m12; M2[i][1] = t.m13; M2[i][2] = t.m23;
+    }
+    const double f = dot3(r[0], r[1], r[2], r[0], r[1], r[2]);
+    const TriEval tr = tri_eval_full(R2S_CR(E), s.xi);
+    double c = tr.v - rt;
+    s.a[0] = tr.d1; s.a[1] = tr.d2; s.a[2] = tr.d3;
+    if (fabs(c) <= rtol) c = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (fabs(s.a[j]) <= rtol) s.a[j] = 0.0;
+    if (c == 0.0 && f < s.fbest) { s.fbest = f; s.xbest[0] = s.xi[0]; s.xbest[1] = s.xi[1]; s.xbest[2] = s.xi[2]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s.g[j] = -2.0 * dot3(r[0], r[1], r[2], J[0][j], J[1][j], J[2][j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j)
+            G[i][j] = G[j][i] = 2.0 * dot3(J[0][i], J[1][i], J[2][i], J[0][j], J[1][j], J[2][j]);
+    s.pat = iso_clean_pattern(s.pat, s.xi);
+    double lam;
+    {
+        double num = 0.0, den = 0.0;
+        const int sp[3] = {s.pat & 3, (s.pat >> 2) & 3, s.pat >> 4};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (!sp[i]) { num = fma(s.a[i], s.g[i], num); den = fma(s.a[i], s.a[i], den); }
+        lam = (den > 0.0) ? -num / den : 0.0;
+    }
+    double S[3];
+    {
+        const double mr[3] = {tr.m12, tr.m13, tr.m23};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            S[q] = fma(lam, mr[q], -2.0 * dot3(r[0], r[1], r[2], M2[0][q], M2[1][q], M2[2][q]));
+    }
+    double lo[3], hi[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        lo[i] = fmax(-1.0 - s.xi[i], -s.Delta);
+        hi[i] = fmin(1.0 - s.xi[i], s.Delta);
+    }
+    const double e = -c;
+    double mplus = 0.0, mminus = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double p = s.a[i] * lo[i], q = s.a[i] * hi[i];
+        mplus += fmax(p, q);
+        mminus += fmin(p, q);
+    }
+    const double trG = G[0][0] + G[1][1] + G[2][2];
+    const double aa2 = dot3(s.a[0], s.a[1], s.a[2], s.a[0], s.a[1], s.a[2]);
+    const double sigma = 100.0 * trG / aa2;
+    s.convex = true; s.corner = false; s.stall = false; s.stop = 0;
+    s.lam_new = lam; s.alpha = 1.0; s.qstep = 0.0;
+    s.f = f; s.c = c;
+    if (e > mplus) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0);
+        s.corner = true;
+    } else if (e < mminus) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.d[i] = (s.a[i] > 0.0) ? lo[i] : ((s.a[i] < 0.0) ? hi[i] : 0.0);
+        s.corner = true;
+    }
+    if (s.corner) {
+        double bp = 0.0, bm = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double p = s.a[i] * (-1.0 - s.xi[i]), q = s.a[i] * (1.0 - s.xi[i]);
+            bp += fmax(p, q);
+            bm += fmin(p, q);
+        }
+        if ((e > 0.0) ? !(bp > 0.05 * e) : !(bm < 0.05 * e)) s.stall = true;
+        double Gd[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Gd[i] = dot3(G[i][0], G[i][1], G[i][2], s.d[0], s.d[1], s.d[2]);
+        s.se = dot3(s.d[0], s.d[1], s.d[2], Gd[0], Gd[1], Gd[2]);
+        s.phase = FS_POST;
+    } else {
+        double gp[3];
+        int stage = s.force2 ? 1 : 0;
+        double sg = stage ? 100.0 * sigma : sigma;
+        for (;;) {
+            iso_qp_data(G, S, s.a, s.g, sg, e, s.H, gp);
+            // (force2: the walk of this iteration ran into a face on which the first matrix is not positive definite - the
+            //  complete solver rebuilds the matrix with the second sigma and restarts the walk WITHOUT testing the warm-start
+            //  face again; the walk's first pattern performs the same Sylvester test, so testing it here changes nothing)
+            s.convex = iso_face_spd(s.H, s.pat);
+            if (s.convex || stage) break;
+            stage = 1;
+            sg = 100.0 * sigma;
+        }
+        s.se = sg * e;
+        s.stage2 = (stage != 0);
+        s.p = s.pat;
+        s.step = 0;
+        s.phase = s.convex ? FS_QP : FS_ENUM;
+    }
+    s.force2 = false;
+}
+
+R2S_DEV void iso_full_bounds(const IsoFullLane& s, double lo[3], double hi[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        lo[i] = fmax(-1.0 - s.xi[i], -s.Delta);
+        hi[i] = fmin(1.0 - s.xi[i], s.Delta);
+    }
+}
+
+R2S_DEV void iso_full_qp(IsoFullLane& s)
+{
+    QpOut o;
+    double lo[3], hi[3], gp[3];
+    iso_full_bounds(s, lo, hi);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gp[i] = fma(-s.se, s.a[i], s.g[i]);
+    const double e = -s.c;
+    const int rc = qp_pattern(s.p, s.H, gp, s.a, e, lo, hi, o);
+    if (rc == 0 && !s.stage2) {
+        s.force2 = true;          // once more with the larger sigma, from the warm-start pattern
+        s.phase = FS_EVAL;
+    } else if (rc == 0) {
+        s.convex = false;
+        s.phase = FS_ENUM;
+    } else if (rc == 1 && o.kkt) {
+        s.pat = s.p;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.d[i] = fmin(fmax(o.d[i], lo[i]), hi[i]);
+        s.lam_new = o.lam;
+        s.qstep = o.q;
+        s.phase = FS_POST;
+    } else {
+        s.p = o.next;
+        s.step += 1;
+        if (!(s.step < R2S_QP_WALK && s.p >= 0)) s.phase = FS_ENUM;   // exhaustive search (convex flavour)
+    }
+}
+
+R2S_DEV void iso_full_enum(IsoFullLane& s)
+{
+    QpOut o;
+    double lo[3], hi[3], gp[3];
+    iso_full_bounds(s, lo, hi);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gp[i] = fma(-s.se, s.a[i], s.g[i]);
+    const double e = -s.c;
+    bool found = false;
+    double bestq = INFINITY;
+    for (int ip = 0; ip < 19; ++ip) {
+        const int p = c_pat_order[ip];
+        int rc;
+        if (s.convex || ip == 0) {
+            rc = qp_pattern(p, s.H, gp, s.a, e, lo, hi, o);
+        } else if (ip < 7) {   // one variable fixed
+            const int s0 = p & 3, s1 = (p >> 2) & 3, s2 = p >> 4;
+            const int i = s0 ? 0 : (s1 ? 1 : 2);
+            rc = qp_fixed1(i, s0 + s1 + s2, s.H, gp, s.a, e, lo, hi, o);
+        } else {               // two fixed
+            const int s0 = p & 3, s1 = (p >> 2) & 3, s2 = p >> 4;
+            const int k = !s0 ? 0 : (!s1 ? 1 : 2);
+            rc = qp_fixed2(k, (k == 0) ? s1 : s0, (k == 2) ? s1 : s2, s.H, gp, s.a, e, lo, hi, o);
+        }
+        if (rc == 1) {
+            if ((s.convex && o.kkt) || o.q < bestq) {
+                bestq = o.q;
+                found = true;
+                s.pat = p;
+                s.d[0] = o.d[0]; s.d[1] = o.d[1]; s.d[2] = o.d[2];
+                s.lam_new = o.lam;
+                s.qstep = o.q;
+            }
+            if (s.convex && o.kkt) break;
+        }
+    }
+    if (!found) {   // numerically degenerate: corner move towards feasibility (without the curvature term of the penalty rule)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            s.d[i] = (e > 0.0) ? ((s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0))
+                               : ((s.a[i] > 0.0) ? lo[i] : ((s.a[i] < 0.0) ? hi[i] : 0.0));
+        s.corner = true;
+        s.convex = true;
+        s.se = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s.d[i] = fmin(fmax(s.d[i], lo[i]), hi[i]);
+    s.phase = FS_POST;
+}
+
+template <class ER>
+R2S_DEV void iso_full_post(const ER& E, double rt, double rtol, IsoFullLane& s)
+{
+    if (!s.convex && ++s.n_nc > R2S_ISO_MAX_NONCONVEX) { iso_full_fail(s); return; }
+    const double dmax = fmax(fabs(s.d[0]), fmax(fabs(s.d[1]), fabs(s.d[2])));
+    s.dmax = dmax;
+    const double ad = dot3(s.a[0], s.a[1], s.a[2], s.d[0], s.d[1], s.d[2]);
+    const double pred_c = fabs(s.c) - fabs(s.c + ad);
+    const bool near_feas = (fabs(s.c) <= 1e4 * rtol);
+    const double mu_keep = (fabs(s.c) <= 1e10 * rtol) ? 0.5 : 1.0;
+    s.phase = FS_UPD;
+    if (s.stall) {
+        s.stop = 2;
+    } else if (!s.convex) {
+        double mu_t = fmax(mu_keep * s.mu, 2.0 * fabs(s.lam_new));
+        double pred = fma(mu_t, pred_c, -s.qstep);
+        if (!(pred > 0.0)) {
+            if (pred_c > 0.0) { mu_t = 2.0 * s.qstep / pred_c; pred = s.qstep; }
+            else s.stop = near_feas ? 3 : 2;
+        }
+        if (!s.stop && !(pred > 1e-14 * s.f)) s.stop = 3;
+        if (!s.stop) {
+            s.mu = mu_t;
+            double xt[3], ft, ct;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(s.xi[i] + s.d[i], -1.0), 1.0);
+            iso_eval_fc(E, s.x, rt, xt, ft, ct);
+            const double phi0 = fma(s.mu, fabs(s.c), s.f);
+            if (!(phi0 - fma(s.mu, fabs(ct), ft) >= 1e-4 * pred)) {
+                const int sp[3] = {s.pat & 3, (s.pat >> 2) & 3, s.pat >> 4};
+                double den = 0.0, d2[3] = {s.d[0], s.d[1], s.d[2]};
+                bool ok = false;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (!sp[i]) den = fma(s.a[i], s.a[i], den);
+                if (den > 0.0) {
+                    const double sc = -ct / den;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        if (!sp[i]) d2[i] = fma(sc, s.a[i], s.d[i]);
+                        xt[i] = fmin(fmax(s.xi[i] + d2[i], -1.0), 1.0);
+                    }
+                    double f2, c2;
+                    iso_eval_fc(E, s.x, rt, xt, f2, c2);
+                    ok = (phi0 - fma(s.mu, fabs(c2), f2) >= 1e-4 * pred);
+                }
+                if (ok) { s.d[0] = d2[0]; s.d[1] = d2[1]; s.d[2] = d2[2]; }
+                else s.alpha = 0.0;
+            }
+        }
+    } else if (!(dmax > R2S_ISO_TOL)) {
+        s.stop = (s.corner && !near_feas) ? 2 : 1;
+    } else {
+        const double gd = dot3(s.g[0], s.g[1], s.g[2], s.d[0], s.d[1], s.d[2]);
+        double mu_t = s.corner ? s.mu : fmax(mu_keep * s.mu, 2.0 * fabs(s.lam_new));
+        if (s.corner && pred_c > 0.0) {
+            const double need = 2.0 * fma(0.5, s.se, gd) / pred_c;
+            if (need > mu_t) mu_t = need;
+        }
+        if (!(fma(-mu_t, pred_c, gd) < 0.0)) {
+            if (pred_c > 0.0) mu_t = 2.0 * gd / pred_c;
+            else s.stop = (near_feas && !s.corner) ? 4 : 2;
+        }
+        if (!s.stop) {
+            s.mu = mu_t;
+            s.D = fma(-s.mu, pred_c, gd);
+            s.phi0 = fma(s.mu, fabs(s.c), s.f);
+            s.ls = 0;
+            s.phase = FS_LS;
+        }
+    }
+}
+
+template <class ER>
+R2S_DEV void iso_full_ls(const ER& E, double rt, IsoFullLane& s)
+{
+    double xt[3], ft, ct;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xt[i] = fmin(fmax(fma(s.alpha, s.d[i], s.xi[i]), -1.0), 1.0);
+    iso_eval_fc(E, s.x, rt, xt, ft, ct);
+    if (fma(s.mu, fabs(ct), ft) <= fma(1e-4 * s.alpha, s.D, s.phi0)) { s.phase = FS_UPD; return; }
+    if (s.ls == 0 && !s.corner) {
+        const int sp[3] = {s.pat & 3, (s.pat >> 2) & 3, s.pat >> 4};
+        double den = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (!sp[i]) den = fma(s.a[i], s.a[i], den);
+        if (den > 0.0) {
+            const double sc = -ct / den;
+            double d2[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                d2[i] = sp[i] ? s.d[i] : fma(sc, s.a[i], s.d[i]);
+                xt[i] = fmin(fmax(s.xi[i] + d2[i], -1.0), 1.0);
+            }
+            double f2, c2;
+            iso_eval_fc(E, s.x, rt, xt, f2, c2);
+            if (fma(s.mu, fabs(c2), f2) <= fma(1e-4, s.D, s.phi0)) {
+                s.d[0] = d2[0]; s.d[1] = d2[1]; s.d[2] = d2[2];
+                s.phase = FS_UPD;
+                return;
+            }
+        }
+    }
+    s.alpha *= 0.5;
+    s.ls += 1;
+    if (s.ls == 30) s.phase = FS_UPD;
+}
+
+template <class ER>
+R2S_DEV void iso_full_upd(const ER& E, double rt, double rtol, IsoFullLane& s)
+{
+    s.Delta = (s.alpha < 1.0) ? ((s.alpha > 0.0) ? s.alpha * s.dmax : 0.25 * s.dmax) : fmin(2.0, fmax(s.Delta, 2.0 * s.dmax));
+    if (s.stop == 2) {
+        const bool near_feas = (fabs(s.c) <= 1e4 * rtol);
+        double xr[3];
+        if (!near_feas && s.nrest < R2S_ISO_MAX_RESTORE && iso_restore(E, s.x, rt, s.xi, s.c, xr)) {
+            s.xi[0] = xr[0]; s.xi[1] = xr[1]; s.xi[2] = xr[2];
+            s.mu = 0.0; s.Delta = 2.0; s.pat = 0; s.nrest++;
+            s.it += 1;
+            if (s.it == R2S_ISO_MAXIT) iso_full_fail(s); else s.phase = FS_EVAL;
+            return;
+        }
+        iso_full_fail(s);
+        return;
+    }
+    if (s.stop == 3 || s.stop == 4) { s.phase = FS_DONE; return; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s.xi[i] = fmin(fmax(fma(s.alpha, s.d[i], s.xi[i]), -1.0), 1.0);
+    if (s.stop == 1) { s.phase = FS_DONE; return; }
+    s.it += 1;
+    if (s.it == R2S_ISO_MAXIT) iso_full_fail(s); else s.phase = FS_EVAL;
 }
 
 // ---- the fast path of the same solver as a per-lane state machine ---------------------------------------

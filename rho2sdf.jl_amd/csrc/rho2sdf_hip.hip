@@ -1264,69 +1264,109 @@ extern "C" int r2s_debug_strag_diag(unsigned long long* out)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_strag_diag), z, sizeof z) != hipSuccess;
 }
 #endif
-// The pairs the fast path handed over, compacted: one lane per pair runs the complete solver (iso_project_full) from
-// xi = 0 - the oracle's iteration operation for operation - and writes the pair's result slot.
+// The pairs the fast path handed over, compacted.  Persistent one-wave workgroups with lane refill run the COMPLETE
+// solver as a lane machine (iso_full_* in r2s_device_math.hpp = iso_project_full = the oracle's iteration, operation for
+// operation): a lane takes the next list entry when its pair is done, and a trip costs what the phases of its lanes cost.
+// (Round 3 started with one lane per pair running iso_project_full straight through: a wavefront then lasts as long as
+// its slowest lane and executes the union of its lanes' branches in every iteration - 14 us per wavefront-iteration,
+// 0.45-0.6 ms for 3 % of the fast kernel's instructions.)  Every lane has its own element: the 32 coefficients of the
+// solver live in a padded LDS column per lane (33 doubles: two-way bank conflicts at most).
+struct IsoCoefPad {
+    double C[8][3];
+    double Cr[8];
+    double pad;
+};
+#ifndef R2S_STRAG_REFILL_MIN
+#define R2S_STRAG_REFILL_MIN 8
+#endif
 __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
                                                            const uint32_t* __restrict__ strag_cnt, const ElemRec* __restrict__ erec,
                                                            double rho_t, double* __restrict__ res, double* __restrict__ res_xp,
-                                                           const uint32_t* __restrict__ abort_flag, uint32_t target_waves, int ppw_arg)
+                                                           const uint32_t* __restrict__ abort_flag, uint32_t* __restrict__ head)
 {
     if (*abort_flag) return;
+    __shared__ IsoCoefPad coef[64];
     const uint32_t n = min(strag_cnt[0], strag_cap);
+    const uint32_t lane = threadIdx.x;
+    IsoFullLane s;
+    s.phase = FS_IDLE;
+    uint32_t my_el = 0;
+    uint64_t my_slot = 0;
+    double rtol = 0.0;
+    bool exhausted = false;
 #ifdef R2S_STRAG_DIAG
     const unsigned long long t0 = wall_clock64();
-    int its_max = 0, its_sum = 0;
+    unsigned long long trips = 0, pairs = 0;
 #endif
-    // pairs per wavefront: a wavefront lasts as long as its slowest lane and executes the union of its lanes' branches,
-    // so fewer pairs per wavefront finish sooner as long as there are SIMDs to spare - 64 only when the list is long
-    // enough to give every SIMD two full wavefronts (a rank's share of a multi-GPU run has an eighth of the pairs and
-    // the same latency otherwise)
-    const uint32_t ppw = (ppw_arg > 0) ? (uint32_t)ppw_arg : min(64u, max(8u, (n + target_waves - 1u) / target_waves));
-    if (threadIdx.x >= ppw) return;
-    // (consecutive entries per wavefront: the list is in work order, neighbouring entries come from the same element and
-    //  need similar treatment - interleaving them over the wavefronts was measured: every wavefront then executes the
-    //  union of all kinds of runs in every iteration, 19 us per iteration instead of 14, the kernel 0.6 instead of 0.45 ms)
-    for (uint32_t i = blockIdx.x * ppw + threadIdx.x; i < n; i += gridDim.x * ppw) {
-        const IsoStraggler e = strag[i];
-        const ElemRec& E = erec[e.el];
-        // the solver's coefficients in registers: the 30-odd field evaluations of a run must not each wait for memory
-        // (one wavefront per SIMD, 64 different elements per wavefront: nothing hides that latency)
-        IsoElemCoef K;
+    for (;;) {
+        const uint64_t m_done = __ballot(s.phase == FS_DONE);
+        const uint64_t m_busy = __ballot(s.phase != FS_DONE && s.phase != FS_IDLE);
+        if (m_busy == 0 || __popcll(m_done) >= R2S_STRAG_REFILL_MIN || (!exhausted && __popcll(__ballot(s.phase == FS_IDLE)) >= R2S_STRAG_REFILL_MIN)) {
+            if (s.phase == FS_DONE) {
+                const ElemRec& E = erec[my_el];
+                double N[8], xp[3];
+                hex8_shape(s.xi, N);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            K.C[k][0] = E.C[k][0]; K.C[k][1] = E.C[k][1]; K.C[k][2] = E.C[k][2];
-            K.Cr[k] = E.Cr[k];
-        }
-        double xi[3] = {e.xi[0], e.xi[1], e.xi[2]};
+                for (int q = 0; q < 3; ++q) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t = fma(E.X[k][q], N[k], t);
+                    xp[q] = t;
+                }
+                res[my_slot] = norm3(s.x[0] - xp[0], s.x[1] - xp[1], s.x[2] - xp[2]);
+                if (res_xp) {
+                    res_xp[3 * my_slot] = xp[0];
+                    res_xp[3 * my_slot + 1] = xp[1];
+                    res_xp[3 * my_slot + 2] = xp[2];
+                }
+                s.phase = FS_IDLE;
+            }
+            const uint64_t m_idle = __ballot(s.phase == FS_IDLE);
+            if (m_idle && !exhausted) {
+                const uint32_t nid = (uint32_t)__popcll(m_idle);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, nid);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + nid >= n) exhausted = true;
+                const uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                if (s.phase == FS_IDLE && i < n) {
+                    const IsoStraggler e = strag[i];
+                    const ElemRec& E = erec[e.el];
+                    IsoCoefPad& K = coef[lane];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        K.C[k][0] = E.C[k][0]; K.C[k][1] = E.C[k][1]; K.C[k][2] = E.C[k][2];
+                        K.Cr[k] = E.Cr[k];
+                    }
+                    rtol = fmax(fabs(rho_t), fmax(fabs(E.rmax), fabs(E.rmin))) * 1e-14;
+                    my_el = e.el;
+                    my_slot = e.slot;
+                    iso_full_start(s, e.x, e.xi, e.mu, e.Delta, e.pat, e.it);
 #ifdef R2S_STRAG_DIAG
-        const int its = iso_project_full(K, fmax(fabs(E.rmax), fabs(E.rmin)), e.x, rho_t, xi, e.mu, e.Delta, e.pat, e.it) - e.it;
-        its_max = its; its_sum = its;
-#else
-        iso_project_full(K, fmax(fabs(E.rmax), fabs(E.rmin)), e.x, rho_t, xi, e.mu, e.Delta, e.pat, e.it);
+                    pairs += 1;
 #endif
-        double N[8], xp[3];
-        hex8_shape(xi, N);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t = fma(E.X[k][q], N[k], t);
-            xp[q] = t;
+                }
+            }
+            if (exhausted && __ballot(s.phase != FS_IDLE) == 0) break;
         }
-        res[e.slot] = norm3(e.x[0] - xp[0], e.x[1] - xp[1], e.x[2] - xp[2]);
-        if (res_xp) {
-            res_xp[3 * e.slot] = xp[0];
-            res_xp[3 * e.slot + 1] = xp[1];
-            res_xp[3 * e.slot + 2] = xp[2];
+        // ---- one visit of each phase that some lane is in ----
+        {
+            const IsoCoefPad& E = coef[lane];
+            if (s.phase == FS_EVAL) iso_full_eval(E, rho_t, rtol, s);
+            if (s.phase == FS_QP) iso_full_qp(s);
+            if (s.phase == FS_ENUM) iso_full_enum(s);
+            if (s.phase == FS_POST) iso_full_post(E, rho_t, rtol, s);
+            if (s.phase == FS_LS) iso_full_ls(E, rho_t, s);
+            if (s.phase == FS_UPD) iso_full_upd(E, rho_t, rtol, s);
+#ifdef R2S_STRAG_DIAG
+            trips += 1;
+#endif
         }
     }
 #ifdef R2S_STRAG_DIAG
-    {   // per wavefront: cycles, longest and summed SQP iterations of its lanes
-        if (blockIdx.x < 16384) {
-            atomicMax(&g_strag_diag[3 * blockIdx.x + 1], (unsigned long long)its_max);
-            atomicAdd(&g_strag_diag[3 * blockIdx.x + 2], (unsigned long long)its_sum);
-            if (threadIdx.x == 0) g_strag_diag[3 * blockIdx.x] = wall_clock64() - t0;
-        }
+    if (blockIdx.x < 16384) {
+        atomicAdd(&g_strag_diag[3 * blockIdx.x + 2], pairs);
+        if (lane == 0) { g_strag_diag[3 * blockIdx.x] = wall_clock64() - t0; g_strag_diag[3 * blockIdx.x + 1] = trips; }
     }
 #endif
 }
@@ -2289,7 +2329,7 @@ static uint32_t iso_straggler_cap(uint32_t n_store)
 
 // The HEX8 projection on stream `st`: the persistent fast-path kernel, behind it the complete
 // solver on the pairs it handed over, last the sweep that only does something when the list overflowed.  Nothing here
-// waits for a count on the host.  counters: [8] chunk counter, [12] list entries, [13] overflow flag.
+// waits for a count on the host.  counters: [8] chunk counter, [12] list entries, [13] overflow flag, [14] list head.
 static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32_t n_chunks, uint32_t n_store, uint32_t wps,
                            const GridDev& g, const SlabInfo& s, double rho_t, double* res_xp, uint32_t* counters,
                            const uint32_t* abort_flag)
@@ -2317,11 +2357,8 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
     else
         iso_project_hex_pl_kernel<2><<<grid, 64, 0, st>>>(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
                                                           counters + 8, perm, abort_flag, list, cap, counters + 12, counters + 13);
-    static const int ppw_env = getenv("R2S_STRAG_PPW") ? atoi(getenv("R2S_STRAG_PPW")) : 0;   // tuning knob: pairs per straggler wavefront
-    // 8-64 pairs per wavefront (chosen on the device from the count): enough wavefronts for the shortest list, grid-stride
-    // beyond half a million pairs; the wavefronts beyond the count leave at once
-    iso_straggler_kernel<<<std::min<uint32_t>((cap + 7u) / 8u, 65536u), 64, 0, st>>>(list, cap, counters + 12, erec, rho_t, res, res_xp,
-                                                                                    abort_flag, (uint32_t)P->n_cu * 8u, ppw_env);
+    // two persistent wavefronts per SIMD pull entries from the list (counters[14]); those that find none leave at once
+    iso_straggler_kernel<<<(uint32_t)P->n_cu * 8u, 64, 0, st>>>(list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, counters + 14);
     iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(items, n_items, chunk_off, n_chunks, perm, erec, g, s, rho_t, res, res_xp,
                                                              counters + 13, abort_flag);
     return 0;

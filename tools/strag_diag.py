@@ -28,10 +28,10 @@ for _ in range(3):
 L.r2s_debug_strag_diag(buf)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 3).astype(np.int64)
 act = a[a[:, 2] > 0]
-print("active wavefronts", len(act), "pairs' iterations in all", act[:, 2].sum())
+print("wavefronts with work", len(act), "pairs in all", act[:, 2].sum(), "trips in all", act[:, 1].sum())
 cyc = act[:, 0] / 100.0   # wall_clock64 ticks at 100 MHz -> microseconds
 print("wavefront duration us: mean %.1f  median %.1f  p90 %.1f  p99 %.1f  max %.1f" % (cyc.mean(), np.median(cyc), np.percentile(cyc, 90), np.percentile(cyc, 99), cyc.max()))
-print("longest lane (iterations) per wavefront: mean %.1f max %d;  us per iteration of the longest lane: median %.1f" % (act[:, 1].mean(), act[:, 1].max(), np.median(cyc / np.maximum(act[:, 1], 1))))
-print("histogram of the longest lane per wavefront (iterations):", np.bincount(np.minimum(act[:, 1], 60) // 5).tolist())
+print("trips per wavefront: mean %.1f max %d;  us per trip: median %.2f;  pairs per wavefront: mean %.1f max %d" % (
+    act[:, 1].mean(), act[:, 1].max(), np.median(cyc / np.maximum(act[:, 1], 1)), act[:, 2].mean(), act[:, 2].max()))
 order = np.argsort(-cyc)[:8]
-print("slowest wavefronts (us, longest lane, sum):", [(round(float(cyc[i]), 1), int(act[i, 1]), int(act[i, 2])) for i in order])
+print("slowest wavefronts (us, trips, pairs):", [(round(float(cyc[i]), 1), int(act[i, 1]), int(act[i, 2])) for i in order])
