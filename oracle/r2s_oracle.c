@@ -355,19 +355,23 @@ int orc_inv_map_hex8(const double x[3], const double *Xe_flat /* 8*3 */, double 
 /*   min_xi ||x - Xe N(xi)||^2  s.t.  N(xi).rho_e = rho_t, -1<=xi<=1    */
 /*   start xi = 0 (ComputeCoordsOnIso.jl:25-26,70,78)                  */
 /*                                                                     */
-/* Reference optimiser: NLopt LD_SLSQP (tolerances 1e-5).  Restated as */
-/* an SQP on the same problem from the same start, converged to ISO_TOL on the step: */
-/*   - Hessian of the Lagrangian: exact (Gauss-Newton part 2 J^T J plus */
-/*     the mixed second derivatives of the trilinear maps) when that is */
-/*     positive definite, Gauss-Newton otherwise;                       */
-/*   - QP sub-problem (3 unknowns, 1 linear equality, box) solved       */
-/*     exactly: the previous active set is accepted if it satisfies the */
-/*     KKT conditions, otherwise all 27 free/lower/upper patterns are   */
-/*     solved and the primal-feasible one of least QP value is taken    */
-/*     (for a strictly convex QP that is the unique minimiser);         */
-/*   - if the linearised equality cannot be met inside the box the step */
-/*     goes to the box corner that comes closest to meeting it;         */
-/*   - backtracking on the L1 merit f + mu |c|.                         */
+/* Reference optimiser: NLopt LD_SLSQP (tolerances 1e-5, maxeval 1000).  Restated as a second-order SQP on the same
+ * problem from the same start, converged to ISO_TOL on a step of the convex mode (DESIGN.md section 2 has the reasons
+ * for every rule and what round 2's version got wrong):
+ *   - Hessian of the Lagrangian: always the exact one (Gauss-Newton part 2 J^T J plus the mixed second derivatives of
+ *     the trilinear maps, multiplier = least squares over the free variables), convexified along the constraint
+ *     normal (H + sigma a a^T, two sizes of sigma);
+ *   - convex on the faces the active-set walk visits: QP (3 unknowns, 1 linear equality, box cut with the trust region)
+ *     solved exactly - walk from the previous pattern, exhaustive search over the 19 patterns when it cycles; L1 merit
+ *     f + mu |c| with back-tracking and a second-order correction at the first failed trial;
+ *   - not convex: global minimiser of the QP over box and trust region, taken as a trust-region step (actual against
+ *     predicted reduction of the merit function), the region shrinks on rejection;
+ *   - linearised equality out of reach inside the trust region: step to the corner that comes closest; out of reach
+ *     anywhere in the element, or no descent off the surface: restoration along the segments to the nodes on the other
+ *     side of rho_t;
+ *   - rounding residue of the density field (1e-14 of its scale) counts as zero; a constraint gradient without a
+ *     component along the free variables makes the equality vacuous on that face;
+ *   - failing runs (caps, Brent's cycle test) return the nearest iterate that was on the iso-surface.                  */
 /* ------------------------------------------------------------------ */
 #define ISO_MAXIT 100
 #define ISO_MAX_NONCONVEX 48 /* iterations on a non-convex model per run: converging runs were seen to need <= 30 (<= 47 iterations in
@@ -607,7 +611,7 @@ static int iso_project_hex8(const double x[3], const double Xe[16][3], const dou
          * ever (nearly degenerate elements - an iso-surface within 1e-4 of an element face - send feasibility steps,
          * restorations and QP steps round in cycles of period 3-9).  Brent's scheme: remember the state at iterations
          * 16, 32, 64, 128 and stop as failed when it recurs, instead of running to the cap (the slowest lane sets the
-         * run time of the device's straggler launch: 200 iterations of one pair were 3 ms). */
+         * run time of the device's straggler launch). */
         if (it > 16 && xi[0] == sx[0] && xi[1] == sx[1] && xi[2] == sx[2] && mu == smu && Delta == sDelta && pat == spat) {
             st.it = it; g_iso_stats = st;
             if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }

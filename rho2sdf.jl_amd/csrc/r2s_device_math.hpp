@@ -667,8 +667,9 @@ R2S_DEV int iso_clean_pattern(int pat, const double xi[3])
 // ---- the complete solver, one lane = one (element, voxel) pair ------------------------------------------
 // Operation for operation the oracle's iso_project_hex8 (oracle/r2s_oracle.c): exact Lagrangian Hessian, convex
 // active-set QP or the global minimiser of the non-convex QP over the trust region, L1 merit with second-order
-// correction, restoration along nodal segments from stalls.  iso_straggler_kernel / iso_sweep_kernel run it for the
-// pairs the fast lane machine below hands over (anything but plain full Newton-SQP steps).
+// correction, restoration along nodal segments from stalls.  This straight-line form is the REFERENCE for the two lane
+// machines below (the complete one of iso_straggler_kernel, phase by phase the same operations; the fast path of
+// iso_project_hex_pl_kernel, its common case) and what iso_sweep_kernel runs when the straggler list overflowed.
 template <class ER>
 R2S_DEV bool iso_restore(const ER& E, const double x[3], double rt, const double xi[3], double c, double out[3])
 {
@@ -1398,8 +1399,10 @@ R2S_DEV void iso_full_upd(const ER& E, double rt, double rtol, IsoFullLane& s)
 // and feasibility steps into a corner of the trust region.  Every phase performs exactly the IEEE operations of the
 // corresponding part of iso_project_full, in the same order.  Anything else (non-convex model, second sigma, exhaustive
 // pattern search, rejected step, stall, more than R2S_ISO_FAST_IT iterations) ends in ISO_BAIL: the pair goes to the
-// straggler list and iso_project_full solves it from the start.  The fast path therefore never has to agree with the
-// complete solver beyond the point where it bails - and needs neither line-search nor pattern-search state.
+// straggler list with its state at the start of the iteration (xi, mu, Delta, pattern, iteration count) and the complete
+// lane machine continues from there (from xi = 0 when an earlier iterate was exactly feasible: IsoLane::seen).  The fast
+// path therefore never has to agree with the complete solver beyond the point where it bails - and needs neither
+// line-search nor pattern-search state.
 //   EVAL    fields, QP data, corner test            -> QP | FINISH | BAIL
 //   QP      ONE active-set pattern per visit        -> QP | FINISH | BAIL
 //   FINISH  step test, merit parameter, the full-step trial, trust region, iterate update -> EVAL | DONE | BAIL
