@@ -319,20 +319,22 @@ def main():
 
     if rank == 0:
         sts = [s for s in stats_acc if s]
-        avg = {k: float(np.mean([s[k] for s in sts])) for k in ("ms_prep", "ms_bins", "ms_fill", "ms_main", "ms_gather", "ms_sign")}
+        avg = {k: float(np.mean([s[k] for s in sts])) for k in ("ms_prep", "ms_bins", "ms_fill", "ms_main", "ms_iso_fast", "ms_gather", "ms_sign")}
         st0 = sts[-1]
         nvox_rank = sg.my_planes * plane
         mesh_bytes = X.nbytes + IEN.nbytes + rho_n.nbytes
         alg_bytes = ALG_BYTES_PER_VOXEL * nvox_rank + mesh_bytes
         dominant = DOMINANT_KERNEL[elem]
-        main_s = avg["ms_main"] * 1e-3
+        # HEX8: the dominant kernel alone (its own pair of events); ms_main also spans the straggler and sweep kernels
+        kernel_ms = avg["ms_iso_fast"] if avg["ms_iso_fast"] > 0 else avg["ms_main"]
+        main_s = kernel_ms * 1e-3
         achieved = alg_bytes / main_s / 1e9 if main_s > 0 else 0.0
         default_ns = args.workload == "ns" and not args.grid and not args.mesh and world == 1
         prof = load_committed_profile(dominant) if default_ns else None
         roof = {"bound": "hbm", "kernel": dominant,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": prof["traffic"] if prof else None,
-                "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["ms_main"],
+                "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
                 "avg_launch_ms_source": "HIP events around the kernel on its launch stream, this run",
                 "real_limiter": "fp64-valu",
                 "note": "the dominant kernel is FP64-VALU bound (SURVEY.md 0.7), not HBM bound: achieved/peak/frac are the "

@@ -93,6 +93,8 @@ typedef struct {
      * (sdf_tiles_kernel<dist>), sign kernel */
     double ms_prep, ms_bins, ms_fill, ms_main, ms_gather, ms_sign;
     int64_t n_sign_only_tiles; /* tiles without band items whose voxels are all +-1e10 (compressed stitching) */
+    /* HEX8: iso_project_hex_pl_kernel alone; ms_main also holds iso_straggler_kernel and iso_sweep_kernel */
+    double ms_iso_fast;
 } r2s_stats;
 
 int r2s_version(void);

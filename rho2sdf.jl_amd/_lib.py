@@ -56,7 +56,7 @@ class R2SStats(ctypes.Structure):
                 ("ms_prep", ctypes.c_double), ("ms_bins", ctypes.c_double),
                 ("ms_fill", ctypes.c_double), ("ms_main", ctypes.c_double),
                 ("ms_gather", ctypes.c_double), ("ms_sign", ctypes.c_double),
-                ("n_sign_only_tiles", ctypes.c_int64)]
+                ("n_sign_only_tiles", ctypes.c_int64), ("ms_iso_fast", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

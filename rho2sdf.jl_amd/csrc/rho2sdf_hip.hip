@@ -2141,6 +2141,8 @@ struct r2s_plan {
     hipStream_t st2 = nullptr;
     hipStream_t st3 = nullptr;   // bounding half-spaces (hex_planes_kernel), beside the chains of the other two during preparation
     hipEvent_t ev2[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fast[2] = {nullptr, nullptr};   // around iso_project_hex_pl_kernel alone (r2s_stats.ms_iso_fast)
+    bool fast_timed = false;                      // ... recorded by the current call
 };
 
 // exclusive scans of one or two (in1 != nullptr) arrays of n entries each
@@ -2279,6 +2281,7 @@ int r2s_plan_create(int32_t device, r2s_plan** out)
     HIP_TRY(hipHostGetDevicePointer((void**)&P->d_pinned, P->h_pinned, 0));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev[i]));
     for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&P->ev2[i]));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreate(&P->ev_fast[i]));
     {
         // high priority: the short stages of the second stream (sentinel sweep, inverse maps of the sign pass,
         // sign-only gather) get wave slots ahead of the long persistent projection kernel.  Measured on the
@@ -2309,6 +2312,8 @@ void r2s_plan_destroy(r2s_plan* P)
         if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
     for (int i = 0; i < 8; ++i)
         if (P->ev2[i]) (void)hipEventDestroy(P->ev2[i]);
+    for (int i = 0; i < 2; ++i)
+        if (P->ev_fast[i]) (void)hipEventDestroy(P->ev_fast[i]);
     if (P->st2) (void)hipStreamDestroy(P->st2);
     if (P->st3) (void)hipStreamDestroy(P->st3);
     delete P;
@@ -2351,12 +2356,15 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
     double* res = P->iso_res.as<double>();
     // two instantiations: 168 registers (3 wavefronts per SIMD, 48 B of scratch per lane) when the kernel has the GPU to
     // itself, 2 per SIMD without scratch when it starts beside the binning (early launch, see run_impl)
+    HIP_TRY(hipEventRecord(P->ev_fast[0], st));
     if (wps >= 3)
         iso_project_hex_pl_kernel<3><<<grid, 64, 0, st>>>(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
                                                           counters + 8, perm, abort_flag, list, cap, counters + 12, counters + 13);
     else
         iso_project_hex_pl_kernel<2><<<grid, 64, 0, st>>>(items, n_items, chunk_off, n_chunks, group, erec, g, s, rho_t, res, res_xp,
                                                           counters + 8, perm, abort_flag, list, cap, counters + 12, counters + 13);
+    HIP_TRY(hipEventRecord(P->ev_fast[1], st));
+    P->fast_timed = true;
     // two persistent wavefronts per SIMD pull entries from the list (counters[14]); those that find none leave at once
     iso_straggler_kernel<<<(uint32_t)P->n_cu * 8u, 64, 0, st>>>(list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, counters + 14);
     iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(items, n_items, chunk_off, n_chunks, perm, erec, g, s, rho_t, res, res_xp,
@@ -2387,6 +2395,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     if ((mode & R2S_OUT_XP) && !d_xp) return fail(R2S_ERR_ARG, "d_xp is null");
     HIP_TRY(hipSetDevice(P->device));
     hipStream_t st = (hipStream_t)stream;
+    P->fast_timed = false;
 
     GridDev g;
     for (int i = 0; i < 3; ++i) {
@@ -2905,6 +2914,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         if (hipEventElapsedTime(&ms, P->ev[1], P->ev[2]) == hipSuccess) stats->ms_bins = ms;
         if (hipEventElapsedTime(&ms, P->ev2[0], P->ev2[3]) == hipSuccess) stats->ms_fill = ms;   // second stream: beside the projection kernel
         if (hipEventElapsedTime(&ms, P->ev[7], P->ev[6]) == hipSuccess) stats->ms_main = ms;
+        if (P->fast_timed && hipEventElapsedTime(&ms, P->ev_fast[0], P->ev_fast[1]) == hipSuccess) stats->ms_iso_fast = ms;
         if (hipEventElapsedTime(&ms, P->ev[6], P->ev[4]) == hipSuccess) stats->ms_gather = ms;
         stats->n_iso_chunks = n_chunks;
         if (hipEventElapsedTime(&ms, P->ev[4], P->ev[5]) == hipSuccess) stats->ms_sign = ms;
