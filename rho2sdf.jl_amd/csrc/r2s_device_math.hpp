@@ -1258,6 +1258,79 @@ R2S_DEV void iso_full_enum(IsoFullLane& s)
     s.phase = FS_POST;
 }
 
+// iso_full_enum for ONE lane `src` (wave-uniform) by the whole wavefront: lane ip < 19 solves pattern ip of the owner's
+// QP, the winner is picked by the rule of the loop above (first pattern in c_pat_order with a KKT point when the model is
+// convex, else the first one with the smallest model value).  Same numbers as the loop - qp_pattern and its specialised
+// forms agree bit for bit - at the latency of one pattern instead of nineteen: the straggler kernel lasts as long as its
+// slowest pairs, and those are the ones whose iterations end up here.  All 64 lanes call it; only lane `src` changes.
+R2S_DEV void iso_full_enum_coop(IsoFullLane& s, const int src)
+{
+    double lo[3], hi[3], gp[3];
+    iso_full_bounds(s, lo, hi);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gp[i] = fma(-s.se, s.a[i], s.g[i]);
+    auto bcast = [src](double v) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+    };
+    Sym3 H;
+    H.a00 = bcast(s.H.a00); H.a01 = bcast(s.H.a01); H.a02 = bcast(s.H.a02);
+    H.a11 = bcast(s.H.a11); H.a12 = bcast(s.H.a12); H.a22 = bcast(s.H.a22);
+    double a[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a[i] = bcast(s.a[i]); gp[i] = bcast(gp[i]); lo[i] = bcast(lo[i]); hi[i] = bcast(hi[i]); }
+    const double e = bcast(-s.c);
+    const bool convex = __builtin_amdgcn_readlane((int)s.convex, src) != 0;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int pat = c_pat_order[lane < 19 ? lane : 0];
+    QpOut o;
+    const int rc = qp_pattern(pat, H, gp, a, e, lo, hi, o);
+    const bool ok = lane < 19 && rc == 1;
+    int win = -1;
+    const unsigned long long mk = __ballot(ok && o.kkt);
+    if (convex && mk) {
+        win = __builtin_ctzll(mk);
+    } else {
+        double q = (ok && o.q < INFINITY) ? o.q : INFINITY;   // (the loop takes a pattern only when q < best so far)
+        double qmin = q;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {   // lanes 0..18 hold the candidates: five butterfly steps reach them all
+            const double t = __hiloint2double(__shfl_xor(__double2hiint(qmin), off), __shfl_xor(__double2loint(qmin), off));
+            qmin = fmin(qmin, t);
+        }
+        const unsigned long long mq = __ballot(q < INFINITY && q == qmin);
+        if (mq) win = __builtin_ctzll(mq);
+    }
+    double wd[3] = {0.0, 0.0, 0.0}, wlam = 0.0, wq = 0.0;
+    if (win >= 0) {
+        auto from = [win](double v) {
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), win), __builtin_amdgcn_readlane(__double2loint(v), win));
+        };
+        wd[0] = from(o.d[0]); wd[1] = from(o.d[1]); wd[2] = from(o.d[2]);
+        wlam = from(o.lam);
+        wq = from(o.q);
+    }
+    if (lane != src) return;
+    iso_full_bounds(s, lo, hi);
+    const double es = -s.c;
+    if (win >= 0) {
+        s.pat = c_pat_order[win];
+        s.d[0] = wd[0]; s.d[1] = wd[1]; s.d[2] = wd[2];
+        s.lam_new = wlam;
+        s.qstep = wq;
+    } else {   // numerically degenerate: corner move towards feasibility (as in iso_full_enum)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            s.d[i] = (es > 0.0) ? ((s.a[i] > 0.0) ? hi[i] : ((s.a[i] < 0.0) ? lo[i] : 0.0))
+                                : ((s.a[i] > 0.0) ? lo[i] : ((s.a[i] < 0.0) ? hi[i] : 0.0));
+        s.corner = true;
+        s.convex = true;
+        s.se = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s.d[i] = fmin(fmax(s.d[i], lo[i]), hi[i]);
+    s.phase = FS_POST;
+}
+
 template <class ER>
 R2S_DEV void iso_full_post(const ER& E, double rt, double rtol, IsoFullLane& s)
 {

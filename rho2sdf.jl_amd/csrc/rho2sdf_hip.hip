@@ -1263,6 +1263,13 @@ extern "C" int r2s_debug_strag_diag(unsigned long long* out)
     static unsigned long long z[3 * 16384];
     return hipMemcpyToSymbol(HIP_SYMBOL(g_strag_diag), z, sizeof z) != hipSuccess;
 }
+__device__ unsigned long long g_strag_hist[256];   // [0,128): SQP iterations of a pair at its end; [128,256): its trips
+extern "C" int r2s_debug_strag_hist(unsigned long long* out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strag_hist), sizeof(unsigned long long) * 256) != hipSuccess) return 1;
+    static unsigned long long z[256];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_strag_hist), z, sizeof z) != hipSuccess;
+}
 #endif
 // The pairs the fast path handed over, compacted.  Persistent one-wave workgroups with lane refill run the COMPLETE
 // solver as a lane machine (iso_full_* in r2s_device_math.hpp = iso_project_full = the oracle's iteration, operation for
@@ -1278,6 +1285,9 @@ struct IsoCoefPad {
 };
 #ifndef R2S_STRAG_REFILL_MIN
 #define R2S_STRAG_REFILL_MIN 8
+#endif
+#ifndef R2S_ENUM_COOP_MAX
+#define R2S_ENUM_COOP_MAX 6   // lanes in the pattern search up to which the wavefront serves them one by one
 #endif
 __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
                                                            const uint32_t* __restrict__ strag_cnt, const ElemRec* __restrict__ erec,
@@ -1297,6 +1307,7 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
 #ifdef R2S_STRAG_DIAG
     const unsigned long long t0 = wall_clock64();
     unsigned long long trips = 0, pairs = 0;
+    int my_trips = 0;
 #endif
     for (;;) {
         const uint64_t m_done = __ballot(s.phase == FS_DONE);
@@ -1319,6 +1330,13 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
                     res_xp[3 * my_slot + 1] = xp[1];
                     res_xp[3 * my_slot + 2] = xp[2];
                 }
+#ifdef R2S_STRAG_DIAG
+                if (R2S_STRAG_DIAG >= 2) {   // (same-address atomics: the wavefront times of such a build mean nothing)
+                    atomicAdd(&g_strag_hist[min(max(s.it, 0), 127)], 1ull);
+                    atomicAdd(&g_strag_hist[128 + min(my_trips, 127)], 1ull);
+                }
+                my_trips = 0;
+#endif
                 s.phase = FS_IDLE;
             }
             const uint64_t m_idle = __ballot(s.phase == FS_IDLE);
@@ -1352,14 +1370,35 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
         // ---- one visit of each phase that some lane is in ----
         {
             const IsoCoefPad& E = coef[lane];
-            if (s.phase == FS_EVAL) iso_full_eval(E, rho_t, rtol, s);
-            if (s.phase == FS_QP) iso_full_qp(s);
-            if (s.phase == FS_ENUM) iso_full_enum(s);
+            // The short phases a pair may visit several times per iteration (active-set walk: <= 8 patterns; second
+            // sigma: back to EVAL once; line search: <= 30 trials) are repeated until no lane is left in them, instead
+            // of one visit per trip of ALL phases: a pair took 2.5 trips per SQP iteration, and the kernel lasts as
+            // long as the trips of its slowest pairs (0.455 -> 0.41 ms behind the fast kernel)
+            for (int rep = 0; rep < 2; ++rep) {
+                if (s.phase == FS_EVAL) iso_full_eval(E, rho_t, rtol, s);
+                while (__ballot(s.phase == FS_QP)) {
+                    if (s.phase == FS_QP) iso_full_qp(s);
+                }
+                if (!__ballot(s.phase == FS_EVAL)) break;
+            }
+            {
+                // exhaustive pattern search: one lane at a time by the whole wavefront while few lanes need it (the tail
+                // of the kernel is a handful of pairs with dozens of non-convex iterations), lane by lane otherwise
+                uint64_t m_enum = __ballot(s.phase == FS_ENUM);
+                if (m_enum && __popcll(m_enum) <= R2S_ENUM_COOP_MAX) {
+                    for (; m_enum; m_enum &= m_enum - 1) iso_full_enum_coop(s, (int)__builtin_ctzll(m_enum));
+                } else if (s.phase == FS_ENUM) {
+                    iso_full_enum(s);
+                }
+            }
             if (s.phase == FS_POST) iso_full_post(E, rho_t, rtol, s);
-            if (s.phase == FS_LS) iso_full_ls(E, rho_t, s);
+            while (__ballot(s.phase == FS_LS)) {
+                if (s.phase == FS_LS) iso_full_ls(E, rho_t, s);
+            }
             if (s.phase == FS_UPD) iso_full_upd(E, rho_t, rtol, s);
 #ifdef R2S_STRAG_DIAG
             trips += 1;
+            if (s.phase != FS_IDLE) my_trips += 1;
 #endif
         }
     }
@@ -2366,7 +2405,8 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
     HIP_TRY(hipEventRecord(P->ev_fast[1], st));
     P->fast_timed = true;
     // two persistent wavefronts per SIMD pull entries from the list (counters[14]); those that find none leave at once
-    iso_straggler_kernel<<<(uint32_t)P->n_cu * 8u, 64, 0, st>>>(list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, counters + 14);
+    static const int strag_wpc = getenv("R2S_STRAG_WPC") ? std::min(std::max(atoi(getenv("R2S_STRAG_WPC")), 1), 32) : 8;   // tuning knob (4-16: +-1 %)
+    iso_straggler_kernel<<<(uint32_t)P->n_cu * (uint32_t)strag_wpc, 64, 0, st>>>(list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, counters + 14);
     iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(items, n_items, chunk_off, n_chunks, perm, erec, g, s, rho_t, res, res_xp,
                                                              counters + 13, abort_flag);
     return 0;
