@@ -2380,9 +2380,14 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
 {
     static const int free_env = getenv("R2S_ISO_FREE") ? atoi(getenv("R2S_ISO_FREE")) : 0;   // tuning knob: fewer persistent wavefronts
     const uint32_t resident = (uint32_t)P->n_cu * 4u * wps - (uint32_t)std::min(std::max(free_env, 0), (int)P->n_cu * 4);
-    // chunks per fetch: 4 when every wavefront gets dozens of them (1-8: +-2 %), fewer for a small share of the grid
-    // (one rank of 4 / 8), where coarse groups leave wavefronts unevenly loaded (-15 % at 13 chunks/wave)
-    const uint32_t group = std::min(4u, std::max(1u, n_chunks / (resident * 12u)));
+    // chunks per fetch (tools/rank_share.py, R2S_ISO_GROUP): consecutive chunks mostly belong to one item, so a group costs
+    // one atomic and one item record (dependent loads with every lane of the wavefront waiting) instead of one per chunk.
+    // 8 when a wavefront gets a hundred chunks and more (N = 1: 4.14 -> 4.06 ms against 4), never fewer than 4: one rank
+    // of 8 with single chunks took 0.69 instead of 0.45 ms (the rule of round 2, "1 for a small share", dated from the
+    // kernel without lane refill, where a coarse group left a wavefront 15 % behind the others)
+    static const int group_env = getenv("R2S_ISO_GROUP") ? atoi(getenv("R2S_ISO_GROUP")) : 0;   // tuning knob
+    const uint32_t group = group_env > 0 ? (uint32_t)group_env
+                           : std::max(1u, std::min(std::min(8u, std::max(4u, n_chunks / (resident * 6u))), n_chunks / (resident * 2u)));   // (small grids: two fetches per wavefront at least)
     const uint32_t ngroups = (n_chunks + group - 1) / group;
     const uint32_t cap = iso_straggler_cap(n_store);
     ENSURE(P->strag, sizeof(IsoStraggler) * (size_t)cap);

@@ -40,4 +40,4 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,8").split(",")]:
             el = None
             print("  wave %4d exits at %.0f us; work dry for it at %.0f us with %d lanes busy, last item %d" % (w, tt[w] * 1e-2, dry[w], info[w, 2], info[w, 1]))
     print("world %d: kernel %.0f us by events; wavefront exits after the start (us): first %.0f, 10%% %.0f, 50%% %.0f, "
-          "90%% %.0f, 99%% %.0f, last %.0f" % (world, st["ms_main"] * 1e3, ends[0], q(0.1), q(0.5), q(0.9), q(0.99), ends[-1]))
+          "90%% %.0f, 99%% %.0f, last %.0f" % (world, st["ms_iso_fast"] * 1e3, ends[0], q(0.1), q(0.5), q(0.9), q(0.99), ends[-1]))
