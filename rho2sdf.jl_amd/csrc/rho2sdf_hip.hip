@@ -1304,6 +1304,7 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
     uint64_t my_slot = 0;
     double rtol = 0.0;
     bool exhausted = false;
+    const uint32_t quota = min(64u, max(4u, (n + gridDim.x - 1u) / gridDim.x));
 #ifdef R2S_STRAG_DIAG
     const unsigned long long t0 = wall_clock64();
     unsigned long long trips = 0, pairs = 0;
@@ -1312,7 +1313,13 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
     for (;;) {
         const uint64_t m_done = __ballot(s.phase == FS_DONE);
         const uint64_t m_busy = __ballot(s.phase != FS_DONE && s.phase != FS_IDLE);
-        if (m_busy == 0 || __popcll(m_done) >= R2S_STRAG_REFILL_MIN || (!exhausted && __popcll(__ballot(s.phase == FS_IDLE)) >= R2S_STRAG_REFILL_MIN)) {
+        // (quota: lanes a wavefront keeps busy - all 64 on a long list; a short list, e.g. one rank's share of 8, is spread
+        //  over all wavefronts instead: a trip costs what the phases of its lanes cost, and the kernel lasts as long as
+        //  the trips of its slowest pair)
+        const uint32_t refill_min = min((uint32_t)R2S_STRAG_REFILL_MIN, max(1u, quota / 4u));
+        if (m_busy == 0 || __popcll(m_done) >= R2S_STRAG_REFILL_MIN ||
+            (!exhausted && (uint32_t)__popcll(m_busy) + refill_min <= quota &&
+             (uint32_t)__popcll(__ballot(s.phase == FS_IDLE)) + (quota < 64u ? (uint32_t)__popcll(m_done) : 0u) >= refill_min)) {
             if (s.phase == FS_DONE) {
                 const ElemRec& E = erec[my_el];
                 double N[8], xp[3];
@@ -1339,7 +1346,14 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
 #endif
                 s.phase = FS_IDLE;
             }
-            const uint64_t m_idle = __ballot(s.phase == FS_IDLE);
+            uint64_t m_idle = __ballot(s.phase == FS_IDLE);
+            {   // at most `quota` busy lanes: the lowest idle lanes take the new entries
+                const uint32_t busy_now = 64u - (uint32_t)__popcll(m_idle);
+                uint32_t room = quota > busy_now ? quota - busy_now : 0u;
+                uint64_t keep = 0;
+                for (uint64_t m = m_idle; m && room; m &= m - 1, --room) keep |= m & (~m + 1);
+                m_idle = keep;
+            }
             if (m_idle && !exhausted) {
                 const uint32_t nid = (uint32_t)__popcll(m_idle);
                 uint32_t base = 0;
@@ -1347,7 +1361,7 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base + nid >= n) exhausted = true;
                 const uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
-                if (s.phase == FS_IDLE && i < n) {
+                if (s.phase == FS_IDLE && ((m_idle >> lane) & 1ull) && i < n) {
                     const IsoStraggler e = strag[i];
                     const ElemRec& E = erec[e.el];
                     IsoCoefPad& K = coef[lane];
