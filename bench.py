@@ -102,7 +102,8 @@ def e2e_leg(pkg, X, IEN, rho_n, rho_t, grid, dev_index, sg):
         same = np.array_equal(out.reshape(sg.nz, sg.ny, sg.nx)[::32], sg.volume()[::32].cpu().numpy())
         res[kind]["equals_device_path"] = bool(same)
         del out
-    res["note"] = "r2s_sdf(host pointers): H2D mesh + kernels + D2H of 8 B/voxel; never `value`"
+    res["note"] = ("r2s_sdf(host pointers): H2D mesh + kernels + the field in the caller's array (sparse download: sentinel written by "
+                   "host threads, non-sentinel tiles over PCIe; R2S_HOST_SPARSE=0: dense 8 B/voxel transfer); never `value`")
     # the whole rho2sdf() with the reference's default options (rbf_interp = true, rbf_grid = :same, artifact removal) in
     # ONE call (r2s_rho2sdf): element densities = mean of the nodal field, threshold 0.5, same grid
     rho_e = np.ascontiguousarray(rho_n[IEN - 1].mean(axis=1))

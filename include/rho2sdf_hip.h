@@ -180,7 +180,9 @@ int r2s_rho2sdf(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, c
                 double *sdf_dists_out, float *fine_sdf_out, r2s_run_info *info);
 
 /* Pinned host memory for result arrays (the Julia wrapper `unsafe_wrap`s it): device -> host copies into it run
- * at PCIe rate with no staging.  Any other host pointer works too (staged, multi-threaded). */
+ * at PCIe rate with no staging.  Any other host pointer works too (staged, multi-threaded).  The fused field of
+ * r2s_sdf (one device, >= 4 M voxels) does not cross PCIe whole: host threads write the sentinel -1e10 into the caller's
+ * array while the device works and only the tiles that can differ from it are transferred (R2S_HOST_SPARSE=0: dense). */
 void *r2s_host_alloc(size_t bytes);
 void r2s_host_free(void *p);
 

@@ -41,7 +41,8 @@ double now_ms()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// ---- a small persistent pool that copies one staged chunk into pageable memory on several cores ----
+// ---- a small persistent pool of host threads: staged chunks into pageable memory, sentinel fill and tile scatter of
+// the sparse download ----
 class CopyPool {
   public:
     explicit CopyPool(int n) : n_(n)
@@ -58,18 +59,36 @@ class CopyPool {
         cv_.notify_all();
         for (auto& t : th_) t.join();
     }
+    int size() const { return n_; }
+    // every thread runs fn(id, n); returns at once - wait() before the next start()
+    void start(std::function<void(int, int)> fn)
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        fn_ = std::move(fn);
+        pending_ = n_;
+        ++gen_;
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> l(mu_);
+        done_.wait(l, [this] { return pending_ == 0; });
+    }
     void copy(void* dst, const void* src, size_t bytes)
     {
         if (bytes < (1u << 20) || n_ <= 1) {
             memcpy(dst, src, bytes);
             return;
         }
-        std::unique_lock<std::mutex> l(mu_);
-        dst_ = (char*)dst; src_ = (const char*)src; bytes_ = bytes;
-        pending_ = n_;
-        ++gen_;
-        cv_.notify_all();
-        done_.wait(l, [this] { return pending_ == 0; });
+        char* d = (char*)dst;
+        const char* s = (const char*)src;
+        start([d, s, bytes](int id, int n) {
+            // 4 KiB-aligned slices: every destination page is first touched by exactly one thread
+            const size_t per = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
+            const size_t lo = std::min(bytes, per * (size_t)id), hi = std::min(bytes, per * (size_t)(id + 1));
+            if (hi > lo) memcpy(d + lo, s + lo, hi - lo);
+        });
+        wait();
     }
 
   private:
@@ -81,16 +100,11 @@ class CopyPool {
             cv_.wait(l, [&] { return gen_ != seen; });
             seen = gen_;
             if (stop_) return;
-            char* d = dst_;
-            const char* s = src_;
-            const size_t b = bytes_;
+            std::function<void(int, int)> fn = fn_;
             l.unlock();
-            // 4 KiB-aligned slices: every destination page is first touched by exactly one thread
-            const size_t per = ((b + n_ - 1) / n_ + 4095) & ~(size_t)4095;
-            const size_t lo = std::min(b, per * (size_t)id), hi = std::min(b, per * (size_t)(id + 1));
-            if (hi > lo) memcpy(d + lo, s + lo, hi - lo);
+            fn(id, n_);
             l.lock();
-            if (--pending_ == 0) done_.notify_one();
+            if (--pending_ == 0) done_.notify_all();
         }
     }
     int n_;
@@ -99,9 +113,7 @@ class CopyPool {
     std::condition_variable cv_, done_;
     uint64_t gen_ = 0;
     bool stop_ = false;
-    char* dst_ = nullptr;
-    const char* src_ = nullptr;
-    size_t bytes_ = 0;
+    std::function<void(int, int)> fn_;
     int pending_ = 0;
 };
 
@@ -120,6 +132,9 @@ struct HostSession {
     std::vector<hipEvent_t> evf;   // one per forwarded chunk of the smoothed field (r2s_rho2sdf)
     void* rbf_ws = nullptr;        // buffers of the smoothing stage, kept between r2s_rho2sdf calls
     CopyPool* pool = nullptr;
+    DevBuf pk;                     // packed tiles of the sparse download (device)
+    void* pk_host = nullptr;       // ... and their pinned landing zone
+    size_t pk_host_cap = 0;
 
     int init(int dev)
     {
@@ -148,8 +163,11 @@ struct HostSession {
         (void)hipSetDevice(device);
         if (plan) r2s_plan_destroy(plan);
         plan = nullptr;
-        DevBuf* all[] = {&dX, &dI, &dR, &dE, &out[0], &out[1], &out[2], &out[3], &fine, &raw, &slab};
+        DevBuf* all[] = {&dX, &dI, &dR, &dE, &out[0], &out[1], &out[2], &out[3], &fine, &raw, &slab, &pk};
         for (DevBuf* b : all) b->release();
+        if (pk_host) (void)hipHostFree(pk_host);
+        pk_host = nullptr;
+        pk_host_cap = 0;
         for (int i = 0; i < 2; ++i) {
             if (stage[i]) (void)hipHostFree(stage[i]);
             if (ev[i]) (void)hipEventDestroy(ev[i]);
@@ -226,6 +244,14 @@ struct Segment {   // one contiguous piece of a result: device source -> host de
     size_t bytes;
 };
 
+void ensure_pool(HostSession* S)
+{
+    if (S->pool) return;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    static const int env = getenv("R2S_HOST_THREADS") ? atoi(getenv("R2S_HOST_THREADS")) : 0;
+    S->pool = new CopyPool(env > 0 ? std::min(env, 64) : (int)std::min(16u, std::max(2u, hw / 2)));
+}
+
 // device -> host.  Pinned destination: plain DMA.  Pageable: DMA into the two staging buffers, each staged chunk
 // spread over the pool's threads while the next chunk is in flight.
 int download(HostSession* S, const std::vector<Segment>& segs, bool pinned)
@@ -236,10 +262,7 @@ int download(HostSession* S, const std::vector<Segment>& segs, bool pinned)
         HIP_TRY(hipStreamSynchronize(S->cs));
         return 0;
     }
-    if (!S->pool) {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        S->pool = new CopyPool((int)std::min(8u, std::max(2u, hw / 2)));
-    }
+    ensure_pool(S);
     std::vector<Segment> chunks;
     for (const Segment& g : segs)
         for (size_t o = 0; o < g.bytes; o += STAGE_BYTES)
@@ -329,11 +352,161 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
     prm.zphase = G > 1 ? r : 0;
     prm.n_gpus = 1;
     const double t1 = now_ms();
+    // SPARSE DOWNLOAD of the fused field on one device: nine voxels in ten are the sentinel -1e10, and what the caller's
+    // array costs is the PCIe transfer of all of them (1.07 GB ~ 19 ms for the north-star grid against 4 ms of kernels).
+    // Host threads write the sentinel into the caller's array WHILE the device works (Z slabs of whole tile layers, one
+    // per thread); only the tiles that can differ from it come down - band tiles as 64 doubles, sign-only tiles as one
+    // 64-bit mask (the packing of the multi-GPU stitching) - and every thread scatters the tiles of its own slab.
+    static const bool sparse_env = !(getenv("R2S_HOST_SPARSE") && atoi(getenv("R2S_HOST_SPARSE")) == 0);
+    const bool sparse = sparse_env && G == 1 && c.mode == R2S_OUT_SDF && c.sdf && nvox >= ((size_t)1 << 22);
+    const int nx = (int)c.grid->N[0] + 1, ny = (int)c.grid->N[1] + 1;
+    const int64_t layers_z = (nz + 3) / 4;
+    if (sparse) {
+        ensure_pool(S);
+        double* const out = c.sdf;
+        const int64_t pl = plane;
+        S->pool->start([out, pl, nz, layers_z](int id, int n) {
+            const int64_t l0 = layers_z * id / n, l1 = layers_z * (id + 1) / n;
+            const int64_t k0 = 4 * l0, k1 = std::min<int64_t>(nz, 4 * l1);
+            double* p = out + k0 * pl;
+            const int64_t cnt = (k1 - k0) * pl;
+            for (int64_t i = 0; i < cnt; ++i) p[i] = -1.0e10;
+        });
+    }
+    r2s_stats st_local;
+    r2s_stats* const stp = stats ? stats : &st_local;
     rc = r2s_plan_run_dev(S->plan, S->dX.as<double>(), c.nnp, S->dI.as<int64_t>(), c.nel, S->dR.as<double>(), c.rho_t, c.grid,
                           &prm, 0, nz, c.mode, S->out[0].as<double>(), S->out[1].as<double>(), S->out[2].as<double>(),
-                          S->out[3].as<double>(), nullptr, stats);
-    if (rc) return rc;
+                          S->out[3].as<double>(), nullptr, stp);
+    if (rc) {
+        if (sparse) S->pool->wait();
+        return rc;
+    }
     const double t2 = now_ms();
+    if (sparse) {
+        const int64_t nf = stp->n_active_tiles, nm = stp->n_sign_only_tiles;
+        // [payload nf x 64 doubles | masks nm x u64 | ids nf x u32 | mask ids nm x u32]
+        const size_t off_masks = (size_t)nf * 512, off_ids = off_masks + (size_t)nm * 8, off_mids = off_ids + (((size_t)nf * 4 + 7) & ~(size_t)7);
+        const size_t bytes = off_mids + (((size_t)nm * 4 + 7) & ~(size_t)7);
+        auto bail = [&](int code) { S->pool->wait(); return code; };
+        if (S->pk.ensure(std::max<size_t>(bytes, 8))) return bail(fail(R2S_ERR_NOMEM, "hipMalloc of the packed tiles failed"));
+        if (S->pk_host_cap < bytes) {
+            if (S->pk_host) (void)hipHostFree(S->pk_host);
+            S->pk_host = nullptr;
+            S->pk_host_cap = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc(&S->pk_host, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return bail(fail(R2S_ERR_NOMEM, "hipHostMalloc of the landing zone of the packed tiles failed"));
+            }
+            S->pk_host_cap = want;
+        }
+        char* const dpk = (char*)S->pk.p;
+        int64_t nf2 = 0, nm2 = 0;
+        rc = r2s_plan_pack_tiles2_dev(S->plan, S->out[2].as<double>(), (double*)dpk, (uint32_t*)(dpk + off_ids), nf,
+                                      (uint64_t*)(dpk + off_masks), (uint32_t*)(dpk + off_mids), nm, &nf2, &nm2, S->cs);
+        if (rc) return bail(rc);
+        if (nf2 != nf || nm2 != nm) return bail(fail(R2S_ERR_HIP, "sparse download: tile counts changed between run and pack"));
+        // Every thread scatters the tiles of ITS Z slab (the one it filled: its pages, its cache lines - a tile row is half
+        // a cache line).  R2S_HOST_PIECES > 1 brings the packed tiles down in pieces and scatters piece q while piece
+        // q + 1 is on the bus: measured slower (the tile list is roughly Z-ordered, so a piece keeps a quarter of the
+        // threads busy; with shares of the list instead of slabs the scatter took 9 instead of 4-5 ms) - one piece it is.
+        constexpr int NPIECE_MAX = 8;
+        static const int NPIECE = getenv("R2S_HOST_PIECES") ? std::min(std::max(atoi(getenv("R2S_HOST_PIECES")), 1), NPIECE_MAX) : 1;
+        static const bool mask_skip = !(getenv("R2S_HOST_MASKSKIP") && atoi(getenv("R2S_HOST_MASKSKIP")) == 0);
+        if (S->evf.size() < (size_t)NPIECE) {
+            const size_t have = S->evf.size();
+            S->evf.resize(NPIECE, nullptr);
+            for (size_t q = have; q < (size_t)NPIECE; ++q)
+                if (hipEventCreateWithFlags(&S->evf[q], hipEventDisableTiming) != hipSuccess) return bail(fail(R2S_ERR_HIP, "hipEventCreate failed"));
+        }
+        char* const hpk_w = (char*)S->pk_host;
+        int64_t f0[NPIECE_MAX + 1], m0[NPIECE_MAX + 1];
+        for (int q = 0; q <= NPIECE; ++q) { f0[q] = nf * q / NPIECE; m0[q] = nm * q / NPIECE; }
+        // (ids first: they are small and every piece needs its own)
+        if (bytes > off_ids && hipMemcpyAsync(hpk_w + off_ids, dpk + off_ids, bytes - off_ids, hipMemcpyDeviceToHost, S->cs) != hipSuccess)
+            return bail(fail(R2S_ERR_HIP, "copy of the packed tiles failed"));
+        for (int q = 0; q < NPIECE; ++q) {
+            const size_t pb = (size_t)(f0[q + 1] - f0[q]) * 512, mb = (size_t)(m0[q + 1] - m0[q]) * 8;
+            if (pb && hipMemcpyAsync(hpk_w + (size_t)f0[q] * 512, dpk + (size_t)f0[q] * 512, pb, hipMemcpyDeviceToHost, S->cs) != hipSuccess)
+                return bail(fail(R2S_ERR_HIP, "copy of the packed tiles failed"));
+            if (mb && hipMemcpyAsync(hpk_w + off_masks + (size_t)m0[q] * 8, dpk + off_masks + (size_t)m0[q] * 8, mb, hipMemcpyDeviceToHost, S->cs) != hipSuccess)
+                return bail(fail(R2S_ERR_HIP, "copy of the packed tiles failed"));
+            if (hipEventRecord(S->evf[q], S->cs) != hipSuccess) return bail(fail(R2S_ERR_HIP, "hipEventRecord failed"));
+        }
+        const double t3 = now_ms();
+        S->pool->wait();   // the sentinel is everywhere
+        const double t4 = now_ms();
+        const char* const hpk = (const char*)S->pk_host;
+        double* const out = c.sdf;
+        const int ntx = (nx + 3) / 4, nty = (ny + 3) / 4;
+        const int64_t nzz = nz;
+        double t_ev = 0.0, t_sc = 0.0;
+        for (int q = 0; q < NPIECE; ++q) {
+            const double ta = now_ms();
+            if (hipEventSynchronize(S->evf[q]) != hipSuccess) return fail(R2S_ERR_HIP, "copy of the packed tiles failed");
+            const double tb = now_ms();
+            t_ev += tb - ta;
+            const int64_t fa = f0[q], fb = f0[q + 1], ma = m0[q], mb2 = m0[q + 1];
+            S->pool->start([=](int id, int n) {
+                const double* payload = (const double*)hpk;
+                const uint64_t* masks = (const uint64_t*)(hpk + off_masks);
+                const uint32_t* ids = (const uint32_t*)(hpk + off_ids);
+                const uint32_t* mids = (const uint32_t*)(hpk + off_mids);
+                const int64_t l0 = layers_z * id / n, l1 = layers_z * (id + 1) / n;
+                const uint32_t t_lo = (uint32_t)(l0 * nty * ntx), t_hi = (uint32_t)(l1 * nty * ntx);   // tile ids of the slab
+                for (int64_t w = fa; w < fb; ++w) {
+                    const uint32_t t = ids[w];
+                    if (t < t_lo || t >= t_hi) continue;
+                    const int tx = (int)(t % (uint32_t)ntx), ty = (int)((t / (uint32_t)ntx) % (uint32_t)nty);
+                    const int64_t tz = t / ((uint32_t)ntx * (uint32_t)nty);
+                    const double* src = payload + w * 64;
+                    const int i0 = 4 * tx, wx = std::min(4, nx - i0);
+                    for (int z = 0; z < 4; ++z) {
+                        const int64_t k = 4 * tz + z;
+                        if (k >= nzz) break;
+                        for (int y = 0; y < 4; ++y) {
+                            const int j = 4 * ty + y;
+                            if (j >= ny) break;
+                            double* dst = out + (k * ny + j) * (int64_t)nx + i0;
+                            const double* s4 = src + 16 * z + 4 * y;
+                            for (int x = 0; x < wx; ++x) dst[x] = s4[x];
+                        }
+                    }
+                }
+                for (int64_t w = ma; w < mb2; ++w) {
+                    const uint32_t t = mids[w];
+                    if (t < t_lo || t >= t_hi) continue;
+                    const uint64_t m = masks[w];
+                    if (m == 0 && mask_skip) continue;   // every voxel -1e10: the sentinel is there already
+                    const int tx = (int)(t % (uint32_t)ntx), ty = (int)((t / (uint32_t)ntx) % (uint32_t)nty);
+                    const int64_t tz = t / ((uint32_t)ntx * (uint32_t)nty);
+                    const int i0 = 4 * tx, wx = std::min(4, nx - i0);
+                    for (int z = 0; z < 4; ++z) {
+                        const int64_t k = 4 * tz + z;
+                        if (k >= nzz) break;
+                        for (int y = 0; y < 4; ++y) {
+                            const int j = 4 * ty + y;
+                            if (j >= ny) break;
+                            const unsigned row = (unsigned)((m >> (16 * z + 4 * y)) & 15ull);
+                            if (!row && mask_skip) continue;
+                            double* dst = out + (k * ny + j) * (int64_t)nx + i0;
+                            for (int x = 0; x < wx; ++x) dst[x] = ((row >> x) & 1u) ? 1.0e10 : -1.0e10;
+                        }
+                    }
+                }
+            });
+            S->pool->wait();
+            t_sc += now_ms() - tb;
+        }
+        static const bool timing_env = getenv("R2S_HOST_TIMING") && atoi(getenv("R2S_HOST_TIMING"));
+        if (timing_env)
+            fprintf(stderr, "[r2s host] upload %.2f run %.2f pack+copy (%.1f MB) %.2f wait for the fill %.2f scatter %.2f ms, %d threads\n",
+                    t1 - t0, t2 - t1, bytes / 1e6, t3 - t2, t4 - t3, now_ms() - t4, S->pool->size()),
+            fprintf(stderr, "[r2s host]   waiting for the pieces %.2f, scattering %.2f ms\n", t_ev, t_sc);
+        if (ms3) { ms3[0] = t1 - t0; ms3[1] = t2 - t1; ms3[2] = now_ms() - t2; }
+        return 0;
+    }
     for (int i = 0; i < 4; ++i)
         if (c.mode & bits[i]) {
             std::vector<Segment> segs;

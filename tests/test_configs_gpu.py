@@ -192,6 +192,35 @@ def test_host_entry_points_reuse_their_session(pkg, oracle, pinned):
     assert np.isfinite(pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5)).all()     # sessions come back after a release
 
 
+@pytest.mark.parametrize("tets,npts", [(False, 173), (True, 170)])
+def test_host_pointer_sparse_download(pkg, tets, npts):
+    """r2s_sdf on grids of more than 4 M voxels brings the fused field into the caller's array by the sparse download
+    (host threads write the sentinel while the device works, only the 4x4x4 tiles that can differ from it are
+    transferred and scattered: run_host_device in r2s_host.hip).  Bit-equal to the device path, into pinned and into
+    ordinary memory, on grids whose sizes are no multiples of the tile edge, twice in a row (the second call reuses the
+    landing zone and speculates the sizes)."""
+    import torch
+    from rho2sdf_jl_amd import synthetic
+    X, IEN, rn = (synthetic.tet_mesh if tets else synthetic.hex_mesh)(9)
+    pg = pkg.Grid(X.min(0), X.max(0), synthetic.grid_n_max_for_points(npts), 3)
+    assert pg.ngp > (1 << 22) and any(d % 4 for d in pg.dims)
+    dev = torch.device("cuda:0")
+    dX, dI, dR = (torch.from_numpy(a).to(dev) for a in (X, IEN, rn))
+    plan = pkg.DevicePlan(0)
+    want = torch.empty(pg.ngp, dtype=torch.float64, device=dev)
+    plan.run(dX, dI, dR, 0.5, pg, sdf=want)
+    want = want.cpu().numpy()
+    plan.close()
+    assert (np.abs(want) < 1e9).sum() > 10000 and (want == 1.0e10).any() and (want == -1.0e10).any()
+    mesh = pkg.Mesh(X, IEN)
+    for alloc in (pkg.host_array, np.empty):
+        out = alloc(pg.ngp)
+        for _ in range(2):
+            out[:] = 7.0                                     # nothing of the previous call may survive
+            got = pkg.sdf_fused(mesh, pg, rn, 0.5, out=out)
+            assert got is out and np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("G", [2, 3, 8])
 def test_single_process_fan_out(pkg, oracle, G, monkeypatch):
     """r2s_params.n_gpus / r2s_options.n_gpus: ONE call fans out over G devices (one host thread each, interleaved
