@@ -93,7 +93,7 @@ def e2e_leg(pkg, X, IEN, rho_n, rho_t, grid, dev_index, sg):
     for kind in ("pinned", "pageable"):
         out = pkg.host_array(grid.ngp) if kind == "pinned" else np.empty(grid.ngp)
         times = []
-        for _ in range(4):
+        for _ in range(9):   # (the host side of the sparse download varies from call to call on a shared box: best of 8)
             t0 = time.perf_counter()
             pkg.sdf_fused(mesh, grid, rho_n, rho_t, device=dev_index, out=out)
             times.append(time.perf_counter() - t0)
