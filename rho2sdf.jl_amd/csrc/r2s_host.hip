@@ -244,6 +244,19 @@ struct Segment {   // one contiguous piece of a result: device source -> host de
     size_t bytes;
 };
 
+// n doubles of one value with non-temporal stores: no read-for-ownership of a gigabyte that is about to be overwritten
+// (half the memory traffic of plain stores, and the caches keep what the other threads are working on)
+void fill_stream(double* p, int64_t n, double v)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    int64_t i = 0;
+    while (i < n && ((uintptr_t)(p + i) & 15u)) p[i++] = v;
+    const v2d vv = {v, v};
+    for (; i + 2 <= n; i += 2) __builtin_nontemporal_store(vv, reinterpret_cast<v2d*>(p + i));
+    for (; i < n; ++i) p[i] = v;
+    std::atomic_thread_fence(std::memory_order_seq_cst);   // (sfence: the streamed lines are visible before the scatter)
+}
+
 void ensure_pool(HostSession* S)
 {
     if (S->pool) return;
@@ -368,9 +381,7 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
         S->pool->start([out, pl, nz, layers_z](int id, int n) {
             const int64_t l0 = layers_z * id / n, l1 = layers_z * (id + 1) / n;
             const int64_t k0 = 4 * l0, k1 = std::min<int64_t>(nz, 4 * l1);
-            double* p = out + k0 * pl;
-            const int64_t cnt = (k1 - k0) * pl;
-            for (int64_t i = 0; i < cnt; ++i) p[i] = -1.0e10;
+            fill_stream(out + k0 * pl, (k1 - k0) * pl, -1.0e10);
         });
     }
     r2s_stats st_local;
