@@ -419,11 +419,11 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
         if (rc) return bail(rc);
         if (nf2 != nf || nm2 != nm) return bail(fail(R2S_ERR_HIP, "sparse download: tile counts changed between run and pack"));
         // Every thread scatters the tiles of ITS Z slab (the one it filled: its pages, its cache lines - a tile row is half
-        // a cache line).  R2S_HOST_PIECES > 1 brings the packed tiles down in pieces and scatters piece q while piece
-        // q + 1 is on the bus: measured slower (the tile list is roughly Z-ordered, so a piece keeps a quarter of the
-        // threads busy; with shares of the list instead of slabs the scatter took 9 instead of 4-5 ms) - one piece it is.
-        constexpr int NPIECE_MAX = 8;
-        static const int NPIECE = getenv("R2S_HOST_PIECES") ? std::min(std::max(atoi(getenv("R2S_HOST_PIECES")), 1), NPIECE_MAX) : 1;
+        // a cache line).  Two phases: the masks of the sign-only tiles and all ids come down first (6 MB) and are scattered
+        // while the 97 MB of band tiles are on the bus.  (Band tiles in 2-8 pieces, scattered piece by piece behind the
+        // transfer: slower - the tile list is roughly Z-ordered, so a piece keeps a fraction of the threads busy; shares
+        // of the list instead of slabs: 9 instead of 4-5 ms.)
+        constexpr int NPIECE = 2;
         static const bool mask_skip = !(getenv("R2S_HOST_MASKSKIP") && atoi(getenv("R2S_HOST_MASKSKIP")) == 0);
         if (S->evf.size() < (size_t)NPIECE) {
             const size_t have = S->evf.size();
@@ -432,19 +432,13 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
                 if (hipEventCreateWithFlags(&S->evf[q], hipEventDisableTiming) != hipSuccess) return bail(fail(R2S_ERR_HIP, "hipEventCreate failed"));
         }
         char* const hpk_w = (char*)S->pk_host;
-        int64_t f0[NPIECE_MAX + 1], m0[NPIECE_MAX + 1];
-        for (int q = 0; q <= NPIECE; ++q) { f0[q] = nf * q / NPIECE; m0[q] = nm * q / NPIECE; }
-        // (ids first: they are small and every piece needs its own)
-        if (bytes > off_ids && hipMemcpyAsync(hpk_w + off_ids, dpk + off_ids, bytes - off_ids, hipMemcpyDeviceToHost, S->cs) != hipSuccess)
+        const int64_t f0[NPIECE + 1] = {0, 0, nf}, m0[NPIECE + 1] = {0, nm, nm};   // phase 0: masks, phase 1: band tiles
+        if (bytes > off_masks && hipMemcpyAsync(hpk_w + off_masks, dpk + off_masks, bytes - off_masks, hipMemcpyDeviceToHost, S->cs) != hipSuccess)
             return bail(fail(R2S_ERR_HIP, "copy of the packed tiles failed"));
-        for (int q = 0; q < NPIECE; ++q) {
-            const size_t pb = (size_t)(f0[q + 1] - f0[q]) * 512, mb = (size_t)(m0[q + 1] - m0[q]) * 8;
-            if (pb && hipMemcpyAsync(hpk_w + (size_t)f0[q] * 512, dpk + (size_t)f0[q] * 512, pb, hipMemcpyDeviceToHost, S->cs) != hipSuccess)
-                return bail(fail(R2S_ERR_HIP, "copy of the packed tiles failed"));
-            if (mb && hipMemcpyAsync(hpk_w + off_masks + (size_t)m0[q] * 8, dpk + off_masks + (size_t)m0[q] * 8, mb, hipMemcpyDeviceToHost, S->cs) != hipSuccess)
-                return bail(fail(R2S_ERR_HIP, "copy of the packed tiles failed"));
-            if (hipEventRecord(S->evf[q], S->cs) != hipSuccess) return bail(fail(R2S_ERR_HIP, "hipEventRecord failed"));
-        }
+        if (hipEventRecord(S->evf[0], S->cs) != hipSuccess) return bail(fail(R2S_ERR_HIP, "hipEventRecord failed"));
+        if (off_masks && hipMemcpyAsync(hpk_w, dpk, off_masks, hipMemcpyDeviceToHost, S->cs) != hipSuccess)
+            return bail(fail(R2S_ERR_HIP, "copy of the packed tiles failed"));
+        if (hipEventRecord(S->evf[1], S->cs) != hipSuccess) return bail(fail(R2S_ERR_HIP, "hipEventRecord failed"));
         const double t3 = now_ms();
         S->pool->wait();   // the sentinel is everywhere
         const double t4 = now_ms();
