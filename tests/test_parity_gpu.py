@@ -122,6 +122,33 @@ def test_distorted_hexes_random_density(pkg, oracle, seed, jit):
     _compare(pkg, oracle, X, IEN, rn, 0.5, pg, og, 1.1, f"distorted hexes seed {seed}")
 
 
+@pytest.mark.parametrize("seed", [100, 101, 102])
+def test_random_meshes_and_density_kinds(pkg, oracle, seed):
+    """three cases of tools/fuzz_parity.py (160 of them ran bit-equal, profiles/r03_fuzz_parity.txt): random mesh size,
+    jitter and grid; densities 0/1 (iso-surfaces on element faces, seed 100), nearly flat around the threshold (101),
+    random normal (102) - every voxel of the fused field bit-equal to the oracle"""
+    from rho2sdf_jl_amd import synthetic
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(4, 9))
+    jit = float(rng.uniform(0.1, 0.38))
+    X, IEN, _ = synthetic.hex_mesh(n, jitter=jit, seed=seed)
+    kind = seed % 3
+    if kind == 0:
+        rn = np.clip(rng.normal(0.5, 0.35, len(X)), 0, 1)
+    elif kind == 1:
+        rn = (rng.random(len(X)) < 0.5).astype(float)
+    else:
+        rn = np.clip(0.5 + 0.02 * rng.normal(size=len(X)), 0, 1)
+    nmax = synthetic.grid_n_max_for_points(int(rng.integers(40, 72)))
+    pg = pkg.Grid(X.min(0), X.max(0), nmax, 3)
+    og = oracle.grid_make(X.min(0), X.max(0), nmax, 3)
+    sdf = pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5)
+    odist, _, ost = oracle.eval_distances(X, IEN, rn, 0.5, og, 1.1, want_xp=False)
+    want = odist * oracle.sign_detection(X, IEN, rn, 0.5, og)
+    assert ost["n_iso_solves"] > 100000
+    assert np.array_equal(sdf, want), f"seed {seed}: {int((sdf != want).sum())} voxels differ"
+
+
 def test_straggler_list_overflow(pkg, oracle):
     """R2S_ISO_STRAGGLER_CAP=64 (read once per process: run in a child): the list of handed-over pairs overflows and
     iso_sweep_kernel finds the unsolved result slots - same field"""
