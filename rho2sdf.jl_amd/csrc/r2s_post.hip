@@ -852,6 +852,10 @@ struct RbfLutGeom {
     const float* T;                // [(2R+1)^3][NV][NV][NV], x variant fastest; 0 = entry absent (val <= threshold)
     const double* TA;              // [(2R+1)^3][NVA]^3: the kernel values of the EVALUATION (rbf_apply_kernel's arithmetic); 0 = beyond max_distance
     const double* TA16;            // the same with RBF_NV slots per axis (lattice-to-lattice evaluation with <= 15 variants), or null
+    // the same values in the layout of the row-walk kernels (r2s_rbf_walk.hpp), or null
+    const float* WT;               // matrix entries, RBF_NV slots per axis
+    const double* WA;              // evaluation, wa_nv slots per axis
+    int wa_nv;
 };
 struct RbfLutVals {
     float v[3][7][RBF_NVA];        // the variant values per axis and offset
@@ -1201,10 +1205,32 @@ __global__ void __launch_bounds__(256) rbf_matvec_lds_kernel(RbfLutGeom G, const
     if (t < tend) y[t] = acc;
 }
 
+#include "r2s_rbf_walk.hpp"
+
+// [t0, t1) / [xlo, xhi] as whole planes, or false
+static bool rbf_walk_planes(const RbfLutGeom& LG, int64_t t0, int64_t t1, int64_t xlo, int64_t xhi, RbfWalkArgs* A)
+{
+    const int64_t plane = (int64_t)LG.nx * LG.ny, n = plane * LG.nz;
+    if (t1 < 0) t1 = n;
+    if (xhi < 0) xhi = n - 1;
+    if (t0 % plane || t1 % plane || xlo % plane || (xhi + 1) % plane) return false;
+    memset(A, 0, sizeof *A);
+    A->nx = LG.nx; A->ny = LG.ny; A->nz = LG.nz;
+    A->vx = LG.vx; A->vy = LG.vy; A->vz = LG.vz;
+    A->k_begin = (int)(t0 / plane); A->k_end = (int)(t1 / plane);
+    A->xk_lo = (int)(xlo / plane); A->xk_hi = (int)((xhi + 1) / plane) - 1;
+    return true;
+}
 static void launch_rbf_matvec_lut(const RbfLutGeom& LG, unsigned nb, hipStream_t st, const float* x, float* y, int64_t t0 = 0,
-                                  int64_t t1 = -1, int64_t xlo = 0, int64_t xhi = -1)
+                                  int64_t t1 = -1, int64_t xlo = 0, int64_t xhi = -1, double* dot_partial = nullptr)
 {
     const char* mv_env = getenv("R2S_RBF_MATVEC");
+    RbfWalkArgs WAr;
+    if (!mv_env && LG.WT && rbf_walk_supported(LG.R, LG.tap_d2, LG.nx, LG.ny) && rbf_walk_planes(LG, t0, t1, xlo, xhi, &WAr)) {
+        WAr.T = LG.WT; WAr.x = x; WAr.y = y; WAr.dot_partial = dot_partial;
+        rbf_walk_launch(0, RBF_NV, WAr, st);
+        return;
+    }
     const bool global_only = mv_env && !strcmp(mv_env, "lutg");   // table entries gathered from L1/L2 (the tests compare)
     if (LG.R == 2 && LG.tap_d2 == 7 && !global_only) rbf_matvec_lds_kernel<2, 7><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);   // threshold 1e-3 (default)
     else if (LG.R == 2 && LG.tap_d2 == 7) rbf_matvec_lut_kernel<2, 7><<<nb, 256, 0, st>>>(LG, x, y, t0, t1, xlo, xhi);
@@ -1412,8 +1438,15 @@ static bool launch_rbf_apply_lut(const RbfGeom& G, const RbfLutGeom& LG, const S
                                  const float* w, const float* tx, const float* ty, const float* tz, const Stencil* d_stencil, float add,
                                  float* out, int64_t t0 = 0, int64_t t1 = -1, int64_t xlo = 0, int64_t xhi = -1)
 {
-    if (!LG.TA || !rbf_stencil_is_canonical(host_stencil, LG.R, LG.tap_d2)) return false;
+    if (!rbf_stencil_is_canonical(host_stencil, LG.R, LG.tap_d2)) return false;
     const char* ap_env = getenv("R2S_RBF_APPLY");
+    RbfWalkArgs WAr;
+    if (!ap_env && LG.WA && rbf_walk_supported(LG.R, LG.tap_d2, LG.nx, LG.ny) && rbf_walk_planes(LG, t0, t1, xlo, xhi, &WAr)) {
+        WAr.T = LG.WA; WAr.x = w; WAr.y = out; WAr.add = add;
+        rbf_walk_launch(1, LG.wa_nv, WAr, st);
+        return true;
+    }
+    if (!LG.TA) return false;
     const bool gathered = ap_env && !strcmp(ap_env, "lutg");   // table entries gathered from L1 / L2 (the tests compare)
     if (LG.R == 2 && LG.tap_d2 == 7 && LG.TA16 && LG.nx >= 256 && tx == G.cx && ty == G.cy && tz == G.cz && !gathered)   // (nx >= 256: a workgroup spans <= 2 rows)
         rbf_apply_lds_kernel<2, 7><<<nb, 256, 0, st>>>(G, LG, w, d_stencil, add, out, t0, t1, xlo, xhi);
@@ -1617,7 +1650,7 @@ static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
 }
 
 struct RbfWork {   // the device buffers of one rbf_smooth_host call
-    DevBuf b[30];
+    DevBuf b[33];
     VolumeWork vw;
     void release()
     {
@@ -1646,7 +1679,8 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     DevBuf &d_sdf = W.b[0], &d_f = W.b[1], &d_w = W.b[2], &d_lsf = W.b[3], &d_fine = W.b[4], &d_cx = W.b[5], &d_cy = W.b[6], &d_cz = W.b[7],
            &d_tx = W.b[8], &d_ty = W.b[9], &d_tz = W.b[10], &d_st = W.b[11], &d_cnt = W.b[12], &d_r = W.b[13], &d_u = W.b[14], &d_q = W.b[15],
            &d_part = W.b[16], &d_sum = W.b[17], &d_lut = W.b[18], &d_luta = W.b[19], &d_vx = W.b[20], &d_vy = W.b[21], &d_vz = W.b[22],
-           &d_lutf = W.b[23], &d_fvx = W.b[24], &d_fvy = W.b[25], &d_fvz = W.b[26], &d_lv = W.b[27], &d_lvf = W.b[28], &d_luta16 = W.b[29];
+           &d_lutf = W.b[23], &d_fvx = W.b[24], &d_fvy = W.b[25], &d_fvz = W.b[26], &d_lv = W.b[27], &d_lvf = W.b[28], &d_luta16 = W.b[29],
+           &d_wt = W.b[30], &d_wa = W.b[31], &d_waf = W.b[32];
     VolumeWork& vw = W.vw;
     auto cleanup = [&]() {
         if (!ws) W.release();
@@ -1739,25 +1773,36 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     memset(&LG, 0, sizeof LG);
     memset(&LGF, 0, sizeof LGF);
     const bool fine_one_to_one = smooth == 1 && fx == nx && fy == ny && fz == nz;
+    const bool walk_ok = rbf_walk_supported(G.tap_r, G.tap_d2, nx, ny);
     if (G.tap_r >= 1 && G.tap_r <= 3 && want_ap_lut && fine_one_to_one) {
         RbfLutVals LV;
         memset(&LV, 0, sizeof LV);
         LV.R = G.tap_r; LV.sigma = G.sigma; LV.thr = G.thr; LV.max_distance = G.max_distance;
         std::vector<uint8_t> ix, iy, iz;
-        if (rbf_lut_axis(tx, cx, G.tap_r, LV.v[0], ix) && rbf_lut_axis(ty, cy, G.tap_r, LV.v[1], iy) && rbf_lut_axis(tz, cz, G.tap_r, LV.v[2], iz)) {
+        const int f0 = rbf_lut_axis(tx, cx, G.tap_r, LV.v[0], ix), f1 = rbf_lut_axis(ty, cy, G.tap_r, LV.v[1], iy),
+                  f2 = rbf_lut_axis(tz, cz, G.tap_r, LV.v[2], iz);
+        if (f0 && f1 && f2) {
             const int W = 2 * G.tap_r + 1;
-            const size_t nT = (size_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
             ENSURE_C(d_fvx, ix.size()); ENSURE_C(d_fvy, iy.size()); ENSURE_C(d_fvz, iz.size());
             HIP_C(hipMemcpy(d_fvx.p, ix.data(), ix.size(), hipMemcpyHostToDevice));
             HIP_C(hipMemcpy(d_fvy.p, iy.data(), iy.size(), hipMemcpyHostToDevice));
             HIP_C(hipMemcpy(d_fvz.p, iz.data(), iz.size(), hipMemcpyHostToDevice));
             LGF.nx = nx; LGF.ny = ny; LGF.nz = nz; LGF.R = G.tap_r; LGF.tap_d2 = G.tap_d2;
             LGF.vx = d_fvx.as<uint8_t>(); LGF.vy = d_fvy.as<uint8_t>(); LGF.vz = d_fvz.as<uint8_t>();
-            ENSURE_C(d_lutf, sizeof(double) * nT);
             ENSURE_C(d_lvf, sizeof LV);
             HIP_C(hipMemcpy(d_lvf.p, &LV, sizeof LV, hipMemcpyHostToDevice));
-            rbf_lut_build_apply_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(d_lvf.as<RbfLutVals>(), d_lutf.as<double>());
-            LGF.TA = d_lutf.as<double>();
+            if (walk_ok && !ap_env) {   // the table of the row-walk kernel (r2s_rbf_walk.hpp)
+                const int nv = std::max(f0, std::max(f1, f2)) <= RBF_NV - 1 ? RBF_NV : RBF_NVA;
+                const size_t nT = (size_t)W * W * W * nv * nv * nv;
+                ENSURE_C(d_waf, sizeof(double) * nT);
+                rbf_walk_table_kernel<1><<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(d_lvf.as<RbfLutVals>(), d_waf.p, nv);
+                LGF.WA = d_waf.as<double>(); LGF.wa_nv = nv;
+            } else {
+                const size_t nT = (size_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
+                ENSURE_C(d_lutf, sizeof(double) * nT);
+                rbf_lut_build_apply_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(d_lvf.as<RbfLutVals>(), d_lutf.as<double>());
+                LGF.TA = d_lutf.as<double>();
+            }
         }
     }
     if (G.tap_r >= 1 && G.tap_r <= 3 && (want_mv_lut || want_ap_lut)) {
@@ -1779,12 +1824,22 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             LG.vx = d_vx.as<uint8_t>(); LG.vy = d_vy.as<uint8_t>(); LG.vz = d_vz.as<uint8_t>();
             ENSURE_C(d_lv, sizeof LV);
             HIP_C(hipMemcpy(d_lv.p, &LV, sizeof LV, hipMemcpyHostToDevice));
-            if (want_mv_lut && mv_fits) {
+            if (want_mv_lut && mv_fits && walk_ok && !mv_env) {
+                ENSURE_C(d_wt, sizeof(float) * nT);
+                rbf_walk_table_kernel<0><<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(d_lv.as<RbfLutVals>(), d_wt.p, RBF_NV);
+                LG.WT = d_wt.as<float>();
+            } else if (want_mv_lut && mv_fits) {
                 ENSURE_C(d_lut, sizeof(float) * nT);
                 rbf_lut_build_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, st>>>(d_lv.as<RbfLutVals>(), d_lut.as<float>());
                 LG.T = d_lut.as<float>();
             }
-            if (want_ap_lut) {
+            if (want_ap_lut && walk_ok && !ap_env) {
+                const int nv = mv_fits ? RBF_NV : RBF_NVA;
+                const size_t nW = (size_t)W * W * W * nv * nv * nv;
+                ENSURE_C(d_wa, sizeof(double) * nW);
+                rbf_walk_table_kernel<1><<<(unsigned)((nW + 255) / 256), 256, 0, st>>>(d_lv.as<RbfLutVals>(), d_wa.p, nv);
+                LG.WA = d_wa.as<double>(); LG.wa_nv = nv;
+            } else if (want_ap_lut) {
                 const size_t nTA = (size_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
                 ENSURE_C(d_luta, sizeof(double) * nTA);
                 rbf_lut_build_apply_kernel<<<(unsigned)((nTA + 255) / 256), 256, 0, st>>>(d_lv.as<RbfLutVals>(), d_luta.as<double>());
@@ -1837,7 +1892,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
                     taps.n++;
                 }
         // first choice: the table of distinct entries; then the materialised matrix; then on the fly
-        const bool use_lut = LG.T != nullptr;
+        const bool use_lut = LG.T != nullptr || LG.WT != nullptr;
         bool use_k = false;
         std::unique_lock<std::mutex> kv_lock(g_rbf_kv_mutex, std::defer_lock);
         if (!use_lut && !(mv_env && mv_env[0] == 'f')) kv_lock.try_lock();   // busy: fall back to on-the-fly
@@ -2304,12 +2359,17 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
     memset(&LVF, 0, sizeof LVF);
     std::vector<uint8_t> fix, fiy, fiz;
     bool lutf_axes = false;
+    int lutf_most = 0;
     if (want_ap_lut && fine_one_to_one && G0.tap_r >= 1 && G0.tap_r <= 3) {
         LVF.R = G0.tap_r; LVF.sigma = G0.sigma; LVF.thr = G0.thr; LVF.max_distance = G0.max_distance;
-        lutf_axes = rbf_lut_axis(tx, cx, G0.tap_r, LVF.v[0], fix) && rbf_lut_axis(ty, cy, G0.tap_r, LVF.v[1], fiy) &&
-                    rbf_lut_axis(tz, cz, G0.tap_r, LVF.v[2], fiz);
+        const int f0 = rbf_lut_axis(tx, cx, G0.tap_r, LVF.v[0], fix), f1 = rbf_lut_axis(ty, cy, G0.tap_r, LVF.v[1], fiy),
+                  f2 = rbf_lut_axis(tz, cz, G0.tap_r, LVF.v[2], fiz);
+        lutf_axes = f0 && f1 && f2;
+        lutf_most = std::max(f0, std::max(f1, f2));
     }
-    SlabBufs blutf(S), bfvx(S), bfvy(S), bfvz(S), blv(S), blvf(S), bsegmn(S), bsegmx(S), bluta16(S);
+    const bool walk_ok = rbf_walk_supported(G0.tap_r, G0.tap_d2, nx, ny);
+    const char* mv_env = getenv("R2S_RBF_MATVEC");
+    SlabBufs blutf(S), bfvx(S), bfvy(S), bfvz(S), blv(S), blvf(S), bsegmn(S), bsegmx(S), bluta16(S), bwt(S), bwa(S), bwaf(S);
     SlabBufs bf(S), bw(S), br(S), bu(S), bq(S), blsf(S), bfine(S), bcx(S), bcy(S), bcz(S), btx(S), bty(S), btz(S), bst(S), bcnt(S),
         bpart(S), blut(S), bluta(S), bvx(S), bvy(S), bvz(S), brows(S);
     std::vector<RbfGeom> Gq(G, G0);
@@ -2371,12 +2431,22 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
             SLAB_TRY(up(blv, &LV, sizeof LV));
             LG[q].nx = nx; LG[q].ny = ny; LG[q].nz = nz; LG[q].R = G0.tap_r; LG[q].tap_d2 = G0.tap_d2;
             LG[q].vx = bvx.at<uint8_t>(q); LG[q].vy = bvy.at<uint8_t>(q); LG[q].vz = bvz.at<uint8_t>(q);
-            if (use_lut) {
+            if (use_lut && walk_ok && !mv_env) {
+                SLAB_TRY(bwt.ensure(q, sizeof(float) * nT));
+                rbf_walk_table_kernel<0><<<(unsigned)((nT + 255) / 256), 256, 0, d.stream>>>(blv.at<RbfLutVals>(q), bwt.b[q].p, RBF_NV);
+                LG[q].WT = bwt.at<float>(q);
+            } else if (use_lut) {
                 SLAB_TRY(blut.ensure(q, sizeof(float) * nT));
                 rbf_lut_build_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, d.stream>>>(blv.at<RbfLutVals>(q), blut.at<float>(q));
                 LG[q].T = blut.at<float>(q);
             }
-            if (want_ap_lut) {
+            if (want_ap_lut && walk_ok && !ap_env) {
+                const int nv = mv_fits ? RBF_NV : RBF_NVA;
+                const size_t nW = (size_t)W * W * W * nv * nv * nv;
+                SLAB_TRY(bwa.ensure(q, sizeof(double) * nW));
+                rbf_walk_table_kernel<1><<<(unsigned)((nW + 255) / 256), 256, 0, d.stream>>>(blv.at<RbfLutVals>(q), bwa.b[q].p, nv);
+                LG[q].WA = bwa.at<double>(q); LG[q].wa_nv = nv;
+            } else if (want_ap_lut) {
                 const size_t nTA = (size_t)W * W * W * RBF_NVA * RBF_NVA * RBF_NVA;
                 SLAB_TRY(bluta.ensure(q, sizeof(double) * nTA));
                 rbf_lut_build_apply_kernel<<<(unsigned)((nTA + 255) / 256), 256, 0, d.stream>>>(blv.at<RbfLutVals>(q), bluta.at<double>(q));
@@ -2395,10 +2465,18 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
             SLAB_TRY(up(bfvx, fix.data(), fix.size())); SLAB_TRY(up(bfvy, fiy.data(), fiy.size())); SLAB_TRY(up(bfvz, fiz.data(), fiz.size()));
             LGF[q].nx = nx; LGF[q].ny = ny; LGF[q].nz = nz; LGF[q].R = G0.tap_r; LGF[q].tap_d2 = G0.tap_d2;
             LGF[q].vx = bfvx.at<uint8_t>(q); LGF[q].vy = bfvy.at<uint8_t>(q); LGF[q].vz = bfvz.at<uint8_t>(q);
-            SLAB_TRY(blutf.ensure(q, sizeof(double) * nT));
             SLAB_TRY(up(blvf, &LVF, sizeof LVF));
-            rbf_lut_build_apply_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, d.stream>>>(blvf.at<RbfLutVals>(q), blutf.at<double>(q));
-            LGF[q].TA = blutf.at<double>(q);
+            if (walk_ok && !ap_env) {
+                const int nv = lutf_most <= RBF_NV - 1 ? RBF_NV : RBF_NVA;
+                const size_t nW = (size_t)W * W * W * nv * nv * nv;
+                SLAB_TRY(bwaf.ensure(q, sizeof(double) * nW));
+                rbf_walk_table_kernel<1><<<(unsigned)((nW + 255) / 256), 256, 0, d.stream>>>(blvf.at<RbfLutVals>(q), bwaf.b[q].p, nv);
+                LGF[q].WA = bwaf.at<double>(q); LGF[q].wa_nv = nv;
+            } else {
+                SLAB_TRY(blutf.ensure(q, sizeof(double) * nT));
+                rbf_lut_build_apply_kernel<<<(unsigned)((nT + 255) / 256), 256, 0, d.stream>>>(blvf.at<RbfLutVals>(q), blutf.at<double>(q));
+                LGF[q].TA = blutf.at<double>(q);
+            }
         }
         // process_vector pass 1 on the OWNED planes (every plane counts once for the maximum)
         SLAB_HIP(hipMemsetAsync(bcnt.b[q].p, 0, 64, d.stream));

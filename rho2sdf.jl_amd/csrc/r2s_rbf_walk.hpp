@@ -1,0 +1,437 @@
+// RBF stencil products as a row walk (included by r2s_post.hip after RbfLutVals / exp_neg_fast / rbf_tap_order).
+//
+//   MODE 0:  y = K x            (compute_sparse_kernel_matrix + the CG's product, RBFs4Smoothing.jl:142-176, 191-202)
+//   MODE 1:  out = sum_j w_j exp(-(dist/sigma)^2) + add   with one target per lattice point
+//                                (rbf_interpolation_kdtree, RBFs4Smoothing.jl:219-248)
+//
+// Both are (2R+1)^3-point stencils whose coefficients depend on the lattice position only through the three Float32
+// coordinate differences (rbf_lut_axis: a handful of distinct values - "variants" - per axis and offset).  The
+// coefficient of tap (dk, dj, di) at lattice point (i, j, k) is  T[dk][c(k,dk)][dj][b(j,dj)][di][a(i,di)].
+//
+// Data flow of one workgroup (NW wavefronts = 64 NW consecutive i, one plane k, L consecutive rows j):
+//   * x: every lane keeps the (2R+1) x (2R+1) rows around its output row in REGISTERS (each with its 2R+1 shifted
+//     copies) and walks along j: a step loads one new row per plane (2R+1 rows instead of (2R+1)^2), issued one step
+//     ahead.  The loads are buffer loads - descriptor and row offset in SGPRs, the lane part a precomputed 32-bit
+//     offset - so the VALU carries the products only.
+//   * coefficients: per step the workgroup stages the rows T[dk][c][dj][b][:][:] of its (j, k) in LDS (contiguous
+//     (2R+1) x NV chunks, double-buffered, fetched one step ahead, ONE barrier per step); a lane picks its entry with
+//     one LDS read per tap (address = its x variant + an immediate).
+//   * absent neighbours (outside the lattice, or beyond the kernel support) have coefficient 0 (variant slot NV-1 is
+//     all zero, and T holds 0 where the reference's threshold test fails) and a clamped address: adding 0 * (finite
+//     value) leaves the Float32 / Float64 partial sums unchanged, so the sums equal the reference's, which skips
+//     those neighbours, bit for bit - with no predicates in the loop.
+//   * order of the additions: MODE 0 ascending (dk, dj, di) = ascending column index of the sparse matrix; MODE 1 by
+//     lattice distance^2, then (dz, dy, dx) (build_stencil), Float64 product and sum rounded to Float32 per neighbour.
+#pragma once
+
+#include <type_traits>
+
+#define RBF_WALK_LMAX 32
+
+struct RbfWalkArgs {
+    int nx, ny, nz;
+    const uint8_t *vx, *vy, *vz;   // [2R+1][n]: variant id of (offset, index), 255 = no such neighbour
+    const void* T;                 // [dk][c][dj][b][di][a]: float (MODE 0) or double (MODE 1), NV slots per variant axis
+    const float* x;                // input vector, addressed as the whole lattice
+    float* y;                      // output, addressed as the whole lattice
+    int k_begin, k_end;            // planes to produce
+    int xk_lo, xk_hi;              // planes of x that exist on this device (inclusive)
+    int L, nchunk, nxt;            // rows per walk, walks per plane, workgroups per row
+    float add;                     // MODE 1: constant added to every output
+    double* dot_partial;           // MODE 0: sum of x*y per workgroup [(k - k_begin) * nchunk * nxt + ...], or null
+};
+
+template <int R>
+struct RbfWalkRows {
+    int n;
+    signed char dk[(2 * R + 1) * (2 * R + 1)], dj[(2 * R + 1) * (2 * R + 1)], dmax[(2 * R + 1) * (2 * R + 1)];
+    signed char index[2 * R + 1][2 * R + 1];
+};
+template <int R, int D2>
+constexpr RbfWalkRows<R> rbf_walk_rows()
+{
+    RbfWalkRows<R> r{};
+    r.n = 0;
+    for (int dk = -R; dk <= R; ++dk)
+        for (int dj = -R; dj <= R; ++dj) {
+            r.index[dk + R][dj + R] = -1;
+            if (dk * dk + dj * dj > D2) continue;
+            int m = 0;
+            while (m + 1 <= R && dk * dk + dj * dj + (m + 1) * (m + 1) <= D2) ++m;
+            r.index[dk + R][dj + R] = (signed char)r.n;
+            r.dk[r.n] = (signed char)(dk + R); r.dj[r.n] = (signed char)(dj + R); r.dmax[r.n] = (signed char)m;
+            r.n++;
+        }
+    return r;
+}
+
+// the coefficient tables in the layout of the walk: a = fastest
+template <int MODE>
+__global__ void __launch_bounds__(256) rbf_walk_table_kernel(const RbfLutVals* __restrict__ Vp, void* __restrict__ Tout, int nv)
+{
+    const RbfLutVals& V = *Vp;
+    __shared__ double etab[64];
+    if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_neg_64[threadIdx.x];
+    __syncthreads();
+    const int W = 2 * V.R + 1;
+    const int64_t n = (int64_t)W * W * W * nv * nv * nv;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t t0 = t;
+    const int a = (int)(t % nv); t /= nv;
+    const int di = (int)(t % W); t /= W;
+    const int b = (int)(t % nv); t /= nv;
+    const int dj = (int)(t % W); t /= W;
+    const int c = (int)(t % nv); t /= nv;
+    const int dk = (int)t;
+    const float dx = V.v[0][di][a], dy = V.v[1][dj][b], dz = V.v[2][dk][c];
+    const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (MODE == 0) {   // rbf_matvec_kernel's arithmetic (unused variant slots hold NaN: comparison false -> 0)
+        const double u = (double)r / V.sigma;
+        const double val = exp(-(u * u));
+        ((float*)Tout)[t0] = (val > V.thr) ? (float)val : 0.0f;
+    } else {           // rbf_apply_point's arithmetic
+        const double inv_sigma = 1.0 / V.sigma;
+        double val = 0.0;
+        if (r <= V.max_distance) {
+            const double u = (double)r * inv_sigma;
+            val = exp_neg_fast(u * u, etab);
+        }
+        ((double*)Tout)[t0] = val;
+    }
+}
+
+typedef unsigned int rbf_u32x4 __attribute__((ext_vector_type(4)));
+typedef float rbf_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int R, int D2, int MODE, int NV, int NW>
+struct RbfWalk {
+    static constexpr int W = 2 * R + 1;
+    typedef typename std::conditional<MODE == 0, float, double>::type TE;
+    static constexpr int ES = (int)sizeof(TE);
+    static constexpr int NT = NW * 64;
+    static constexpr int ROWLEN = W * NV;
+    static constexpr int NROW = rbf_walk_rows<R, D2>().n;
+    static constexpr int CPR = ROWLEN * ES / 16;          // 16-byte chunks per row of T
+    static constexpr int NCHUNK = NROW * CPR;
+    static constexpr int NROUND = (NCHUNK + NT - 1) / NT;
+    // LDS image of one step's coefficients.
+    //   MODE 1: as in T, [row][di][a] doubles (one 8-byte read per neighbour, in the neighbours' order).
+    //   MODE 0: transposed, [di][a][row] floats - the rows in the order of the row sum - so that ONE 16-byte read gives a
+    //           lane its coefficients of four consecutive rows (26 reads per output instead of 81; the LDS pipe, 8
+    //           wavefronts per CU reading their own coefficients, is what bounds this kernel).  RS floats per (di, a): 28 =
+    //           4 x odd puts the 16 variants of a 16-lane read group on disjoint banks; BS floats per di: RS NV + 4 spreads
+    //           the staging stores.
+    static constexpr int NQ = (NROW + 3) / 4;             // 16-byte groups of rows
+    static constexpr int RS = 4 * NQ + 4 + ((NQ + 1) % 2 ? 0 : 4);
+    static constexpr int BS = RS * NV + 4;
+    static constexpr int BUFB = MODE == 0 ? W * BS * 4 : NROW * ROWLEN * ES;
+
+    struct State {
+        float xw[W][W][W];        // [plane][ring slot][shift]
+        uint32_t aoff[W];         // byte offset of the lane's x variant inside the LDS image, per di
+        uint32_t xoff[W];         // byte offset of the lane's (clamped) column i + di inside a row of x
+        int kp[W];                // plane k + dk, clamped into the planes that exist, relative to the descriptor's base
+        uint32_t gpre[NROUND];    // chunk (16 bytes) offset of the lane's staging chunks in T without the row variant b
+        uint32_t sbad[NROUND];    // ... where their b is found in sB
+        uint32_t sdst[NROUND];    // ... and where they go in the LDS image
+        rbf_u32x4 tv[NROUND];     // staged chunks in flight
+        __amdgpu_buffer_rsrc_t rx;
+    };
+
+    __device__ static __forceinline__ void load_row(const RbfWalkArgs& A, State& S, int p, int slot, int jrow)
+    {
+        const int jj = jrow < 0 ? 0 : (jrow >= A.ny ? A.ny - 1 : jrow);
+        const int soff = (S.kp[p] * A.ny + jj) * A.nx * 4;
+#pragma unroll
+        for (int d = 0; d < W; ++d)
+            S.xw[p][slot][d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rx, (int)S.xoff[d], soff, 0));
+    }
+    __device__ static __forceinline__ void table_fetch(const RbfWalkArgs& A, State& S, const uint8_t* sB, int sn)
+    {
+        const rbf_u32x4* __restrict__ T = (const rbf_u32x4*)A.T;
+#pragma unroll
+        for (int r = 0; r < NROUND; ++r) {
+            const uint32_t b = sB[S.sbad[r] + (uint32_t)sn];
+            S.tv[r] = T[S.gpre[r] + b * (uint32_t)CPR];
+        }
+    }
+    __device__ static __forceinline__ void table_store(State& S, char* sT, int buf, uint32_t tid)
+    {
+#pragma unroll
+        for (int r = 0; r < NROUND; ++r) {
+            const uint32_t e = tid + (uint32_t)(r * NT);
+            if ((r + 1) * NT <= NCHUNK || e < (uint32_t)NCHUNK) {
+                char* dst = sT + buf * BUFB + S.sdst[r];
+                if constexpr (MODE == 0) {   // four x variants of one (row, di): RS floats apart
+                    *(uint32_t*)(dst) = S.tv[r].x;
+                    *(uint32_t*)(dst + RS * 4) = S.tv[r].y;
+                    *(uint32_t*)(dst + 2 * RS * 4) = S.tv[r].z;
+                    *(uint32_t*)(dst + 3 * RS * 4) = S.tv[r].w;
+                } else {
+                    *(rbf_u32x4*)dst = S.tv[r];
+                }
+            }
+        }
+    }
+    // where chunk e of a step's coefficients (16 bytes of T: row e / CPR, then di, then a) goes in the LDS image
+    __device__ static __forceinline__ uint32_t chunk_dst(uint32_t e)
+    {
+        if constexpr (MODE == 0) {
+            const uint32_t row = e / (uint32_t)CPR, within = e - row * (uint32_t)CPR;   // CPR = W NV / 4
+            const uint32_t di = within / (uint32_t)(NV / 4), a4 = within - di * (uint32_t)(NV / 4);
+            return ((di * (uint32_t)BS + 4u * a4 * (uint32_t)RS) + row) * 4u;
+        } else {
+            return e * 16u;
+        }
+    }
+    __device__ static __forceinline__ uint32_t lane_aoff(uint32_t di, uint32_t a)
+    {
+        return MODE == 0 ? (di * (uint32_t)BS + a * (uint32_t)RS) * 4u : a * (uint32_t)ES;
+    }
+
+    template <int P>
+    __device__ static __forceinline__ float step(const RbfWalkArgs& A, State& S, const char* sT, int s, int j0)
+    {
+        constexpr RbfWalkRows<R> RL = rbf_walk_rows<R, D2>();
+        const int jnew = j0 + s + R + 1;   // the row that enters the window for the NEXT step (into the slot of dj = -R)
+        uint32_t ab[W];
+#pragma unroll
+        for (int d = 0; d < W; ++d) ab[d] = S.aoff[d] + (uint32_t)((s & 1) * BUFB);
+        float acc = 0.0f;
+        if constexpr (MODE == 0) {
+            // software pipeline over groups of four rows: the reads of group g + 1 are issued, then the products of
+            // group g run (the compiler's own order - every read, one wait, the serial sum - leaves the LDS pipe and the
+            // VALU idle in turn, in all wavefronts of the workgroup at once)
+            rbf_f32x4 wq[2][W];
+            auto read_group = [&](int g, rbf_f32x4 (&dst)[W]) {
+#pragma unroll
+                for (int di = 0; di < W; ++di) {
+                    bool used = false;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        if (4 * g + rr < NROW && RL.dmax[4 * g + rr] >= (di > R ? di - R : R - di)) used = true;
+                    if (used) dst[di] = *(const rbf_f32x4*)(sT + ab[di] + g * 16);
+                }
+            };
+            read_group(0, wq[0]);
+#pragma unroll
+            for (int g = 0; g < NQ; ++g) {
+                if (g + 1 < NQ) read_group(g + 1, wq[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = 4 * g + rr;
+                    if (row >= NROW) continue;
+                    const int p = RL.dk[row], dj = RL.dj[row], m = RL.dmax[row];
+#pragma unroll
+                    for (int di = R - m; di <= R + m; ++di) acc += wq[g & 1][di][rr] * S.xw[p][(P + dj) % W][di];
+                    // the plane's last row has been used: the slot of its dj = -R row takes the row of the next step
+                    if (row + 1 == NROW || RL.dk[row + 1] != p) load_row(A, S, p, P % W, jnew);
+                }
+                asm volatile("" : "+v"(acc));   // (pins the products of the group between the two barriers)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            constexpr RbfTapOrder<R> TO = rbf_tap_order<R, D2>();
+            constexpr int NB = 9;   // neighbours per batch
+            double eb[2][NB];
+            auto read_batch = [&](int q0, double (&dst)[NB]) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int q = q0 + u;
+                    if (q >= TO.n) continue;
+                    const int row = RL.index[TO.dk[q]][TO.dj[q]];
+                    dst[u] = ((const double*)(sT + ab[TO.di[q]]))[(row * W + TO.di[q]) * NV];
+                }
+            };
+            read_batch(0, eb[0]);
+#pragma unroll
+            for (int q0 = 0; q0 < TO.n; q0 += NB) {
+                if (q0 + NB < TO.n) read_batch(q0 + NB, eb[(q0 / NB + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int q = q0 + u;
+                    if (q >= TO.n) continue;
+                    const int p = TO.dk[q], dj = TO.dj[q], di = TO.di[q];
+                    // (the conversion as an opaque instruction: left to the compiler, the Float64 images of the window's
+                    //  values are kept across the steps of the unrolled ring - twice the registers of the window)
+                    double wd;
+                    asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(wd) : "v"(S.xw[p][(P + dj) % W][di]));
+                    acc = (float)((double)acc + wd * eb[(q0 / NB) & 1][u]);
+                }
+                asm volatile("" : "+v"(acc));   // (pins the sums of the batch between the two barriers)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int p = 0; p < W; ++p) load_row(A, S, p, P % W, jnew);
+        }
+        return acc;
+    }
+};
+
+template <int R, int D2, int MODE, int NV, int NW>
+__global__ void __launch_bounds__(NW * 64) rbf_walk_kernel(const RbfWalkArgs A)
+{
+    typedef RbfWalk<R, D2, MODE, NV, NW> K;
+    typedef typename K::TE TE;
+    constexpr int W = K::W, NT = K::NT, NROUND = K::NROUND;
+    constexpr RbfWalkRows<R> RL = rbf_walk_rows<R, D2>();
+    __shared__ __attribute__((aligned(16))) char sT[2 * K::BUFB];
+    __shared__ uint8_t sB[W * RBF_WALK_LMAX];
+    const uint32_t tid = threadIdx.x;
+    const int U = A.nchunk * A.nxt;
+    const int kk = (int)blockIdx.x / U, u = (int)blockIdx.x - kk * U;
+    const int chunk = u / A.nxt, xt = u - chunk * A.nxt;
+    const int k = A.k_begin + kk;
+    const int j0 = chunk * A.L;
+    const int Lc = A.ny - j0 < A.L ? A.ny - j0 : A.L;
+    const int i = xt * NT + (int)tid;
+    const int iv = i < A.nx ? i : A.nx - 1;
+    typename K::State S;
+    // ---- per-lane constants ----
+#pragma unroll
+    for (int d = 0; d < W; ++d) {
+        const uint32_t va = A.vx[d * A.nx + iv];
+        S.aoff[d] = K::lane_aoff((uint32_t)d, va != 255u ? va : (uint32_t)(NV - 1));
+        int ic = iv + d - R;
+        ic = ic < 0 ? 0 : (ic >= A.nx ? A.nx - 1 : ic);
+        S.xoff[d] = (uint32_t)ic * 4u;
+    }
+    int kbase = k - R;
+    kbase = kbase < A.xk_lo ? A.xk_lo : (kbase > A.xk_hi ? A.xk_hi : kbase);
+#pragma unroll
+    for (int p = 0; p < W; ++p) {
+        int kq = k + p - R;
+        kq = kq < A.xk_lo ? A.xk_lo : (kq > A.xk_hi ? A.xk_hi : kq);
+        S.kp[p] = kq - kbase;
+    }
+    const int64_t plane = (int64_t)A.nx * A.ny;
+    {
+        const int64_t avail = (int64_t)(A.xk_hi - kbase + 1) * plane * 4, want = (int64_t)W * plane * 4;
+        S.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(A.x + (int64_t)kbase * plane), 0, (int)(avail < want ? avail : want), 0x00020000);
+    }
+    // ---- row variants of the walk, staging bookkeeping ----
+    for (int e = (int)tid; e < W * Lc; e += NT) {
+        const int d = e / Lc, s = e - d * Lc;
+        const uint32_t vb = A.vy[d * A.ny + j0 + s];
+        sB[d * RBF_WALK_LMAX + s] = (uint8_t)(vb != 255u ? vb : (uint32_t)(NV - 1));
+    }
+#pragma unroll
+    for (int r = 0; r < NROUND; ++r) {
+        uint32_t e = tid + (uint32_t)(r * NT);
+        if (e >= (uint32_t)K::NCHUNK) e = 0;   // (never stored)
+        const int row = (int)(e / (uint32_t)K::CPR), within = (int)e - row * K::CPR;
+        int dk = 0, dj = 0;
+#pragma unroll
+        for (int q = 0; q < RL.n; ++q)
+            if (row == q) { dk = RL.dk[q]; dj = RL.dj[q]; }
+        const uint32_t vc = A.vz[dk * A.nz + k];
+        const uint32_t c = vc != 255u ? vc : (uint32_t)(NV - 1);
+        S.gpre[r] = (((uint32_t)dk * NV + c) * W + (uint32_t)dj) * (uint32_t)(NV * K::CPR) + (uint32_t)within;
+        S.sbad[r] = (uint32_t)(dj * RBF_WALK_LMAX);
+        S.sdst[r] = K::chunk_dst(e);
+    }
+    __syncthreads();
+    K::table_fetch(A, S, sB, 0);
+    K::table_store(S, sT, 0, tid);
+    if (Lc > 1) K::table_fetch(A, S, sB, 1);
+    // ---- the window of step 0 ----
+#pragma unroll
+    for (int rr = 0; rr < W; ++rr)
+#pragma unroll
+        for (int p = 0; p < W; ++p) K::load_row(A, S, p, rr, j0 + rr - R);
+    float* __restrict__ yrow = A.y + ((int64_t)k * A.ny + j0) * A.nx + i;
+    double dsum = 0.0;
+    int s = 0;
+#define RBF_WALK_STEP(P)                                                                                        \
+    {                                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
+        if (s + 1 < Lc) K::table_store(S, sT, (s + 1) & 1, tid);                                                \
+        if (s + 2 < Lc) K::table_fetch(A, S, sB, s + 2);                                                        \
+        const float xc = S.xw[R][((P) + R) % W][R];                                                             \
+        const float acc = K::template step<(P)>(A, S, sT, s, j0);                                               \
+        asm volatile("" ::"v"(acc)); /* (keeps the sum where it is: otherwise it sinks into the branch of the store) */ \
+        if (i < A.nx) {                                                                                         \
+            yrow[(int64_t)s * A.nx] = MODE == 0 ? acc : acc + A.add;                                            \
+            if (MODE == 0) dsum += (double)xc * (double)acc;                                                    \
+        }                                                                                                       \
+        if (++s >= Lc) break;                                                                                   \
+    }
+    for (;;) {
+        RBF_WALK_STEP(0)
+        if constexpr (W > 1) RBF_WALK_STEP(1)
+        if constexpr (W > 2) RBF_WALK_STEP(2)
+        if constexpr (W > 3) RBF_WALK_STEP(3)
+        if constexpr (W > 4) RBF_WALK_STEP(4)
+        if constexpr (W > 5) RBF_WALK_STEP(5)
+        if constexpr (W > 6) RBF_WALK_STEP(6)
+    }
+#undef RBF_WALK_STEP
+    if (MODE == 0 && A.dot_partial) {
+        // sum of x * y over the workgroup's outputs in a fixed order: lanes (xor tree), then wavefronts
+        __shared__ double sred[NW];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+        if ((tid & 63u) == 0) sred[tid >> 6] = dsum;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < NW; ++w) t += sred[w];
+            A.dot_partial[blockIdx.x] = t;
+        }
+    }
+}
+
+// ---- host side ----
+struct RbfWalkPlan {
+    int NW, L, nchunk, nxt;
+};
+static RbfWalkPlan rbf_walk_plan(int nx, int ny, int nplanes)
+{
+    RbfWalkPlan P;
+    // wavefronts per workgroup: the fewest idle lanes, then the widest workgroup (one staged table per row piece)
+    P.NW = 1;
+    int64_t best = -1;
+    for (int nw = 1; nw <= 8; nw *= 2) {
+        const int64_t lanes = (int64_t)((nx + 64 * nw - 1) / (64 * nw)) * 64 * nw;
+        if (best < 0 || lanes <= best) { best = lanes; P.NW = nw; }
+    }
+    if (const char* e = getenv("R2S_RBF_WALK_NW")) {   // (experiments)
+        const int nw = atoi(e);
+        if (nw == 1 || nw == 2 || nw == 4 || nw == 8) P.NW = nw;
+    }
+    P.nxt = (nx + 64 * P.NW - 1) / (64 * P.NW);
+    // rows per walk: long walks amortise the window of the first step, short ones fill the chip on small lattices
+    P.L = RBF_WALK_LMAX;
+    while (P.L > 4 && (int64_t)nplanes * ((ny + P.L - 1) / P.L) * P.nxt < 2048) P.L /= 2;
+    P.nchunk = (ny + P.L - 1) / P.L;
+    return P;
+}
+// is there a walk kernel for this stencil / lattice?
+static bool rbf_walk_supported(int R, int tap_d2, int nx, int ny)
+{
+    return R == 2 && tap_d2 == 7 && (int64_t)nx * ny * 5 * 4 < 0x7FFFFFFFll;
+}
+template <int MODE, int NV>
+static void rbf_walk_launch_nw(const RbfWalkArgs& A, int NW, unsigned nb, hipStream_t st)
+{
+    switch (NW) {
+    case 1: rbf_walk_kernel<2, 7, MODE, NV, 1><<<nb, 64, 0, st>>>(A); break;
+    case 2: rbf_walk_kernel<2, 7, MODE, NV, 2><<<nb, 128, 0, st>>>(A); break;
+    case 4: rbf_walk_kernel<2, 7, MODE, NV, 4><<<nb, 256, 0, st>>>(A); break;
+    default: rbf_walk_kernel<2, 7, MODE, NV, 8><<<nb, 512, 0, st>>>(A); break;
+    }
+}
+// mode 0: y = K x (T: float table, nv = 16); mode 1: evaluation (T: double table, nv = 16 or 64)
+static void rbf_walk_launch(int mode, int nv, RbfWalkArgs A, hipStream_t st)
+{
+    const RbfWalkPlan P = rbf_walk_plan(A.nx, A.ny, A.k_end - A.k_begin);
+    A.L = P.L; A.nchunk = P.nchunk; A.nxt = P.nxt;
+    const unsigned nb = (unsigned)((int64_t)(A.k_end - A.k_begin) * P.nchunk * P.nxt);
+    if (nb == 0) return;
+    if (mode == 0) rbf_walk_launch_nw<0, 16>(A, P.NW, nb, st);
+    else if (nv == 16) rbf_walk_launch_nw<1, 16>(A, P.NW, nb, st);
+    else rbf_walk_launch_nw<1, 64>(A, P.NW, nb, st);
+}

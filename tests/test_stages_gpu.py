@@ -89,6 +89,15 @@ def test_remove_artifacts(pkg, oracle):
         pkg.remove_sdf_artifacts(np.zeros(7), pg)
 
 
+def _set_rbf_mode(monkeypatch, mode, names=("R2S_RBF_MATVEC", "R2S_RBF_APPLY")):
+    """mode "walk" = the default kernels (row walk, r2s_rbf_walk.hpp): no environment override"""
+    for name in names:
+        if mode == "walk":
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, mode)
+
+
 @pytest.mark.parametrize("interp,smooth", [(False, 1), (True, 1), (True, 2)])
 def test_rbf_smoothing(pkg, oracle, interp, smooth):
     """BASELINE configs 2/3: beam, approximation and interpolation, :same and :fine grids"""
@@ -175,11 +184,11 @@ def test_rbf_matvec_variants_are_bit_identical(pkg, oracle, monkeypatch):
     vd, vf = oracle.mesh_volume(X, IEN, rho)
     pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
     outs = {}
-    for mode in ("lut", "lutg", "k", "fly"):   # lut: table rows staged in LDS; lutg: table entries gathered from L1 / L2
-        monkeypatch.setenv("R2S_RBF_MATVEC", mode)
+    for mode in ("walk", "lut", "lutg", "k", "fly"):   # walk: default; lut: table rows staged in LDS; lutg: entries gathered from L1 / L2
+        _set_rbf_mode(monkeypatch, mode, ("R2S_RBF_MATVEC",))
         info = {}
         outs[mode] = (pkg.RBFs_smoothing(sdf, pg, True, 1, vd * vf, info=info), info["cg_iterations"], info["th"], info["lsf"])
-    for mode in ("lutg", "k", "fly"):
+    for mode in ("walk", "lutg", "k", "fly"):
         assert outs[mode][1] == outs["lut"][1] and outs[mode][2] == outs["lut"][2]
         assert np.array_equal(outs[mode][0], outs["lut"][0]) and np.array_equal(outs[mode][3], outs["lut"][3])
     pkg._lib.lib().r2s_release_cache()
@@ -196,13 +205,13 @@ def test_rbf_tables_other_kernel_thresholds(pkg, oracle, monkeypatch, threshold)
     vd, vf = oracle.mesh_volume(X, IEN, rho)
     pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
     outs = {}
-    for mode in ("lut", "fly"):
-        monkeypatch.setenv("R2S_RBF_MATVEC", mode)
-        monkeypatch.setenv("R2S_RBF_APPLY", mode)
+    for mode in ("walk", "lut", "fly"):
+        _set_rbf_mode(monkeypatch, mode)
         info = {}
         outs[mode] = (pkg.RBFs_smoothing(sdf, pg, True, 1, vd * vf, threshold, info=info), info["cg_iterations"], info["th"], info["lsf"])
-    assert outs["fly"][1] == outs["lut"][1] and outs["fly"][2] == outs["lut"][2]
-    assert np.array_equal(outs["fly"][0], outs["lut"][0]) and np.array_equal(outs["fly"][3], outs["lut"][3])
+    for mode in ("walk", "fly"):
+        assert outs[mode][1] == outs["lut"][1] and outs[mode][2] == outs["lut"][2]
+        assert np.array_equal(outs[mode][0], outs["lut"][0]) and np.array_equal(outs[mode][3], outs["lut"][3])
     assert np.isfinite(outs["lut"][0]).all() and outs["lut"][1] > 0
     pkg._lib.lib().r2s_release_cache()
 
@@ -221,12 +230,11 @@ def test_rbf_lds_kernels_on_a_wide_grid(pkg, monkeypatch):
     sdf = np.where(np.abs(sdf) < 6 * g.cell_size, sdf, np.sign(sdf) * 1e10).ravel()
     target = float((sdf > 0).sum()) * g.cell_size ** 3
     outs = {}
-    for mode in ("lut", "lutg", "fly"):
-        monkeypatch.setenv("R2S_RBF_MATVEC", mode)
-        monkeypatch.setenv("R2S_RBF_APPLY", mode)
+    for mode in ("walk", "lut", "lutg", "fly"):
+        _set_rbf_mode(monkeypatch, mode)
         info = {}
         outs[mode] = (pkg.RBFs_smoothing(sdf, g, True, 1, target, info=info), info["cg_iterations"], info["th"], info["lsf"])
-    for mode in ("lutg", "fly"):
+    for mode in ("walk", "lutg", "fly"):
         assert outs[mode][1] == outs["lut"][1] and outs[mode][2] == outs["lut"][2]
         assert np.array_equal(outs[mode][0], outs["lut"][0]) and np.array_equal(outs[mode][3], outs["lut"][3])
     assert outs["lut"][1] > 0 and np.isfinite(outs["lut"][0]).all()
@@ -243,11 +251,11 @@ def test_rbf_evaluation_table_is_bit_identical(pkg, oracle, monkeypatch, interp)
     vd, vf = oracle.mesh_volume(X, IEN, rho)
     pg = pkg.noninteractive_sdf_grid_setup(pkg.Mesh(X, IEN))
     outs = {}
-    for mode in ("lut", "lutg", "fly"):   # lut: table rows staged in LDS where a workgroup spans <= 2 rows; lutg: gathered
-        monkeypatch.setenv("R2S_RBF_APPLY", mode)
+    for mode in ("walk", "lut", "lutg", "fly"):   # walk: default; lut: table rows staged in LDS where a workgroup spans <= 2 rows; lutg: gathered
+        _set_rbf_mode(monkeypatch, mode, ("R2S_RBF_APPLY",))
         info = {}
         outs[mode] = (pkg.RBFs_smoothing(sdf, pg, interp, 1, vd * vf, info=info), info["th"], info["lsf"])
-    for mode in ("lutg", "fly"):
+    for mode in ("walk", "lutg", "fly"):
         assert outs[mode][1] == outs["lut"][1]
         assert np.array_equal(outs[mode][0], outs["lut"][0]) and np.array_equal(outs[mode][2], outs["lut"][2])
     assert np.isfinite(outs["lut"][0]).all() and np.ptp(outs["lut"][0]) > 0
