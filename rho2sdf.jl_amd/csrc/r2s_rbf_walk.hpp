@@ -39,6 +39,7 @@ struct RbfWalkArgs {
     int L, nchunk, nxt;            // rows per walk, walks per plane, workgroups per row
     float add;                     // MODE 1: constant added to every output
     double* dot_partial;           // MODE 0: sum of x*y per workgroup [(k - k_begin) * nchunk * nxt + ...], or null
+    int diag;                      // timing experiments only (wrong results): 1 = wavefronts load disjoint aligned columns
 };
 
 template <int R>
@@ -104,9 +105,27 @@ __global__ void __launch_bounds__(256) rbf_walk_table_kernel(const RbfLutVals* _
 typedef unsigned int rbf_u32x4 __attribute__((ext_vector_type(4)));
 typedef float rbf_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int R, int D2, int MODE, int NV, int NW>
+// lane i-1 / lane i+1 of the wavefront (0 shifted in at its ends)
+__device__ __forceinline__ float rbf_dpp_prev(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));   // wave_shr:1
+}
+__device__ __forceinline__ float rbf_dpp_next(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));   // wave_shl:1
+}
+
+// DPP = 1 (MODE 0): a lane keeps only ITS column of the window (25 registers instead of 125, one load per new row
+// instead of 2R+1) and takes x[i +- 1], x[i +- 2] from the neighbouring lanes by DPP wavefront shifts folded into the
+// multiplications; the first and last R lanes of a wavefront are halo lanes (they load and shift, but own no output), so a
+// wavefront produces 64 - 2R outputs.  A third of the registers = twice the wavefronts per SIMD, which is what this
+// instruction-issue-bound kernel needs (one wavefront issues a VALU instruction every 4 cycles at best).
+template <int R, int D2, int MODE, int NV, int NW, int DPP>
 struct RbfWalk {
     static constexpr int W = 2 * R + 1;
+    static constexpr int DG = DPP / 10;                   // timing-only variants (wrong results): 1 no coefficient reads, 2 no staging, 3 no x loads, 4 no barrier
+    static constexpr int WS = DPP ? 1 : W;                // shifted copies kept per window row
+    static constexpr int OUTW = DPP ? 64 - 2 * R : 64;    // outputs per wavefront
     typedef typename std::conditional<MODE == 0, float, double>::type TE;
     static constexpr int ES = (int)sizeof(TE);
     static constexpr int NT = NW * 64;
@@ -122,13 +141,16 @@ struct RbfWalk {
     //           wavefronts per CU reading their own coefficients, is what bounds this kernel).  RS floats per (di, a): 28 =
     //           4 x odd puts the 16 variants of a 16-lane read group on disjoint banks; BS floats per di: RS NV + 4 spreads
     //           the staging stores.
-    static constexpr int NQ = (NROW + 3) / 4;             // 16-byte groups of rows
-    static constexpr int RS = 4 * NQ + 4 + ((NQ + 1) % 2 ? 0 : 4);
+    static constexpr int NQ4 = (NROW + 3) / 4;            // 16-byte groups of rows
+    static constexpr int RS = 4 * NQ4 + 4 + ((NQ4 + 1) % 2 ? 0 : 4);
+    static constexpr int GR = DPP ? 2 : 4;                // rows per read: 16-byte reads, or 8-byte ones where registers are short
+    static constexpr int NQ = (NROW + GR - 1) / GR;
+    typedef float wq_t __attribute__((ext_vector_type(GR)));
     static constexpr int BS = RS * NV + 4;
     static constexpr int BUFB = MODE == 0 ? W * BS * 4 : NROW * ROWLEN * ES;
 
     struct State {
-        float xw[W][W][W];        // [plane][ring slot][shift]
+        float xw[W][W][WS];       // [plane][ring slot][shift] (DPP: the lane's own column only)
         uint32_t aoff[W];         // byte offset of the lane's x variant inside the LDS image, per di
         uint32_t xoff[W];         // byte offset of the lane's (clamped) column i + di inside a row of x
         int kp[W];                // plane k + dk, clamped into the planes that exist, relative to the descriptor's base
@@ -143,9 +165,15 @@ struct RbfWalk {
     {
         const int jj = jrow < 0 ? 0 : (jrow >= A.ny ? A.ny - 1 : jrow);
         const int soff = (S.kp[p] * A.ny + jj) * A.nx * 4;
+        if constexpr (DG == 3) {
+            S.xw[p][slot][0] = __uint_as_float(S.xoff[R] + (uint32_t)soff);
+        } else if constexpr (DPP) {
+            S.xw[p][slot][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rx, (int)S.xoff[R], soff, 0));
+        } else {
 #pragma unroll
-        for (int d = 0; d < W; ++d)
-            S.xw[p][slot][d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rx, (int)S.xoff[d], soff, 0));
+            for (int d = 0; d < W; ++d)
+                S.xw[p][slot][d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rx, (int)S.xoff[d], soff, 0));
+        }
     }
     __device__ static __forceinline__ void table_fetch(const RbfWalkArgs& A, State& S, const uint8_t* sB, int sn)
     {
@@ -203,15 +231,18 @@ struct RbfWalk {
             // software pipeline over groups of four rows: the reads of group g + 1 are issued, then the products of
             // group g run (the compiler's own order - every read, one wait, the serial sum - leaves the LDS pipe and the
             // VALU idle in turn, in all wavefronts of the workgroup at once)
-            rbf_f32x4 wq[2][W];
-            auto read_group = [&](int g, rbf_f32x4 (&dst)[W]) {
+            wq_t wq[2][W];
+            auto read_group = [&](int g, wq_t (&dst)[W]) {
 #pragma unroll
                 for (int di = 0; di < W; ++di) {
                     bool used = false;
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-                        if (4 * g + rr < NROW && RL.dmax[4 * g + rr] >= (di > R ? di - R : R - di)) used = true;
-                    if (used) dst[di] = *(const rbf_f32x4*)(sT + ab[di] + g * 16);
+                    for (int rr = 0; rr < GR; ++rr)
+                        if (GR * g + rr < NROW && RL.dmax[GR * g + rr] >= (di > R ? di - R : R - di)) used = true;
+                    if (used) {
+                        if constexpr (DG == 1) dst[di] = (wq_t)__uint_as_float(ab[di] + g);
+                        else dst[di] = *(const wq_t*)(sT + ab[di] + g * (GR * 4));
+                    }
                 }
             };
             read_group(0, wq[0]);
@@ -220,12 +251,47 @@ struct RbfWalk {
                 if (g + 1 < NQ) read_group(g + 1, wq[(g + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int row = 4 * g + rr;
+                for (int rr = 0; rr < GR; ++rr) {
+                    const int row = GR * g + rr;
                     if (row >= NROW) continue;
                     const int p = RL.dk[row], dj = RL.dj[row], m = RL.dmax[row];
+                    if constexpr (DPP) {
+                        static_assert(!DPP || R == 2, "the DPP form is written for R = 2");
+                        const float own = S.xw[p][(P + dj) % W][0];
+                        const wq_t* wv = wq[g & 1];
+                        if constexpr (DPP % 10 == 2) {   // one rounding per neighbour (fused multiply-add)
+                            if (m == 2) {
+                                const float t1 = rbf_dpp_prev(own), t2 = rbf_dpp_next(own);
+                                acc = __builtin_fmaf(wv[0][rr], rbf_dpp_prev(t1), acc);
+                                acc = __builtin_fmaf(wv[1][rr], t1, acc);
+                                acc = __builtin_fmaf(wv[2][rr], own, acc);
+                                acc = __builtin_fmaf(wv[3][rr], t2, acc);
+                                acc = __builtin_fmaf(wv[4][rr], rbf_dpp_next(t2), acc);
+                            } else if (m == 1) {
+                                acc = __builtin_fmaf(wv[1][rr], rbf_dpp_prev(own), acc);
+                                acc = __builtin_fmaf(wv[2][rr], own, acc);
+                                acc = __builtin_fmaf(wv[3][rr], rbf_dpp_next(own), acc);
+                            } else {
+                                acc = __builtin_fmaf(wv[2][rr], own, acc);
+                            }
+                        } else if (m == 2) {
+                            const float t1 = rbf_dpp_prev(own), t2 = rbf_dpp_next(own);
+                            acc += wv[0][rr] * rbf_dpp_prev(t1);
+                            acc += wv[1][rr] * t1;
+                            acc += wv[2][rr] * own;
+                            acc += wv[3][rr] * t2;
+                            acc += wv[4][rr] * rbf_dpp_next(t2);
+                        } else if (m == 1) {
+                            acc += wv[1][rr] * rbf_dpp_prev(own);
+                            acc += wv[2][rr] * own;
+                            acc += wv[3][rr] * rbf_dpp_next(own);
+                        } else {
+                            acc += wv[2][rr] * own;
+                        }
+                    } else {
 #pragma unroll
-                    for (int di = R - m; di <= R + m; ++di) acc += wq[g & 1][di][rr] * S.xw[p][(P + dj) % W][di];
+                        for (int di = R - m; di <= R + m; ++di) acc += wq[g & 1][di][rr] * S.xw[p][(P + dj) % W][di];
+                    }
                     // the plane's last row has been used: the slot of its dj = -R row takes the row of the next step
                     if (row + 1 == NROW || RL.dk[row + 1] != p) load_row(A, S, p, P % W, jnew);
                 }
@@ -233,6 +299,7 @@ struct RbfWalk {
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
+            static_assert(MODE == 0 || !DPP, "the evaluation keeps the shifted copies");
             constexpr RbfTapOrder<R> TO = rbf_tap_order<R, D2>();
             constexpr int NB = 9;   // neighbours per batch
             double eb[2][NB];
@@ -258,7 +325,7 @@ struct RbfWalk {
                     // (the conversion as an opaque instruction: left to the compiler, the Float64 images of the window's
                     //  values are kept across the steps of the unrolled ring - twice the registers of the window)
                     double wd;
-                    asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(wd) : "v"(S.xw[p][(P + dj) % W][di]));
+                    asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(wd) : "v"(S.xw[p][(P + dj) % W][DPP ? 0 : di]));
                     acc = (float)((double)acc + wd * eb[(q0 / NB) & 1][u]);
                 }
                 asm volatile("" : "+v"(acc));   // (pins the sums of the batch between the two barriers)
@@ -271,10 +338,11 @@ struct RbfWalk {
     }
 };
 
-template <int R, int D2, int MODE, int NV, int NW>
-__global__ void __launch_bounds__(NW * 64) rbf_walk_kernel(const RbfWalkArgs A)
+// (DPP: at most 96 registers, so that two workgroups of nine wavefronts share a CU)
+template <int R, int D2, int MODE, int NV, int NW, int DPP>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DPP ? 5 : 1))) rbf_walk_kernel(const RbfWalkArgs A)
 {
-    typedef RbfWalk<R, D2, MODE, NV, NW> K;
+    typedef RbfWalk<R, D2, MODE, NV, NW, DPP> K;
     typedef typename K::TE TE;
     constexpr int W = K::W, NT = K::NT, NROUND = K::NROUND;
     constexpr RbfWalkRows<R> RL = rbf_walk_rows<R, D2>();
@@ -287,8 +355,11 @@ __global__ void __launch_bounds__(NW * 64) rbf_walk_kernel(const RbfWalkArgs A)
     const int k = A.k_begin + kk;
     const int j0 = chunk * A.L;
     const int Lc = A.ny - j0 < A.L ? A.ny - j0 : A.L;
-    const int i = xt * NT + (int)tid;
-    const int iv = i < A.nx ? i : A.nx - 1;
+    // lane -> column: consecutive lanes = consecutive columns; with DPP the wavefronts overlap by their 2R halo lanes
+    const int lane = (int)(tid & 63u), wv = (int)(tid >> 6);
+    const int i = xt * (NW * K::OUTW) + wv * K::OUTW + lane - (DPP ? R : 0);
+    const bool valid = i < A.nx && (!DPP || (lane >= R && lane < 64 - R));   // (i >= 0 for lane >= R)
+    const int iv = i < 0 ? 0 : (i < A.nx ? i : A.nx - 1);
     typename K::State S;
     // ---- per-lane constants ----
 #pragma unroll
@@ -296,6 +367,7 @@ __global__ void __launch_bounds__(NW * 64) rbf_walk_kernel(const RbfWalkArgs A)
         const uint32_t va = A.vx[d * A.nx + iv];
         S.aoff[d] = K::lane_aoff((uint32_t)d, va != 255u ? va : (uint32_t)(NV - 1));
         int ic = iv + d - R;
+        if (A.diag == 1) ic = (wv * 64 + lane) % A.nx;
         ic = ic < 0 ? 0 : (ic >= A.nx ? A.nx - 1 : ic);
         S.xoff[d] = (uint32_t)ic * 4u;
     }
@@ -347,13 +419,13 @@ __global__ void __launch_bounds__(NW * 64) rbf_walk_kernel(const RbfWalkArgs A)
     int s = 0;
 #define RBF_WALK_STEP(P)                                                                                        \
     {                                                                                                           \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
-        if (s + 1 < Lc) K::table_store(S, sT, (s + 1) & 1, tid);                                                \
-        if (s + 2 < Lc) K::table_fetch(A, S, sB, s + 2);                                                        \
-        const float xc = S.xw[R][((P) + R) % W][R];                                                             \
+        if (K::DG != 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
+        if (K::DG != 2 && s + 1 < Lc) K::table_store(S, sT, (s + 1) & 1, tid);                                  \
+        if (K::DG != 2 && s + 2 < Lc) K::table_fetch(A, S, sB, s + 2);                                          \
+        const float xc = S.xw[R][((P) + R) % W][DPP ? 0 : R];                                                   \
         const float acc = K::template step<(P)>(A, S, sT, s, j0);                                               \
         asm volatile("" ::"v"(acc)); /* (keeps the sum where it is: otherwise it sinks into the branch of the store) */ \
-        if (i < A.nx) {                                                                                         \
+        if (valid) {                                                                                            \
             yrow[(int64_t)s * A.nx] = MODE == 0 ? acc : acc + A.add;                                            \
             if (MODE == 0) dsum += (double)xc * (double)acc;                                                    \
         }                                                                                                       \
@@ -388,21 +460,27 @@ __global__ void __launch_bounds__(NW * 64) rbf_walk_kernel(const RbfWalkArgs A)
 struct RbfWalkPlan {
     int NW, L, nchunk, nxt;
 };
-static RbfWalkPlan rbf_walk_plan(int nx, int ny, int nplanes)
+// dpp: wavefronts of 60 outputs, NW in {1, 2, 3, 5, 9}; else 64 outputs, NW in {1, 2, 4, 8}
+static RbfWalkPlan rbf_walk_plan(int nx, int ny, int nplanes, bool dpp)
 {
+    static const int nw_dpp[] = {1, 2, 3, 5, 9}, nw_std[] = {1, 2, 4, 8};
+    const int* cand = dpp ? nw_dpp : nw_std;
+    const int ncand = dpp ? 5 : 4, outw = dpp ? 60 : 64;
     RbfWalkPlan P;
-    // wavefronts per workgroup: the fewest idle lanes, then the widest workgroup (one staged table per row piece)
-    P.NW = 1;
+    // wavefronts per workgroup: the fewest wavefronts per row, then the widest workgroup (one staged table per row piece)
+    P.NW = cand[0];
     int64_t best = -1;
-    for (int nw = 1; nw <= 8; nw *= 2) {
-        const int64_t lanes = (int64_t)((nx + 64 * nw - 1) / (64 * nw)) * 64 * nw;
-        if (best < 0 || lanes <= best) { best = lanes; P.NW = nw; }
+    for (int c = 0; c < ncand; ++c) {
+        const int nw = cand[c];
+        const int64_t waves = (int64_t)((nx + outw * nw - 1) / (outw * nw)) * nw;
+        if (best < 0 || waves <= best) { best = waves; P.NW = nw; }
     }
     if (const char* e = getenv("R2S_RBF_WALK_NW")) {   // (experiments)
         const int nw = atoi(e);
-        if (nw == 1 || nw == 2 || nw == 4 || nw == 8) P.NW = nw;
+        for (int c = 0; c < ncand; ++c)
+            if (cand[c] == nw) P.NW = nw;
     }
-    P.nxt = (nx + 64 * P.NW - 1) / (64 * P.NW);
+    P.nxt = (nx + outw * P.NW - 1) / (outw * P.NW);
     // rows per walk: long walks amortise the window of the first step, short ones fill the chip on small lattices
     P.L = RBF_WALK_LMAX;
     while (P.L > 4 && (int64_t)nplanes * ((ny + P.L - 1) / P.L) * P.nxt < 2048) P.L /= 2;
@@ -418,20 +496,42 @@ template <int MODE, int NV>
 static void rbf_walk_launch_nw(const RbfWalkArgs& A, int NW, unsigned nb, hipStream_t st)
 {
     switch (NW) {
-    case 1: rbf_walk_kernel<2, 7, MODE, NV, 1><<<nb, 64, 0, st>>>(A); break;
-    case 2: rbf_walk_kernel<2, 7, MODE, NV, 2><<<nb, 128, 0, st>>>(A); break;
-    case 4: rbf_walk_kernel<2, 7, MODE, NV, 4><<<nb, 256, 0, st>>>(A); break;
-    default: rbf_walk_kernel<2, 7, MODE, NV, 8><<<nb, 512, 0, st>>>(A); break;
+    case 1: rbf_walk_kernel<2, 7, MODE, NV, 1, 0><<<nb, 64, 0, st>>>(A); break;
+    case 2: rbf_walk_kernel<2, 7, MODE, NV, 2, 0><<<nb, 128, 0, st>>>(A); break;
+    case 4: rbf_walk_kernel<2, 7, MODE, NV, 4, 0><<<nb, 256, 0, st>>>(A); break;
+    default: rbf_walk_kernel<2, 7, MODE, NV, 8, 0><<<nb, 512, 0, st>>>(A); break;
+    }
+}
+static void rbf_walk_launch_dpp(const RbfWalkArgs& A, int NW, unsigned nb, hipStream_t st)
+{
+    if (NW == 9) switch (A.diag) {
+        case 2: rbf_walk_kernel<2, 7, 0, 16, 9, 2><<<nb, 576, 0, st>>>(A); return;
+        case 12: rbf_walk_kernel<2, 7, 0, 16, 9, 12><<<nb, 576, 0, st>>>(A); return;
+        case 22: rbf_walk_kernel<2, 7, 0, 16, 9, 22><<<nb, 576, 0, st>>>(A); return;
+        case 32: rbf_walk_kernel<2, 7, 0, 16, 9, 32><<<nb, 576, 0, st>>>(A); return;
+        case 42: rbf_walk_kernel<2, 7, 0, 16, 9, 42><<<nb, 576, 0, st>>>(A); return;
+        default: break;
+    }
+    switch (NW) {
+    case 1: rbf_walk_kernel<2, 7, 0, 16, 1, 1><<<nb, 64, 0, st>>>(A); break;
+    case 2: rbf_walk_kernel<2, 7, 0, 16, 2, 1><<<nb, 128, 0, st>>>(A); break;
+    case 3: rbf_walk_kernel<2, 7, 0, 16, 3, 1><<<nb, 192, 0, st>>>(A); break;
+    case 5: rbf_walk_kernel<2, 7, 0, 16, 5, 1><<<nb, 320, 0, st>>>(A); break;
+    default: rbf_walk_kernel<2, 7, 0, 16, 9, 1><<<nb, 576, 0, st>>>(A); break;
     }
 }
 // mode 0: y = K x (T: float table, nv = 16); mode 1: evaluation (T: double table, nv = 16 or 64)
 static void rbf_walk_launch(int mode, int nv, RbfWalkArgs A, hipStream_t st)
 {
-    const RbfWalkPlan P = rbf_walk_plan(A.nx, A.ny, A.k_end - A.k_begin);
+    static const bool no_dpp = getenv("R2S_RBF_WALK_NODPP") != nullptr;   // (experiments: the register-window form of the product)
+    const bool dpp = mode == 0 && !no_dpp;
+    const RbfWalkPlan P = rbf_walk_plan(A.nx, A.ny, A.k_end - A.k_begin, dpp);
     A.L = P.L; A.nchunk = P.nchunk; A.nxt = P.nxt;
+    if (const char* e = getenv("R2S_RBF_WALK_DIAG")) A.diag = atoi(e);
     const unsigned nb = (unsigned)((int64_t)(A.k_end - A.k_begin) * P.nchunk * P.nxt);
     if (nb == 0) return;
-    if (mode == 0) rbf_walk_launch_nw<0, 16>(A, P.NW, nb, st);
+    if (dpp) rbf_walk_launch_dpp(A, P.NW, nb, st);
+    else if (mode == 0) rbf_walk_launch_nw<0, 16>(A, P.NW, nb, st);
     else if (nv == 16) rbf_walk_launch_nw<1, 16>(A, P.NW, nb, st);
     else rbf_walk_launch_nw<1, 64>(A, P.NW, nb, st);
 }
