@@ -378,24 +378,41 @@ __global__ void __launch_bounds__(256) volume_seg_minmax_kernel(const float* __r
     }
 }
 
-__global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restrict__ sdf, int nx, int ny, int nz,
-                                                         float shift, float iso, float elvol, float jac,
-                                                         QuadTab q, float* __restrict__ partial, int row0 = 0,
-                                                         const float* __restrict__ segmn = nullptr,
-                                                         const float* __restrict__ segmx = nullptr,
-                                                         const float4* __restrict__ qpts = nullptr, int nrows = -1)
+// sum over the lanes of a wavefront in a fixed order (xor butterfly: every lane ends with the same value)
+__device__ __forceinline__ float wave_sum_f32(float v)
 {
-    // nrows >= 0: the workgroups stride over the rows row0 .. row0 + nrows - 1 (fixed grid) and keep the quadrature points
-    // (order <= 9: 729 x 16 B) in LDS for all of their rows - as global look-ups they were a third of the cost of a cut
-    // cell (in registers: 193 VGPRs, 2 wavefronts per SIMD, slower).  nrows < 0: one workgroup per row (gridDim.x rows).
-    // (row0: first cell row of this launch - a Z-slab of a multi-device run works on the rows of its planes, with
-    //  `sdf`, `partial` and the segment arrays addressed as the whole grid's)
-    // segmn / segmx (volume_seg_minmax_kernel, optional): rounding is monotonic, so (segment max - shift) < iso puts
-    // every cell of the segment outside and (segment min - shift) >= iso makes every cell full - the same decisions the
-    // cells would take one by one, without their loads; every thread still adds the same numbers in the same order.
-    __shared__ float red[256];
-    __shared__ int s_cut[256];
-    __shared__ int s_wcnt[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// S(segment) for a segment whose cells are all full: the butterfly of `elvol` over its cells
+__global__ void volume_cfull_kernel(int nx, float elvol, float* __restrict__ cfull)
+{
+    const int lane = threadIdx.x & 63;
+    const int nseg = (nx - 1 + 63) / 64, nlast = (nx - 1) - 64 * (nseg - 1);
+    const float a = wave_sum_f32(elvol), b = wave_sum_f32(lane < nlast ? elvol : 0.0f);
+    if (lane == 0) { cfull[0] = a; cfull[1] = b; }
+}
+
+// Row version: one WAVEFRONT per (j,k) row of cells, 64-cell segments along x (coalesced corner loads, no integer
+// division, no workgroup barrier: rows are independent, so the wavefronts of a CU overlap each other's loads and
+// quadratures).  Per segment S = the butterfly sum over its cells of {a^3 for a full cell, the quadrature sum for a cut
+// cell, 0}; the row's value is the sum of its S in x order.  A cut cell's order^3 Gauss points are split over the lanes
+// (point p to lane p mod 64, summed per lane in p order, then the butterfly).  Every reduction has a fixed order (no
+// float atomics), and a segment's S does not depend on how it was decided.
+// segmn / segmx (volume_seg_minmax_kernel, optional): rounding is monotonic, so (segment max - shift) < iso puts every
+// cell of the segment outside and (segment min - shift) >= iso makes every cell full - the same decisions the cells
+// would take one by one, without their loads.
+// rows / nlist (optional): the rows to work on (level bisection: the rows that can still change, volume_narrow_kernel);
+// else the rows row0 .. row0 + nrows - 1 (a Z-slab of a multi-device run works on the rows of its planes, with `sdf`,
+// `partial` and the segment arrays addressed as the whole grid's).
+__global__ void __launch_bounds__(256) volume_rowwave_kernel(const float* __restrict__ sdf, int nx, int ny, int nz,
+                                                            float shift, float iso, float elvol, float jac, QuadTab q,
+                                                            float* __restrict__ partial, int row0, int nrows,
+                                                            const float* __restrict__ segmn, const float* __restrict__ segmx,
+                                                            const float4* __restrict__ qpts, const int* __restrict__ rows,
+                                                            const uint32_t* __restrict__ nlist)
+{
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t sy = nx, sz = (int64_t)nx * ny;
     const int npts = q.order * q.order * q.order;
@@ -410,143 +427,125 @@ __global__ void __launch_bounds__(256) volume_rows_kernel(const float* __restric
         }
         __syncthreads();
     }
-    const int row_end = row0 + (nrows >= 0 ? nrows : (int)gridDim.x);
-    for (int row = row0 + blockIdx.x; row < row_end; row += gridDim.x) {
-    const int j = row % (ny - 1), k = row / (ny - 1);
-    if (segs) {
-        bool any = false;
-        for (int sg = 0; sg < nseg; ++sg) any = any || !(segmx[(size_t)row * nseg + sg] - shift < iso);
-        if (!any) {   // every cell outside: all partial sums are 0
-            if (tid == 0) partial[row] = 0.0f;
-            continue;
-        }
-    }
-#if defined(VOL_DIAG) && VOL_DIAG == 2   // timing-only build: only the row-level test
-    if (segs) { if (tid == 0) partial[row] = 1.0f; continue; }
-#endif
-    float acc = 0.0f;    // full cells (per thread)
-    float wacc = 0.0f;   // cut cells (lane 0 of each wave)
-    for (int i0 = 0; i0 < nx - 1; i0 += 256) {
-        const int i = i0 + tid;
-        int cls = 0;
-        int state = 2;          // of this wavefront's segment: 0 outside, 1 full, 2 look at the cells
-        bool chunk_cut = true;  // some segment of this chunk needs its cells looked at (uniform over the workgroup)
-        if (segs) {
-            chunk_cut = false;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int sg = (i0 >> 6) + w;
-                int st = 0;
-                if (sg < nseg) {
-                    const float smn = segmn[(size_t)row * nseg + sg] - shift, smx = segmx[(size_t)row * nseg + sg] - shift;
-                    st = (smx < iso) ? 0 : (smn >= iso ? 1 : 2);
-                }
-                chunk_cut = chunk_cut || st == 2;
-                if (w == wave) state = st;
+    const int total = rows ? (int)*nlist : nrows;
+    for (int idx = (int)blockIdx.x * 4 + wave; idx < total; idx += (int)gridDim.x * 4) {
+        const int row = rows ? rows[idx] : row0 + idx;
+        const int j = row % (ny - 1), k = row / (ny - 1);
+        float psum = 0.0f;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int i = sg * 64 + lane;
+            const bool cell = i < nx - 1;
+            int state = 2;   // 0 outside, 1 full, 2 look at the cells
+            if (segs) {
+                const float smn = segmn[(size_t)row * nseg + sg] - shift, smx = segmx[(size_t)row * nseg + sg] - shift;
+                state = (smx < iso) ? 0 : (smn >= iso ? 1 : 2);
             }
-        }
-        if (state == 1) {
-            if (i < nx - 1) acc += elvol;
-        } else if (state == 2 && i < nx - 1) {
-            const int64_t b = ((int64_t)k * ny + j) * nx + i;
-            const float c000 = sdf[b] - shift, c100 = sdf[b + 1] - shift, c010 = sdf[b + sy] - shift,
-                        c110 = sdf[b + sy + 1] - shift, c001 = sdf[b + sz] - shift, c101 = sdf[b + sz + 1] - shift,
-                        c011 = sdf[b + sz + sy] - shift, c111 = sdf[b + sz + sy + 1] - shift;
-            const float mn = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111)));
-            const float mx = fmaxf(fmaxf(fmaxf(c000, c100), fmaxf(c010, c110)), fmaxf(fmaxf(c001, c101), fmaxf(c011, c111)));
-            if (!(mx < iso)) {
-                if (mn >= iso) acc += elvol;
-                else cls = 1;
-            }
-        }
-        if (!chunk_cut) continue;
-        // cut cells listed in x order: ballot per wavefront, offsets from the four wave counts (no serial scan)
-        const uint64_t m = __ballot(cls != 0);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int before = 0, ncut = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int c = s_wcnt[w];
-            before += (w < wave) ? c : 0;
-            ncut += c;
-        }
-        if (cls) s_cut[before + __popcll(m & ((1ull << lane) - 1ull))] = i;
-        __syncthreads();
-#if defined(VOL_DIAG) && VOL_DIAG == 1   // timing-only build: without the quadrature of the cut cells
-        ncut = 0;
-#endif
-        for (int c = wave; c < ncut; c += 4) {
-            const int64_t b = ((int64_t)k * ny + j) * nx + s_cut[c];
-            const float c000 = sdf[b] - shift, c100 = sdf[b + 1] - shift, c010 = sdf[b + sy] - shift,
-                        c110 = sdf[b + sy + 1] - shift, c001 = sdf[b + sz] - shift, c101 = sdf[b + sz + 1] - shift,
-                        c011 = sdf[b + sz + sy] - shift, c111 = sdf[b + sz + sy + 1] - shift;
-            float part = 0.0f;
-            if (in_lds) {   // (the same numbers, the same order of additions; 1 - x is recomputed, exactly)
-                for (int p = lane; p < npts; p += 64) {
-                    const float4 Q = sQ[p];
-                    const float xi = Q.x, eta = Q.y, zeta = Q.z;
-                    const float c00 = c000 * (1.0f - xi) + c100 * xi;
-                    const float c01 = c001 * (1.0f - xi) + c101 * xi;
-                    const float c10 = c010 * (1.0f - xi) + c110 * xi;
-                    const float c11 = c011 * (1.0f - xi) + c111 * xi;
-                    const float c0 = c00 * (1.0f - eta) + c10 * eta;
-                    const float c1 = c01 * (1.0f - eta) + c11 * eta;
-                    const float pv = c0 * (1.0f - zeta) + c1 * zeta;
-                    if (pv >= iso) part += Q.w;
+            if (state == 0) continue;   // S = 0
+            float v = 0.0f;
+            if (state == 1) {
+                v = cell ? elvol : 0.0f;
+            } else {
+                float c000 = 0, c100 = 0, c010 = 0, c110 = 0, c001 = 0, c101 = 0, c011 = 0, c111 = 0;
+                bool cut = false;
+                if (cell) {
+                    const int64_t b = ((int64_t)k * ny + j) * nx + i;
+                    // `shifted_sdf .= sdf .- th` (RBFs4Smoothing.jl:286) folded into the loads
+                    c000 = sdf[b] - shift; c100 = sdf[b + 1] - shift; c010 = sdf[b + sy] - shift; c110 = sdf[b + sy + 1] - shift;
+                    c001 = sdf[b + sz] - shift; c101 = sdf[b + sz + 1] - shift; c011 = sdf[b + sz + sy] - shift; c111 = sdf[b + sz + sy + 1] - shift;
+                    const float mn = fminf(fminf(fminf(c000, c100), fminf(c010, c110)), fminf(fminf(c001, c101), fminf(c011, c111)));
+                    const float mx = fmaxf(fmaxf(fmaxf(c000, c100), fmaxf(c010, c110)), fmaxf(fmaxf(c001, c101), fmaxf(c011, c111)));
+                    if (!(mx < iso)) {
+                        if (mn >= iso) v = elvol;
+                        else cut = true;
+                    }
                 }
-            } else if (qpts) {   // (quad_points_kernel: the same numbers, looked up.  Unrolling this loop 4 / 6 / 12 times: slower)
-                for (int p = lane; p < npts; p += 64) {
-                    const float4 A = qpts[2 * p], B = qpts[2 * p + 1];   // xi, 1-xi, eta, 1-eta | zeta, 1-zeta, weight
-                    const float c00 = c000 * A.y + c100 * A.x;
-                    const float c01 = c001 * A.y + c101 * A.x;
-                    const float c10 = c010 * A.y + c110 * A.x;
-                    const float c11 = c011 * A.y + c111 * A.x;
-                    const float c0 = c00 * A.w + c10 * A.z;
-                    const float c1 = c01 * A.w + c11 * A.z;
-                    const float pv = c0 * B.y + c1 * B.x;
-                    if (pv >= iso) part += B.z;
+                uint64_t m = __ballot(cut);
+                while (m) {   // the cut cells of the segment, one after the other, all lanes on the Gauss points of one cell
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const float d000 = __shfl(c000, src, 64), d100 = __shfl(c100, src, 64), d010 = __shfl(c010, src, 64),
+                                d110 = __shfl(c110, src, 64), d001 = __shfl(c001, src, 64), d101 = __shfl(c101, src, 64),
+                                d011 = __shfl(c011, src, 64), d111 = __shfl(c111, src, 64);
+                    float part = 0.0f;
+                    if (in_lds) {
+                        for (int p = lane; p < npts; p += 64) {
+                            const float4 Q = sQ[p];
+                            const float xi = Q.x, eta = Q.y, zeta = Q.z;
+                            const float c00 = d000 * (1.0f - xi) + d100 * xi;
+                            const float c01 = d001 * (1.0f - xi) + d101 * xi;
+                            const float c10 = d010 * (1.0f - xi) + d110 * xi;
+                            const float c11 = d011 * (1.0f - xi) + d111 * xi;
+                            const float c0 = c00 * (1.0f - eta) + c10 * eta;
+                            const float c1 = c01 * (1.0f - eta) + c11 * eta;
+                            const float pv = c0 * (1.0f - zeta) + c1 * zeta;
+                            if (pv >= iso) part += Q.w;
+                        }
+                    } else {
+                        for (int p = lane; p < npts; p += 64) {
+                            const int iq = p % q.order, jq = (p / q.order) % q.order, kq = p / (q.order * q.order);
+                            const float zeta = (q.gp[kq] + 1) / 2, eta = (q.gp[jq] + 1) / 2, xi = (q.gp[iq] + 1) / 2;
+                            const float c00 = d000 * (1.0f - xi) + d100 * xi;
+                            const float c01 = d001 * (1.0f - xi) + d101 * xi;
+                            const float c10 = d010 * (1.0f - xi) + d110 * xi;
+                            const float c11 = d011 * (1.0f - xi) + d111 * xi;
+                            const float c0 = c00 * (1.0f - eta) + c10 * eta;
+                            const float c1 = c01 * (1.0f - eta) + c11 * eta;
+                            const float pv = c0 * (1.0f - zeta) + c1 * zeta;
+                            if (pv >= iso) part += q.gw[iq] * q.gw[jq] * q.gw[kq] * jac;
+                        }
+                    }
+                    part = wave_sum_f32(part);
+                    if (lane == src) v = part;
                 }
-            } else
-            for (int p = lane; p < npts; p += 64) {
-                const int iq = p % q.order, jq = (p / q.order) % q.order, kq = p / (q.order * q.order);
-                const float zeta = (q.gp[kq] + 1) / 2, eta = (q.gp[jq] + 1) / 2, xi = (q.gp[iq] + 1) / 2;
-                const float c00 = c000 * (1.0f - xi) + c100 * xi;
-                const float c01 = c001 * (1.0f - xi) + c101 * xi;
-                const float c10 = c010 * (1.0f - xi) + c110 * xi;
-                const float c11 = c011 * (1.0f - xi) + c111 * xi;
-                const float c0 = c00 * (1.0f - eta) + c10 * eta;
-                const float c1 = c01 * (1.0f - eta) + c11 * eta;
-                const float pv = c0 * (1.0f - zeta) + c1 * zeta;
-                if (pv >= iso) part += q.gw[iq] * q.gw[jq] * q.gw[kq] * jac;
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-            if (lane == 0) wacc += part;
+            psum += wave_sum_f32(v);
         }
-        __syncthreads();
+        if (lane == 0) partial[row] = psum;
     }
-    // the sum tree red[t] += red[t + s], s = 128 ... 1, with its last six levels inside wavefront 0 (same additions)
-    red[tid] = acc + wacc;
-    __syncthreads();
-    if (tid < 128) red[tid] += red[tid + 128];
-    __syncthreads();
-    if (wave == 0) {
-        float v = red[lane] + red[lane + 64];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);   // lanes < off hold the tree's values
-        if (lane == 0) partial[row] = v;
+}
+
+// Level bisection on one field: every level th lies in [lo, hi].  A segment with max < lo stays outside and one with
+// min >= hi stays full at every further level; a row of such segments keeps its value - written here once, from the
+// constants of volume_cfull_kernel - and leaves the list of rows the next levels work on.
+// in / n_in: the current list (null: all rows 0 .. nrows - 1); out / n_out: the rows that can still change.
+__global__ void __launch_bounds__(256) volume_narrow_kernel(const float* __restrict__ segmn, const float* __restrict__ segmx, int nseg,
+                                                           int nrows, float lo, float hi, const float* __restrict__ cfull,
+                                                           const int* __restrict__ in, const uint32_t* __restrict__ n_in,
+                                                           int* __restrict__ out, uint32_t* __restrict__ n_out,
+                                                           float* __restrict__ partial)
+{
+    const int total = in ? (int)*n_in : nrows;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    int row = 0;
+    if (idx < total) {
+        row = in ? in[idx] : idx;
+        float psum = 0.0f;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const float smn = segmn[(size_t)row * nseg + sg], smx = segmx[(size_t)row * nseg + sg];
+            if (smx < lo) continue;
+            if (smn >= hi) psum += cfull[sg == nseg - 1 ? 1 : 0];
+            else live = true;
+        }
+        if (!live) partial[row] = psum;
     }
-    __syncthreads();   // (red[], s_cut[] are reused by the next row)
+    // append the live rows (one atomic per wavefront; the order of the list does not enter any sum)
+    const uint64_t m = __ballot(live);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_out, (uint32_t)__popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1, 64);
+        if (live) out[base + __popcll(m & ((1ull << lane) - 1ull))] = row;
     }
 }
 
 struct VolumeWork {
-    DevBuf partial, result, segmn, segmx, qpts;
+    DevBuf partial, result, segmn, segmx, qpts, live[2], cnt, cfull;
     float qpts_jac = -1.0f;             // the Jacobian the point table was built with
     const float* seg_field = nullptr;   // the field the segment extrema were computed for (prepare)
+    int cur = -1;                       // live[cur]: the rows the levels still work on (-1: all rows)
     QuadTab q;
-    int nblocks = 2048;
     int init(int order)
     {
         if (order < 1 || order > 32) return fail(R2S_ERR_ARG, "quadrature order %d not in 1..32", order);
@@ -554,7 +553,6 @@ struct VolumeWork {
         gauss_legendre(order, x, w);
         for (int i = 0; i < order; ++i) { q.gp[i] = (float)x[i]; q.gw[i] = (float)w[i]; }   // CalcVolumeFromSDF.jl:43-44
         q.order = order;
-        ENSURE(partial, sizeof(float) * (size_t)nblocks);
         ENSURE(result, 64);
         return 0;
     }
@@ -573,11 +571,36 @@ struct VolumeWork {
     {
         const int nrows = (ny - 1) * (nz - 1), nseg = (nx - 1 + 63) / 64;
         seg_field = nullptr;
+        cur = -1;
         if (nrows <= 0 || nseg <= 0) return 0;
         ENSURE(segmn, sizeof(float) * (size_t)nrows * nseg);
         ENSURE(segmx, sizeof(float) * (size_t)nrows * nseg);
         volume_seg_minmax_kernel<<<nrows, 256, 0, st>>>(d_sdf, nx, ny, nz, segmn.as<float>(), segmx.as<float>(), 0);
         seg_field = d_sdf;
+        return 0;
+    }
+    // level bisection (after prepare): every further run() has its level (shift + iso) in [lo, hi] - rows that cannot change
+    // any more get their final value and leave the list of rows run() works on
+    int narrow(int nx, int ny, int nz, float edge, float lo, float hi, hipStream_t st)
+    {
+        const int nrows = (ny - 1) * (nz - 1), nseg = (nx - 1 + 63) / 64;
+        if (!seg_field || nrows <= 0) return 0;
+        ENSURE(partial, sizeof(float) * (size_t)nrows);
+        ENSURE(live[0], sizeof(int) * (size_t)nrows);
+        ENSURE(live[1], sizeof(int) * (size_t)nrows);
+        ENSURE(cnt, 64);
+        if (!cfull.p) {
+            ENSURE(cfull, 64);
+        }
+        volume_cfull_kernel<<<1, 64, 0, st>>>(nx, edge * edge * edge, cfull.as<float>());
+        const int nxt = cur < 0 ? 0 : 1 - cur;
+        uint32_t* counts = cnt.as<uint32_t>();   // [0], [1]: the lengths of live[0], live[1]
+        HIP_TRY(hipMemsetAsync(counts + nxt, 0, 4, st));
+        // (the launch covers the longest possible list: the current length is read on the device)
+        volume_narrow_kernel<<<(nrows + 255) / 256, 256, 0, st>>>(segmn.as<float>(), segmx.as<float>(), nseg, nrows, lo, hi, cfull.as<float>(),
+                                                                 cur < 0 ? nullptr : live[cur].as<int>(), cur < 0 ? nullptr : counts + cur,
+                                                                 live[nxt].as<int>(), counts + nxt, partial.as<float>());
+        cur = nxt;
         return 0;
     }
     // volume of {sdf - shift >= iso}; synchronises the stream
@@ -586,21 +609,29 @@ struct VolumeWork {
         const float elvol = edge * edge * edge;       // element_edge_length^3 (:40)
         const float jac = elvol / 8.0f;               // :51
         const int nrows = (ny - 1) * (nz - 1);
+        if (nrows <= 0) { *out = 0.0f; return 0; }
         ENSURE(partial, sizeof(float) * (size_t)nrows);
         const bool segs = seg_field == d_sdf && seg_field != nullptr;
+        const bool listed = segs && cur >= 0;
         {
             int rc = points(jac, st);
             if (rc) return rc;
         }
-        volume_rows_kernel<<<std::min(nrows, 8192), 256, 0, st>>>(d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>(), 0,
-                                                                 segs ? segmn.as<float>() : nullptr, segs ? segmx.as<float>() : nullptr,
-                                                                 qpts.as<float4>(), nrows);
+        volume_rowwave_kernel<<<std::min((nrows + 3) / 4, 16384), 256, 0, st>>>(
+            d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>(), 0, nrows, segs ? segmn.as<float>() : nullptr,
+            segs ? segmx.as<float>() : nullptr, qpts.as<float4>(), listed ? live[cur].as<int>() : nullptr,
+            listed ? cnt.as<uint32_t>() + cur : nullptr);
         sum_f32_kernel<<<1, 1024, 0, st>>>(partial.as<float>(), nrows, result.as<float>());
         HIP_TRY(hipMemcpyAsync(out, result.p, sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         return 0;
     }
-    void release() { partial.release(); result.release(); segmn.release(); segmx.release(); qpts.release(); seg_field = nullptr; qpts_jac = -1.0f; }
+    void release()
+    {
+        partial.release(); result.release(); segmn.release(); segmx.release(); qpts.release(); live[0].release(); live[1].release();
+        cnt.release(); cfull.release();
+        seg_field = nullptr; qpts_jac = -1.0f; cur = -1;
+    }
 };
 
 // ====================================================================================
@@ -1600,6 +1631,34 @@ __global__ void __launch_bounds__(256) cg_update_xr_dot_kernel(float* __restrict
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
+// r -= alpha q and the parts of dot(r, r): cg_update_xr_dot_kernel without the weights' step (which the next product takes
+// over, RbfWalkArgs::wacc) - the same grid, assignment and order of additions
+__global__ void __launch_bounds__(256) cg_update_r_dot_kernel(float* __restrict__ r, const float* __restrict__ q, float alpha, int64_t plane,
+                                                             double* __restrict__ partial)
+{
+    __shared__ double red[256];
+    const int64_t k = blockIdx.x / DOT_PARTS, part = blockIdx.x % DOT_PARTS;
+    const int64_t chunk = (plane + DOT_PARTS - 1) / DOT_PARTS, lo = part * chunk, hi = (lo + chunk < plane) ? lo + chunk : plane;
+    const int64_t o = k * plane;
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float rn = r[o + i] - alpha * q[o + i];
+        r[o + i] = rn;
+        acc += (double)rn * (double)rn;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void cg_axpy_kernel(float* __restrict__ x, const float* __restrict__ u, float alpha, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] += alpha * u[i];
+}
 __global__ void __launch_bounds__(256) sum_f64_kernel(const double* __restrict__ in, int n, double* __restrict__ out)
 {
     __shared__ double red[256];
@@ -1650,7 +1709,7 @@ static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
 }
 
 struct RbfWork {   // the device buffers of one rbf_smooth_host call
-    DevBuf b[33];
+    DevBuf b[35];
     VolumeWork vw;
     void release()
     {
@@ -1680,7 +1739,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
            &d_tx = W.b[8], &d_ty = W.b[9], &d_tz = W.b[10], &d_st = W.b[11], &d_cnt = W.b[12], &d_r = W.b[13], &d_u = W.b[14], &d_q = W.b[15],
            &d_part = W.b[16], &d_sum = W.b[17], &d_lut = W.b[18], &d_luta = W.b[19], &d_vx = W.b[20], &d_vy = W.b[21], &d_vz = W.b[22],
            &d_lutf = W.b[23], &d_fvx = W.b[24], &d_fvy = W.b[25], &d_fvz = W.b[26], &d_lv = W.b[27], &d_lvf = W.b[28], &d_luta16 = W.b[29],
-           &d_wt = W.b[30], &d_wa = W.b[31], &d_waf = W.b[32];
+           &d_wt = W.b[30], &d_wa = W.b[31], &d_waf = W.b[32], &d_part2 = W.b[33], &d_u2 = W.b[34];
     VolumeWork& vw = W.vw;
     auto cleanup = [&]() {
         if (!ws) W.release();
@@ -1908,23 +1967,71 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         HIP_C(hipMemcpy(d_r.p, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice));
         HIP_C(hipMemset(d_u.p, 0, sizeof(float) * (size_t)n));
         HIP_C(hipMemset(d_w.p, 0, sizeof(float) * (size_t)n));
+        // dot(u, q): the partial sums of the row-walk product's workgroups (formed by that kernel, or by rbf_walk_dot_kernel
+        // for the other forms of the product: every form of the CG follows the same numbers)
+        const size_t nparts = rbf_walk_nparts(nx, ny, nz, 0, nz);
+        ENSURE_C(d_part2, sizeof(double) * std::max(nparts, (size_t)1));
+        std::vector<double> hp2(nparts);
+        auto sum_parts2 = [&](float* out) -> int {
+            HIP_TRY(hipMemcpy(hp2.data(), d_part2.p, sizeof(double) * nparts, hipMemcpyDeviceToHost));
+            double h = 0.0;
+            for (double v : hp2) h += v;   // in (k, walk, row piece) order
+            *out = (float)h;
+            return 0;
+        };
         float rr;
         TRY_C(dot(d_r.as<float>(), d_r.as<float>(), &rr));
         float residual = std::sqrt(rr), prev = 1.0f;
         const float tol = 3.4526698e-4f * residual;   // reltol = sqrt(eps(Float32)), abstol = 0
-#ifdef RBF_DIAG   // (timing-only builds compute wrong products: a fixed number of iterations)
-        while (its < 6) {
-#else
         const int64_t its_cap = getenv("R2S_RBF_WALK_DIAG") ? 6 : n;   // (timing experiments compute wrong products)
+        RbfWalkArgs WAr;
+        const bool fused = !mv_env && LG.WT && walk_ok && rbf_walk_planes(LG, 0, -1, 0, -1, &WAr) && !getenv("R2S_RBF_CG_UNFUSED");
+        if (fused) {
+            // the product kernel forms u = r + beta u_old itself (written to the other of two buffers), takes the weights' step
+            // of the PREVIOUS iteration (w += alpha u_old) and leaves the parts of dot(u, q); the residual's step and
+            // dot(r, r) are one more pass.  Same operations on the same numbers as the loop below, three passes fewer.
+            ENSURE_C(d_u2, sizeof(float) * (size_t)n);
+            float* ucur = d_u.as<float>();
+            float* unext = d_u2.as<float>();
+            float alpha_prev = 0.0f;
+            auto r_dot = [&](float alpha, float* out) -> int {
+                cg_update_r_dot_kernel<<<nz * DOT_PARTS, 256, 0, st>>>(d_r.as<float>(), d_q.as<float>(), alpha, (int64_t)nx * ny, d_part.as<double>());
+                std::vector<double> hp((size_t)nz * DOT_PARTS);
+                HIP_TRY(hipMemcpy(hp.data(), d_part.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
+                double h = 0.0;
+                for (double v : hp) h += v;
+                *out = (float)h;
+                return 0;
+            };
+            while (!(residual <= tol) && its < its_cap) {
+                const float beta = (residual * residual) / (prev * prev);
+                WAr.T = LG.WT; WAr.x = nullptr; WAr.y = d_q.as<float>(); WAr.dot_partial = d_part2.as<double>();
+                WAr.r = d_r.as<float>(); WAr.u_old = ucur; WAr.u_new = unext; WAr.wacc = d_w.as<float>();
+                WAr.beta = beta; WAr.alpha_prev = alpha_prev;
+                rbf_walk_launch(0, RBF_NV, WAr, st);
+                float uq;
+                TRY_C(sum_parts2(&uq));
+                const float alpha = (residual * residual) / uq;
+                prev = residual;
+                TRY_C(r_dot(alpha, &rr));
+                residual = std::sqrt(rr);
+                its++;
+                alpha_prev = alpha;
+                std::swap(ucur, unext);
+            }
+            if (its > 0) cg_axpy_kernel<<<nb, 256, 0, st>>>(d_w.as<float>(), ucur, alpha_prev, n);   // the last iteration's step
+        } else
         while (!(residual <= tol) && its < its_cap) {
-#endif
             const float beta = (residual * residual) / (prev * prev);
             cg_update_u_kernel<<<nb, 256, 0, st>>>(d_u.as<float>(), d_r.as<float>(), beta, n);
-            if (use_lut) launch_rbf_matvec_lut(LG, nb, st, d_u.as<float>(), d_q.as<float>());
+            double* dp = nullptr;   // (the row-walk kernel leaves the parts of dot(u, q) itself)
+            if (use_lut && LG.WT && !mv_env) dp = d_part2.as<double>();
+            if (use_lut) launch_rbf_matvec_lut(LG, nb, st, d_u.as<float>(), d_q.as<float>(), 0, -1, 0, -1, dp);
             else if (use_k) rbf_matvec_k_kernel<<<nb, 256, 0, st>>>(G, taps, g_rbf_kv.as<float>(), d_u.as<float>(), d_q.as<float>());
             else rbf_matvec_kernel<<<nb, 256, 0, st>>>(G, d_u.as<float>(), d_q.as<float>());
+            if (!dp) rbf_walk_dot_launch(d_u.as<float>(), d_q.as<float>(), nx, ny, nz, 0, nz, d_part2.as<double>(), st);
             float uq;
-            TRY_C(dot(d_u.as<float>(), d_q.as<float>(), &uq));
+            TRY_C(sum_parts2(&uq));
             const float alpha = (residual * residual) / uq;
             prev = residual;
             TRY_C(xr_dot(alpha, &rr));
@@ -1956,6 +2063,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     while (it < 40 && eps > 1.0e-4) {
         th = (lo + hi) / 2;
         float vol;
+        if (it > 0) TRY_C(vw.narrow(nx, ny, nz, edge, lo, hi, st));   // (level 0: [lo, hi] = the range of the field, every row is live)
         TRY_C(vw.run(d_lsf.as<float>(), nx, ny, nz, edge, th, 0.0f, st, &vol));
         eps = std::fabs(target_volume - (double)vol);
         if ((double)vol > target_volume) lo = th; else hi = th;
@@ -2370,7 +2478,7 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
     }
     const bool walk_ok = rbf_walk_supported(G0.tap_r, G0.tap_d2, nx, ny);
     const char* mv_env = getenv("R2S_RBF_MATVEC");
-    SlabBufs blutf(S), bfvx(S), bfvy(S), bfvz(S), blv(S), blvf(S), bsegmn(S), bsegmx(S), bluta16(S), bwt(S), bwa(S), bwaf(S);
+    SlabBufs blutf(S), bfvx(S), bfvy(S), bfvz(S), blv(S), blvf(S), bsegmn(S), bsegmx(S), bluta16(S), bwt(S), bwa(S), bwaf(S), bpart2(S);
     SlabBufs bf(S), bw(S), br(S), bu(S), bq(S), blsf(S), bfine(S), bcx(S), bcy(S), bcz(S), btx(S), bty(S), btz(S), bst(S), bcnt(S),
         bpart(S), blut(S), bluta(S), bvx(S), bvy(S), bvz(S), brows(S);
     std::vector<RbfGeom> Gq(G, G0);
@@ -2386,7 +2494,7 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
         return exchange_halo_slabs(S, base, sizeof(float), plane, radius);
     };
     // plane-wise dot product over all slabs, summed in k order on the host (dot_planes_kernel)
-    std::vector<std::vector<double>> hp(G);
+    std::vector<std::vector<double>> hp(G), hp2(G);
     auto dot = [&](SlabBufs& A, SlabBufs& B, float* out) -> int {
         for (size_t q : order) {
             const Slab& d = S[q];
@@ -2534,11 +2642,24 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
                 float* xv = vptr(bu.at<float>(q), q);
                 float* yv = vptr(bq.at<float>(q), q);
                 const int64_t xlo = (int64_t)d.h0 * plane, xhi = (int64_t)d.h1 * plane - 1;
-                if (use_lut) launch_rbf_matvec_lut(LG[q], nb, d.stream, xv, yv, t0, t1, xlo, xhi);
+                // dot(u, q): the partial sums of the row-walk product's workgroups, as on one device (rbf_smooth_host)
+                const size_t np = rbf_walk_nparts(nx, ny, nz, d.k0, d.k1);
+                SLAB_TRY(bpart2.ensure(q, sizeof(double) * std::max(np, (size_t)1)));
+                hp2[q].resize(np);
+                const bool walk_mv = use_lut && LG[q].WT && !mv_env;
+                if (use_lut) launch_rbf_matvec_lut(LG[q], nb, d.stream, xv, yv, t0, t1, xlo, xhi, walk_mv ? bpart2.at<double>(q) : nullptr);
                 else rbf_matvec_kernel<<<nb, 256, 0, d.stream>>>(Gq[q], xv, yv, t0, t1);
+                if (!walk_mv) rbf_walk_dot_launch(xv, yv, nx, ny, nz, d.k0, d.k1, bpart2.at<double>(q), d.stream);
+                SLAB_HIP(hipMemcpyAsync(hp2[q].data(), bpart2.at<double>(q), sizeof(double) * np, hipMemcpyDeviceToHost, d.stream));
             }
             float uq;
-            SLAB_TRY(dot(bu, bq, &uq));
+            SLAB_TRY(sync_slabs(S));
+            {
+                double h = 0.0;
+                for (size_t q : order)   // (slabs in k order: the order of the single-device run)
+                    for (double v : hp2[q]) h += v;
+                uq = (float)h;
+            }
             const float alpha = (residual * residual) / uq;
             for (size_t q : order) {   // weights / residual update with the parts of dot(r, r)
                 const Slab& d = S[q];
@@ -2635,9 +2756,9 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
                 if (kc1 <= d.k0) continue;
                 const int row0 = d.k0 * (ny - 1), nr = (kc1 - d.k0) * (ny - 1);
                 SLAB_HIP(hipSetDevice(d.device));
-                volume_rows_kernel<<<std::min(nr, 8192), 256, 0, d.stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, th, 0.0f, elvol, jac, vw[q].q,
-                                                                            brows.at<float>(q), row0, bsegmn.at<float>(q), bsegmx.at<float>(q),
-                                                                            vw[q].qpts.as<float4>(), nr);
+                volume_rowwave_kernel<<<std::min((nr + 3) / 4, 16384), 256, 0, d.stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, th, 0.0f, elvol, jac,
+                                                                                          vw[q].q, brows.at<float>(q), row0, nr, bsegmn.at<float>(q),
+                                                                                          bsegmx.at<float>(q), vw[q].qpts.as<float4>(), nullptr, nullptr);
                 if (q != q0)
                     SLAB_HIP(hipMemcpyPeerAsync(brows.at<float>(q0) + row0, S[q0].device, brows.at<float>(q) + row0, d.device,
                                                 sizeof(float) * (size_t)nr, d.stream));

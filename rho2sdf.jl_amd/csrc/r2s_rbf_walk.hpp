@@ -40,6 +40,13 @@ struct RbfWalkArgs {
     float add;                     // MODE 1: constant added to every output
     double* dot_partial;           // MODE 0: sum of x*y per workgroup [(k - k_begin) * nchunk * nxt + ...], or null
     int diag;                      // timing experiments only (wrong results): 1 = wavefronts load disjoint aligned columns
+    // the CG's vector updates folded into the product (single device, variant digit FUSE): the input vector is formed on the
+    // fly as u = r + beta u_old (and stored), and the weights take the step of the previous iteration, w += alpha_prev u_old
+    const float* r;
+    const float* u_old;
+    float* u_new;
+    float* wacc;
+    float beta, alpha_prev;
 };
 
 template <int R>
@@ -123,7 +130,8 @@ __device__ __forceinline__ float rbf_dpp_next(float v)
 template <int R, int D2, int MODE, int NV, int NW, int DPP>
 struct RbfWalk {
     static constexpr int W = 2 * R + 1;
-    static constexpr int DG = DPP / 10;                   // timing-only variants (wrong results): 1 no coefficient reads, 2 no staging, 3 no x loads, 4 no barrier
+    static constexpr int FUSE = (DPP / 100) % 10;         // the CG's vector updates folded in (see RbfWalkArgs)
+    static constexpr int DG = (DPP / 10) % 10;            // timing-only variants (wrong results): 1 no coefficient reads, 2 no staging, 3 no x loads, 4 no barrier
     static constexpr int WS = DPP ? 1 : W;                // shifted copies kept per window row
     static constexpr int OUTW = DPP ? 64 - 2 * R : 64;    // outputs per wavefront
     typedef typename std::conditional<MODE == 0, float, double>::type TE;
@@ -159,13 +167,19 @@ struct RbfWalk {
         uint32_t sdst[NROUND];    // ... and where they go in the LDS image
         rbf_u32x4 tv[NROUND];     // staged chunks in flight
         __amdgpu_buffer_rsrc_t rx;
+        // FUSE: r and u_old of the rows in flight (one per plane), the weights of the centre plane's row, their descriptors
+        float pr[FUSE ? W : 1], pu[FUSE ? W : 1], pw;
+        __amdgpu_buffer_rsrc_t rr, ru;
     };
 
     __device__ static __forceinline__ void load_row(const RbfWalkArgs& A, State& S, int p, int slot, int jrow)
     {
         const int jj = jrow < 0 ? 0 : (jrow >= A.ny ? A.ny - 1 : jrow);
         const int soff = (S.kp[p] * A.ny + jj) * A.nx * 4;
-        if constexpr (DG == 3) {
+        if constexpr (FUSE) {
+            S.pr[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rr, (int)S.xoff[R], soff, 0));
+            S.pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.ru, (int)S.xoff[R], soff, 0));
+        } else if constexpr (DG == 3) {
             S.xw[p][slot][0] = __uint_as_float(S.xoff[R] + (uint32_t)soff);
         } else if constexpr (DPP) {
             S.xw[p][slot][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rx, (int)S.xoff[R], soff, 0));
@@ -173,6 +187,27 @@ struct RbfWalk {
 #pragma unroll
             for (int d = 0; d < W; ++d)
                 S.xw[p][slot][d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rx, (int)S.xoff[d], soff, 0));
+        }
+    }
+    // FUSE: the rows loaded by load_row (row jrow of every plane) enter the window as u = r + beta u_old; the centre plane's
+    // row is this workgroup's to store if it is one of its output rows [j0, j0 + Lc): u_new, and the weights' step
+    __device__ static __forceinline__ void finish_rows(const RbfWalkArgs& A, State& S, int slot, int jrow, int k, int j0, int Lc, int i, bool valid)
+    {
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int p = 0; p < W; ++p) S.xw[p][slot][0] = S.pr[p] + A.beta * S.pu[p];
+            if (valid && jrow >= j0 && jrow < j0 + Lc) {
+                const int64_t o = ((int64_t)k * A.ny + jrow) * A.nx + i;
+                A.u_new[o] = S.xw[R][slot][0];
+                A.wacc[o] = S.pw + A.alpha_prev * S.pu[R];
+            }
+        }
+    }
+    __device__ static __forceinline__ void load_wacc(const RbfWalkArgs& A, State& S, int jrow, int k, int j0, int Lc, int i, bool valid)
+    {
+        if constexpr (FUSE) {
+            S.pw = 0.0f;
+            if (valid && jrow >= j0 && jrow < j0 + Lc) S.pw = A.wacc[((int64_t)k * A.ny + jrow) * A.nx + i];
         }
     }
     __device__ static __forceinline__ void table_fetch(const RbfWalkArgs& A, State& S, const uint8_t* sB, int sn)
@@ -218,9 +253,14 @@ struct RbfWalk {
         return MODE == 0 ? (di * (uint32_t)BS + a * (uint32_t)RS) * 4u : a * (uint32_t)ES;
     }
 
+    struct Ctx {   // the workgroup's / lane's place in the lattice
+        int k, j0, Lc, i;
+        bool valid;
+    };
     template <int P>
-    __device__ static __forceinline__ float step(const RbfWalkArgs& A, State& S, const char* sT, int s, int j0)
+    __device__ static __forceinline__ float step(const RbfWalkArgs& A, State& S, const char* sT, int s, const Ctx& C)
     {
+        const int j0 = C.j0;
         constexpr RbfWalkRows<R> RL = rbf_walk_rows<R, D2>();
         const int jnew = j0 + s + R + 1;   // the row that enters the window for the NEXT step (into the slot of dj = -R)
         uint32_t ab[W];
@@ -293,7 +333,10 @@ struct RbfWalk {
                         for (int di = R - m; di <= R + m; ++di) acc += wq[g & 1][di][rr] * S.xw[p][(P + dj) % W][di];
                     }
                     // the plane's last row has been used: the slot of its dj = -R row takes the row of the next step
-                    if (row + 1 == NROW || RL.dk[row + 1] != p) load_row(A, S, p, P % W, jnew);
+                    if (row + 1 == NROW || RL.dk[row + 1] != p) {
+                        load_row(A, S, p, P % W, jnew);
+                        if (p == R) load_wacc(A, S, jnew, C.k, C.j0, C.Lc, C.i, C.valid);
+                    }
                 }
                 asm volatile("" : "+v"(acc));   // (pins the products of the group between the two barriers)
                 __builtin_amdgcn_sched_barrier(0);
@@ -382,7 +425,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DP
     const int64_t plane = (int64_t)A.nx * A.ny;
     {
         const int64_t avail = (int64_t)(A.xk_hi - kbase + 1) * plane * 4, want = (int64_t)W * plane * 4;
-        S.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(A.x + (int64_t)kbase * plane), 0, (int)(avail < want ? avail : want), 0x00020000);
+        if constexpr (K::FUSE) {
+            S.rr = __builtin_amdgcn_make_buffer_rsrc((void*)(A.r + (int64_t)kbase * plane), 0, (int)(avail < want ? avail : want), 0x00020000);
+            S.ru = __builtin_amdgcn_make_buffer_rsrc((void*)(A.u_old + (int64_t)kbase * plane), 0, (int)(avail < want ? avail : want), 0x00020000);
+        } else {
+            S.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(A.x + (int64_t)kbase * plane), 0, (int)(avail < want ? avail : want), 0x00020000);
+        }
     }
     // ---- row variants of the walk, staging bookkeeping ----
     for (int e = (int)tid; e < W * Lc; e += NT) {
@@ -411,19 +459,24 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DP
     if (Lc > 1) K::table_fetch(A, S, sB, 1);
     // ---- the window of step 0 ----
 #pragma unroll
-    for (int rr = 0; rr < W; ++rr)
+    for (int rr = 0; rr < W; ++rr) {
 #pragma unroll
         for (int p = 0; p < W; ++p) K::load_row(A, S, p, rr, j0 + rr - R);
+        K::load_wacc(A, S, j0 + rr - R, k, j0, Lc, i, valid);
+        K::finish_rows(A, S, rr, j0 + rr - R, k, j0, Lc, i, valid);
+    }
     float* __restrict__ yrow = A.y + ((int64_t)k * A.ny + j0) * A.nx + i;
     double dsum = 0.0;
+    const typename K::Ctx ctx = {k, j0, Lc, i, valid};
     int s = 0;
 #define RBF_WALK_STEP(P)                                                                                        \
     {                                                                                                           \
         if (K::DG != 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
         if (K::DG != 2 && s + 1 < Lc) K::table_store(S, sT, (s + 1) & 1, tid);                                  \
         if (K::DG != 2 && s + 2 < Lc) K::table_fetch(A, S, sB, s + 2);                                          \
+        if (K::FUSE && s > 0) K::finish_rows(A, S, ((P) + W - 1) % W, j0 + s + R, k, j0, Lc, i, valid);         \
         const float xc = S.xw[R][((P) + R) % W][DPP ? 0 : R];                                                   \
-        const float acc = K::template step<(P)>(A, S, sT, s, j0);                                               \
+        const float acc = K::template step<(P)>(A, S, sT, s, ctx);                                              \
         asm volatile("" ::"v"(acc)); /* (keeps the sum where it is: otherwise it sinks into the branch of the store) */ \
         if (valid) {                                                                                            \
             yrow[(int64_t)s * A.nx] = MODE == 0 ? acc : acc + A.add;                                            \
@@ -456,11 +509,47 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DP
     }
 }
 
+// dot(a, b) as the partial sums the product kernel forms for dot(x, y) (RbfWalkArgs::dot_partial): per workgroup of the walk
+// (plane k, rows [j0, j0 + L), 60 NW columns) every lane adds its column's products over the rows in order (Float64), then
+// the lanes of a wavefront (xor butterfly), then the wavefronts in order.  partial[(k - k_begin) nchunk nxt + chunk nxt + xt].
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) rbf_walk_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int nx, int ny,
+                                                              int k_begin, int L, int nchunk, int nxt, double* __restrict__ partial)
+{
+    constexpr int R = 2, OUTW = 64 - 2 * R;
+    const uint32_t tid = threadIdx.x;
+    const int U = nchunk * nxt;
+    const int kk = (int)blockIdx.x / U, u = (int)blockIdx.x - kk * U;
+    const int chunk = u / nxt, xt = u - chunk * nxt;
+    const int k = k_begin + kk, j0 = chunk * L;
+    const int Lc = ny - j0 < L ? ny - j0 : L;
+    const int lane = (int)(tid & 63u), wv = (int)(tid >> 6);
+    const int i = xt * (NW * OUTW) + wv * OUTW + lane - R;
+    const bool valid = i < nx && lane >= R && lane < 64 - R;
+    double dsum = 0.0;
+    if (valid) {
+        const int64_t o = ((int64_t)k * ny + j0) * nx + i;
+        for (int s = 0; s < Lc; ++s) dsum += (double)a[o + (int64_t)s * nx] * (double)b[o + (int64_t)s * nx];
+    }
+    __shared__ double sred[NW];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+    if ((tid & 63u) == 0) sred[tid >> 6] = dsum;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW; ++w) t += sred[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
 // ---- host side ----
 struct RbfWalkPlan {
     int NW, L, nchunk, nxt;
 };
 // dpp: wavefronts of 60 outputs, NW in {1, 2, 3, 5, 9}; else 64 outputs, NW in {1, 2, 4, 8}
+// (nplanes: the planes of the WHOLE lattice - a Z-slab of a multi-device run cuts its walks like the single-device run, so
+//  that the partial sums of the dot product come out the same)
 static RbfWalkPlan rbf_walk_plan(int nx, int ny, int nplanes, bool dpp)
 {
     static const int nw_dpp[] = {1, 2, 3, 5, 9}, nw_std[] = {1, 2, 4, 8};
@@ -504,6 +593,16 @@ static void rbf_walk_launch_nw(const RbfWalkArgs& A, int NW, unsigned nb, hipStr
 }
 static void rbf_walk_launch_dpp(const RbfWalkArgs& A, int NW, unsigned nb, hipStream_t st)
 {
+    if (A.u_new) {   // the CG's vector updates folded in
+        switch (NW) {
+        case 1: rbf_walk_kernel<2, 7, 0, 16, 1, 101><<<nb, 64, 0, st>>>(A); break;
+        case 2: rbf_walk_kernel<2, 7, 0, 16, 2, 101><<<nb, 128, 0, st>>>(A); break;
+        case 3: rbf_walk_kernel<2, 7, 0, 16, 3, 101><<<nb, 192, 0, st>>>(A); break;
+        case 5: rbf_walk_kernel<2, 7, 0, 16, 5, 101><<<nb, 320, 0, st>>>(A); break;
+        default: rbf_walk_kernel<2, 7, 0, 16, 9, 101><<<nb, 576, 0, st>>>(A); break;
+        }
+        return;
+    }
     if (NW == 9) switch (A.diag) {
         case 2: rbf_walk_kernel<2, 7, 0, 16, 9, 2><<<nb, 576, 0, st>>>(A); return;
         case 12: rbf_walk_kernel<2, 7, 0, 16, 9, 12><<<nb, 576, 0, st>>>(A); return;
@@ -523,15 +622,33 @@ static void rbf_walk_launch_dpp(const RbfWalkArgs& A, int NW, unsigned nb, hipSt
 // mode 0: y = K x (T: float table, nv = 16); mode 1: evaluation (T: double table, nv = 16 or 64)
 static void rbf_walk_launch(int mode, int nv, RbfWalkArgs A, hipStream_t st)
 {
-    static const bool no_dpp = getenv("R2S_RBF_WALK_NODPP") != nullptr;   // (experiments: the register-window form of the product)
-    const bool dpp = mode == 0 && !no_dpp;
-    const RbfWalkPlan P = rbf_walk_plan(A.nx, A.ny, A.k_end - A.k_begin, dpp);
+    const bool dpp = mode == 0;
+    const RbfWalkPlan P = rbf_walk_plan(A.nx, A.ny, A.nz, dpp);
     A.L = P.L; A.nchunk = P.nchunk; A.nxt = P.nxt;
     if (const char* e = getenv("R2S_RBF_WALK_DIAG")) A.diag = atoi(e);
     const unsigned nb = (unsigned)((int64_t)(A.k_end - A.k_begin) * P.nchunk * P.nxt);
     if (nb == 0) return;
     if (dpp) rbf_walk_launch_dpp(A, P.NW, nb, st);
-    else if (mode == 0) rbf_walk_launch_nw<0, 16>(A, P.NW, nb, st);
     else if (nv == 16) rbf_walk_launch_nw<1, 16>(A, P.NW, nb, st);
     else rbf_walk_launch_nw<1, 64>(A, P.NW, nb, st);
+}
+
+// workgroups (= partial sums of the dot product) of the planes [k_begin, k_end)
+static size_t rbf_walk_nparts(int nx, int ny, int nz, int k_begin, int k_end)
+{
+    const RbfWalkPlan P = rbf_walk_plan(nx, ny, nz, true);
+    return (size_t)(k_end - k_begin) * P.nchunk * P.nxt;
+}
+static void rbf_walk_dot_launch(const float* a, const float* b, int nx, int ny, int nz, int k_begin, int k_end, double* partial, hipStream_t st)
+{
+    const RbfWalkPlan P = rbf_walk_plan(nx, ny, nz, true);
+    const unsigned nb = (unsigned)((size_t)(k_end - k_begin) * P.nchunk * P.nxt);
+    if (nb == 0) return;
+    switch (P.NW) {
+    case 1: rbf_walk_dot_kernel<1><<<nb, 64, 0, st>>>(a, b, nx, ny, k_begin, P.L, P.nchunk, P.nxt, partial); break;
+    case 2: rbf_walk_dot_kernel<2><<<nb, 128, 0, st>>>(a, b, nx, ny, k_begin, P.L, P.nchunk, P.nxt, partial); break;
+    case 3: rbf_walk_dot_kernel<3><<<nb, 192, 0, st>>>(a, b, nx, ny, k_begin, P.L, P.nchunk, P.nxt, partial); break;
+    case 5: rbf_walk_dot_kernel<5><<<nb, 320, 0, st>>>(a, b, nx, ny, k_begin, P.L, P.nchunk, P.nxt, partial); break;
+    default: rbf_walk_dot_kernel<9><<<nb, 576, 0, st>>>(a, b, nx, ny, k_begin, P.L, P.nchunk, P.nxt, partial); break;
+    }
 }

@@ -7,6 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/rbfprof
 timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rbfprof -- python3 $ROOT/tools/rbf_bench.py --interp --reps 2 "$@" > $OUT/rbf_bench_trace.json
 cp $(ls $OUT/rbfprof/*/*kernel_stats.csv | head -1) $OUT/rbf_stats.csv
+cp $(ls $OUT/rbfprof/*/*kernel_trace.csv | head -1) $OUT/rbf_trace.csv
 rm -rf $OUT/rbfprof
 python3 - <<PY
 import csv
