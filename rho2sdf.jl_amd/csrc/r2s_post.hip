@@ -1983,7 +1983,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         TRY_C(dot(d_r.as<float>(), d_r.as<float>(), &rr));
         float residual = std::sqrt(rr), prev = 1.0f;
         const float tol = 3.4526698e-4f * residual;   // reltol = sqrt(eps(Float32)), abstol = 0
-        const int64_t its_cap = getenv("R2S_RBF_WALK_DIAG") ? 6 : n;   // (timing experiments compute wrong products)
+        const int64_t its_cap = n;
         RbfWalkArgs WAr;
         const bool fused = !mv_env && LG.WT && walk_ok && rbf_walk_planes(LG, 0, -1, 0, -1, &WAr) && !getenv("R2S_RBF_CG_UNFUSED");
         if (fused) {

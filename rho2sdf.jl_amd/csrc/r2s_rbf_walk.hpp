@@ -39,7 +39,6 @@ struct RbfWalkArgs {
     int L, nchunk, nxt;            // rows per walk, walks per plane, workgroups per row
     float add;                     // MODE 1: constant added to every output
     double* dot_partial;           // MODE 0: sum of x*y per workgroup [(k - k_begin) * nchunk * nxt + ...], or null
-    int diag;                      // timing experiments only (wrong results): 1 = wavefronts load disjoint aligned columns
     // the CG's vector updates folded into the product (single device, variant digit FUSE): the input vector is formed on the
     // fly as u = r + beta u_old (and stored), and the weights take the step of the previous iteration, w += alpha_prev u_old
     const float* r;
@@ -131,7 +130,6 @@ template <int R, int D2, int MODE, int NV, int NW, int DPP>
 struct RbfWalk {
     static constexpr int W = 2 * R + 1;
     static constexpr int FUSE = (DPP / 100) % 10;         // the CG's vector updates folded in (see RbfWalkArgs)
-    static constexpr int DG = (DPP / 10) % 10;            // timing-only variants (wrong results): 1 no coefficient reads, 2 no staging, 3 no x loads, 4 no barrier
     static constexpr int WS = DPP ? 1 : W;                // shifted copies kept per window row
     static constexpr int OUTW = DPP ? 64 - 2 * R : 64;    // outputs per wavefront
     typedef typename std::conditional<MODE == 0, float, double>::type TE;
@@ -179,8 +177,6 @@ struct RbfWalk {
         if constexpr (FUSE) {
             S.pr[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rr, (int)S.xoff[R], soff, 0));
             S.pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.ru, (int)S.xoff[R], soff, 0));
-        } else if constexpr (DG == 3) {
-            S.xw[p][slot][0] = __uint_as_float(S.xoff[R] + (uint32_t)soff);
         } else if constexpr (DPP) {
             S.xw[p][slot][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rx, (int)S.xoff[R], soff, 0));
         } else {
@@ -279,10 +275,7 @@ struct RbfWalk {
 #pragma unroll
                     for (int rr = 0; rr < GR; ++rr)
                         if (GR * g + rr < NROW && RL.dmax[GR * g + rr] >= (di > R ? di - R : R - di)) used = true;
-                    if (used) {
-                        if constexpr (DG == 1) dst[di] = (wq_t)__uint_as_float(ab[di] + g);
-                        else dst[di] = *(const wq_t*)(sT + ab[di] + g * (GR * 4));
-                    }
+                    if (used) dst[di] = *(const wq_t*)(sT + ab[di] + g * (GR * 4));
                 }
             };
             read_group(0, wq[0]);
@@ -299,22 +292,7 @@ struct RbfWalk {
                         static_assert(!DPP || R == 2, "the DPP form is written for R = 2");
                         const float own = S.xw[p][(P + dj) % W][0];
                         const wq_t* wv = wq[g & 1];
-                        if constexpr (DPP % 10 == 2) {   // one rounding per neighbour (fused multiply-add)
-                            if (m == 2) {
-                                const float t1 = rbf_dpp_prev(own), t2 = rbf_dpp_next(own);
-                                acc = __builtin_fmaf(wv[0][rr], rbf_dpp_prev(t1), acc);
-                                acc = __builtin_fmaf(wv[1][rr], t1, acc);
-                                acc = __builtin_fmaf(wv[2][rr], own, acc);
-                                acc = __builtin_fmaf(wv[3][rr], t2, acc);
-                                acc = __builtin_fmaf(wv[4][rr], rbf_dpp_next(t2), acc);
-                            } else if (m == 1) {
-                                acc = __builtin_fmaf(wv[1][rr], rbf_dpp_prev(own), acc);
-                                acc = __builtin_fmaf(wv[2][rr], own, acc);
-                                acc = __builtin_fmaf(wv[3][rr], rbf_dpp_next(own), acc);
-                            } else {
-                                acc = __builtin_fmaf(wv[2][rr], own, acc);
-                            }
-                        } else if (m == 2) {
+                        if (m == 2) {
                             const float t1 = rbf_dpp_prev(own), t2 = rbf_dpp_next(own);
                             acc += wv[0][rr] * rbf_dpp_prev(t1);
                             acc += wv[1][rr] * t1;
@@ -410,7 +388,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DP
         const uint32_t va = A.vx[d * A.nx + iv];
         S.aoff[d] = K::lane_aoff((uint32_t)d, va != 255u ? va : (uint32_t)(NV - 1));
         int ic = iv + d - R;
-        if (A.diag == 1) ic = (wv * 64 + lane) % A.nx;
         ic = ic < 0 ? 0 : (ic >= A.nx ? A.nx - 1 : ic);
         S.xoff[d] = (uint32_t)ic * 4u;
     }
@@ -471,9 +448,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DP
     int s = 0;
 #define RBF_WALK_STEP(P)                                                                                        \
     {                                                                                                           \
-        if (K::DG != 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
-        if (K::DG != 2 && s + 1 < Lc) K::table_store(S, sT, (s + 1) & 1, tid);                                  \
-        if (K::DG != 2 && s + 2 < Lc) K::table_fetch(A, S, sB, s + 2);                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
+        if (s + 1 < Lc) K::table_store(S, sT, (s + 1) & 1, tid);                                                \
+        if (s + 2 < Lc) K::table_fetch(A, S, sB, s + 2);                                                        \
         if (K::FUSE && s > 0) K::finish_rows(A, S, ((P) + W - 1) % W, j0 + s + R, k, j0, Lc, i, valid);         \
         const float xc = S.xw[R][((P) + R) % W][DPP ? 0 : R];                                                   \
         const float acc = K::template step<(P)>(A, S, sT, s, ctx);                                              \
@@ -603,14 +580,6 @@ static void rbf_walk_launch_dpp(const RbfWalkArgs& A, int NW, unsigned nb, hipSt
         }
         return;
     }
-    if (NW == 9) switch (A.diag) {
-        case 2: rbf_walk_kernel<2, 7, 0, 16, 9, 2><<<nb, 576, 0, st>>>(A); return;
-        case 12: rbf_walk_kernel<2, 7, 0, 16, 9, 12><<<nb, 576, 0, st>>>(A); return;
-        case 22: rbf_walk_kernel<2, 7, 0, 16, 9, 22><<<nb, 576, 0, st>>>(A); return;
-        case 32: rbf_walk_kernel<2, 7, 0, 16, 9, 32><<<nb, 576, 0, st>>>(A); return;
-        case 42: rbf_walk_kernel<2, 7, 0, 16, 9, 42><<<nb, 576, 0, st>>>(A); return;
-        default: break;
-    }
     switch (NW) {
     case 1: rbf_walk_kernel<2, 7, 0, 16, 1, 1><<<nb, 64, 0, st>>>(A); break;
     case 2: rbf_walk_kernel<2, 7, 0, 16, 2, 1><<<nb, 128, 0, st>>>(A); break;
@@ -625,7 +594,6 @@ static void rbf_walk_launch(int mode, int nv, RbfWalkArgs A, hipStream_t st)
     const bool dpp = mode == 0;
     const RbfWalkPlan P = rbf_walk_plan(A.nx, A.ny, A.nz, dpp);
     A.L = P.L; A.nchunk = P.nchunk; A.nxt = P.nxt;
-    if (const char* e = getenv("R2S_RBF_WALK_DIAG")) A.diag = atoi(e);
     const unsigned nb = (unsigned)((int64_t)(A.k_end - A.k_begin) * P.nchunk * P.nxt);
     if (nb == 0) return;
     if (dpp) rbf_walk_launch_dpp(A, P.NW, nb, st);
