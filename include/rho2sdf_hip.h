@@ -95,6 +95,11 @@ typedef struct {
     int64_t n_sign_only_tiles; /* tiles without band items whose voxels are all +-1e10 (compressed stitching) */
     /* HEX8: iso_project_hex_pl_kernel alone; ms_main also holds iso_straggler_kernel and iso_sweep_kernel */
     double ms_iso_fast;
+    /* HEX8 iso-surface projections (one per iso element x band voxel): pairs the fast Newton-SQP lane machine handed to the
+     * complete solver, and runs of the complete solver that ended WITHOUT a KKT point (iteration / non-convex-step caps,
+     * cycle): their voxel takes the nearest on-surface iterate - the reference likewise uses whatever NLopt returns and
+     * only warns on :FAILURE (ComputeCoordsOnIso.jl:79-86).  SURVEY A6: reported, not hidden. */
+    int64_t n_iso_straggler, n_iso_fail;
 } r2s_stats;
 
 int r2s_version(void);

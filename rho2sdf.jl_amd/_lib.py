@@ -56,7 +56,8 @@ class R2SStats(ctypes.Structure):
                 ("ms_prep", ctypes.c_double), ("ms_bins", ctypes.c_double),
                 ("ms_fill", ctypes.c_double), ("ms_main", ctypes.c_double),
                 ("ms_gather", ctypes.c_double), ("ms_sign", ctypes.c_double),
-                ("n_sign_only_tiles", ctypes.c_int64), ("ms_iso_fast", ctypes.c_double)]
+                ("n_sign_only_tiles", ctypes.c_int64), ("ms_iso_fast", ctypes.c_double),
+                ("n_iso_straggler", ctypes.c_int64), ("n_iso_fail", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -1049,6 +1049,7 @@ R2S_DEV void iso_full_start(IsoFullLane& s, const double x[3], const double xi[3
 R2S_DEV void iso_full_fail(IsoFullLane& s)
 {
     if (s.fbest < INFINITY) { s.xi[0] = s.xbest[0]; s.xi[1] = s.xbest[1]; s.xi[2] = s.xbest[2]; }
+    s.it = R2S_ISO_MAXIT + 1;   // (what iso_project_full returns for a run that ends without a KKT point: counted, r2s_stats::n_iso_fail)
     s.phase = FS_DONE;
 }
 

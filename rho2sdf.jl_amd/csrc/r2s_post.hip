@@ -415,36 +415,54 @@ __global__ void __launch_bounds__(256) volume_rowwave_kernel(const float* __rest
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t sy = nx, sz = (int64_t)nx * ny;
-    const int npts = q.order * q.order * q.order;
+    const int n = q.order, nn = n * n, npts = nn * n;
     const int nseg = (nx - 1 + 63) / 64;
     const bool segs = segmn != nullptr;
-    const bool in_lds = qpts != nullptr && npts <= 12 * 64;
-    __shared__ float4 sQ[12 * 64];   // xi, eta, zeta, weight per quadrature point
-    if (in_lds) {
+    // the tensor form of a cut cell's quadrature (order <= 9: its tables fit the LDS arrays below): the trilinear value at
+    // point (iq, jq, kq) is a chain of seven linear interpolations, of which only the last depends on kq and the first four
+    // only on iq - formed once per cell (4 n along x, 2 n^2 along y, n^3 along z) instead of once per point (7 n^3), from the
+    // same operands by the same expressions: the same values, a fifth of the arithmetic
+    const bool tensor = qpts != nullptr && npts <= 12 * 64 && 4 * n <= 64;
+    __shared__ float4 sQ[12 * 64];     // per quadrature point: zeta, weight, (jq n + iq) as an integer, -
+    __shared__ float sG[32];           // (gp + 1) / 2 per index
+    __shared__ float sC[4][2][96];     // per wavefront: the y-interpolated values c0, c1 of the cell in hand, per (jq, iq)
+    if (tensor) {
         for (int p = tid; p < npts; p += 256) {
-            const float4 A = qpts[2 * p], B = qpts[2 * p + 1];
-            sQ[p] = make_float4(A.x, A.z, B.x, B.z);
+            const float4 B = qpts[2 * p + 1];   // zeta, 1 - zeta, weight
+            sQ[p] = make_float4(B.x, B.z, __int_as_float(p % nn), 0.0f);
         }
+        if (tid < n) sG[tid] = (q.gp[tid] + 1) / 2;
         __syncthreads();
     }
+    const float cfull64 = wave_sum_f32(elvol);
     const int total = rows ? (int)*nlist : nrows;
     for (int idx = (int)blockIdx.x * 4 + wave; idx < total; idx += (int)gridDim.x * 4) {
         const int row = rows ? rows[idx] : row0 + idx;
         const int j = row % (ny - 1), k = row / (ny - 1);
         float psum = 0.0f;
-        for (int sg = 0; sg < nseg; ++sg) {
-            const int i = sg * 64 + lane;
-            const bool cell = i < nx - 1;
-            int state = 2;   // 0 outside, 1 full, 2 look at the cells
-            if (segs) {
-                const float smn = segmn[(size_t)row * nseg + sg] - shift, smx = segmx[(size_t)row * nseg + sg] - shift;
-                state = (smx < iso) ? 0 : (smn >= iso ? 1 : 2);
+        for (int sg0 = 0; sg0 < nseg; sg0 += 64) {
+            // the states of (up to) 64 segments at once: 0 outside, 1 full, 2 look at the cells
+            int st = 0;
+            if (sg0 + lane < nseg) {
+                st = 2;
+                if (segs) {
+                    const float smn = segmn[(size_t)row * nseg + sg0 + lane] - shift, smx = segmx[(size_t)row * nseg + sg0 + lane] - shift;
+                    st = (smx < iso) ? 0 : (smn >= iso ? 1 : 2);
+                }
             }
-            if (state == 0) continue;   // S = 0
-            float v = 0.0f;
-            if (state == 1) {
-                v = cell ? elvol : 0.0f;
-            } else {
+            const uint64_t mfull = __ballot(st == 1), mcut = __ballot(st == 2);
+            uint64_t mwork = mfull | mcut;
+            while (mwork) {   // the segments that add something, in x order
+                const int sl = __ffsll((long long)mwork) - 1;
+                mwork &= mwork - 1;
+                const int sg = sg0 + sl;
+                const int i = sg * 64 + lane;
+                const bool cell = i < nx - 1;
+                if ((mfull >> sl) & 1ull) {
+                    psum += (sg * 64 + 64 <= nx - 1) ? cfull64 : wave_sum_f32(cell ? elvol : 0.0f);
+                    continue;
+                }
+                float v = 0.0f;
                 float c000 = 0, c100 = 0, c010 = 0, c110 = 0, c001 = 0, c101 = 0, c011 = 0, c111 = 0;
                 bool cut = false;
                 if (cell) {
@@ -467,18 +485,34 @@ __global__ void __launch_bounds__(256) volume_rowwave_kernel(const float* __rest
                                 d110 = __shfl(c110, src, 64), d001 = __shfl(c001, src, 64), d101 = __shfl(c101, src, 64),
                                 d011 = __shfl(c011, src, 64), d111 = __shfl(c111, src, 64);
                     float part = 0.0f;
-                    if (in_lds) {
-                        for (int p = lane; p < npts; p += 64) {
-                            const float4 Q = sQ[p];
-                            const float xi = Q.x, eta = Q.y, zeta = Q.z;
-                            const float c00 = d000 * (1.0f - xi) + d100 * xi;
-                            const float c01 = d001 * (1.0f - xi) + d101 * xi;
-                            const float c10 = d010 * (1.0f - xi) + d110 * xi;
-                            const float c11 = d011 * (1.0f - xi) + d111 * xi;
+                    if (tensor) {
+                        // along x: lane (pair n + iq) holds c00, c01, c10, c11 (pair 0 .. 3) at xi_iq
+                        float s1 = 0.0f;
+                        {
+                            const int pr = lane / n, iq = lane - pr * n;
+                            const float xi = sG[iq < n ? iq : 0];
+                            const float cA = pr == 0 ? d000 : (pr == 1 ? d001 : (pr == 2 ? d010 : d011));
+                            const float cB = pr == 0 ? d100 : (pr == 1 ? d101 : (pr == 2 ? d110 : d111));
+                            s1 = cA * (1.0f - xi) + cB * xi;
+                        }
+                        // along y: c0, c1 per (jq, iq) into the wavefront's LDS rows (every lane takes part in the shuffles)
+                        for (int e0 = 0; e0 < nn; e0 += 64) {
+                            const int e = e0 + lane < nn ? e0 + lane : nn - 1;
+                            const int jq = e / n, iq = e - jq * n;
+                            const float eta = sG[jq];
+                            const float c00 = __shfl(s1, iq, 64), c01 = __shfl(s1, n + iq, 64), c10 = __shfl(s1, 2 * n + iq, 64),
+                                        c11 = __shfl(s1, 3 * n + iq, 64);
                             const float c0 = c00 * (1.0f - eta) + c10 * eta;
                             const float c1 = c01 * (1.0f - eta) + c11 * eta;
-                            const float pv = c0 * (1.0f - zeta) + c1 * zeta;
-                            if (pv >= iso) part += Q.w;
+                            if (e0 + lane < nn) { sC[wave][0][e] = c0; sC[wave][1][e] = c1; }
+                        }
+                        // along z, per point (the wavefront's LDS operations complete in order: the rows are there)
+                        for (int p = lane; p < npts; p += 64) {
+                            const float4 Q = sQ[p];
+                            const int ij = __float_as_int(Q.z);
+                            const float zeta = Q.x;
+                            const float pv = sC[wave][0][ij] * (1.0f - zeta) + sC[wave][1][ij] * zeta;
+                            if (pv >= iso) part += Q.y;
                         }
                     } else {
                         for (int p = lane; p < npts; p += 64) {
@@ -497,8 +531,8 @@ __global__ void __launch_bounds__(256) volume_rowwave_kernel(const float* __rest
                     part = wave_sum_f32(part);
                     if (lane == src) v = part;
                 }
+                psum += wave_sum_f32(v);
             }
-            psum += wave_sum_f32(v);
         }
         if (lane == 0) partial[row] = psum;
     }
@@ -540,6 +574,11 @@ __global__ void __launch_bounds__(256) volume_narrow_kernel(const float* __restr
     }
 }
 
+static int vol_grid()
+{
+    static const int g = getenv("R2S_VOL_GRID") ? atoi(getenv("R2S_VOL_GRID")) : 2048;
+    return g > 0 ? g : 2048;
+}
 struct VolumeWork {
     DevBuf partial, result, segmn, segmx, qpts, live[2], cnt, cfull;
     float qpts_jac = -1.0f;             // the Jacobian the point table was built with
@@ -617,7 +656,8 @@ struct VolumeWork {
             int rc = points(jac, st);
             if (rc) return rc;
         }
-        volume_rowwave_kernel<<<std::min((nrows + 3) / 4, 16384), 256, 0, st>>>(
+        // (a fixed grid of persistent workgroups: each sets up the quadrature tables once and takes rows in turn)
+        volume_rowwave_kernel<<<std::min((nrows + 3) / 4, vol_grid()), 256, 0, st>>>(
             d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>(), 0, nrows, segs ? segmn.as<float>() : nullptr,
             segs ? segmx.as<float>() : nullptr, qpts.as<float4>(), listed ? live[cur].as<int>() : nullptr,
             listed ? cnt.as<uint32_t>() + cur : nullptr);
@@ -2756,7 +2796,7 @@ int rbf_smooth_slabs(const std::vector<Slab>& S, const r2s_grid* g, int is_inter
                 if (kc1 <= d.k0) continue;
                 const int row0 = d.k0 * (ny - 1), nr = (kc1 - d.k0) * (ny - 1);
                 SLAB_HIP(hipSetDevice(d.device));
-                volume_rowwave_kernel<<<std::min((nr + 3) / 4, 16384), 256, 0, d.stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, th, 0.0f, elvol, jac,
+                volume_rowwave_kernel<<<std::min((nr + 3) / 4, vol_grid()), 256, 0, d.stream>>>(vptr(blsf.at<float>(q), q), nx, ny, nz, th, 0.0f, elvol, jac,
                                                                                           vw[q].q, brows.at<float>(q), row0, nr, bsegmn.at<float>(q),
                                                                                           bsegmx.at<float>(q), vw[q].qpts.as<float4>(), nullptr, nullptr);
                 if (q != q0)

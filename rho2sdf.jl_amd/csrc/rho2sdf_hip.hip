@@ -1292,7 +1292,8 @@ struct IsoCoefPad {
 __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler* __restrict__ strag, uint32_t strag_cap,
                                                            const uint32_t* __restrict__ strag_cnt, const ElemRec* __restrict__ erec,
                                                            double rho_t, double* __restrict__ res, double* __restrict__ res_xp,
-                                                           const uint32_t* __restrict__ abort_flag, uint32_t* __restrict__ head)
+                                                           const uint32_t* __restrict__ abort_flag, uint32_t* __restrict__ head,
+                                                           uint32_t* __restrict__ n_fail)
 {
     if (*abort_flag) return;
     __shared__ IsoCoefPad coef[64];
@@ -1320,6 +1321,11 @@ __global__ void __launch_bounds__(64, 2) iso_straggler_kernel(const IsoStraggler
         if (m_busy == 0 || __popcll(m_done) >= R2S_STRAG_REFILL_MIN ||
             (!exhausted && (uint32_t)__popcll(m_busy) + refill_min <= quota &&
              (uint32_t)__popcll(__ballot(s.phase == FS_IDLE)) + (quota < 64u ? (uint32_t)__popcll(m_done) : 0u) >= refill_min)) {
+            {   // runs that ended without a KKT point (the nearest on-surface iterate is used, as the reference uses
+                // whatever NLopt returns, ComputeCoordsOnIso.jl:79-86): counted for r2s_stats
+                const uint64_t mf = __ballot(s.phase == FS_DONE && s.it > R2S_ISO_MAXIT);
+                if (mf && lane == (uint32_t)__builtin_ctzll(mf)) atomicAdd(n_fail, (uint32_t)__popcll(mf));
+            }
             if (s.phase == FS_DONE) {
                 const ElemRec& E = erec[my_el];
                 double N[8], xp[3];
@@ -1432,7 +1438,7 @@ __global__ void __launch_bounds__(256) iso_sweep_kernel(const BandItem* __restri
                                                         const uint32_t* __restrict__ perm, const ElemRec* __restrict__ erec,
                                                         GridDev g, SlabInfo sl, double rho_t, double* __restrict__ res,
                                                         double* __restrict__ res_xp, const uint32_t* __restrict__ strag_cnt,
-                                                        const uint32_t* __restrict__ abort_flag)
+                                                        const uint32_t* __restrict__ abort_flag, uint32_t* __restrict__ n_fail)
 {
     if (*abort_flag || *strag_cnt == 0u) return;   // (strag_cnt: the overflow flag)
     const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
@@ -1462,7 +1468,7 @@ __global__ void __launch_bounds__(256) iso_sweep_kernel(const BandItem* __restri
             K.C[k][0] = E.C[k][0]; K.C[k][1] = E.C[k][1]; K.C[k][2] = E.C[k][2];
             K.Cr[k] = E.Cr[k];
         }
-        iso_project_full(K, fmax(fabs(E.rmax), fabs(E.rmin)), x, rho_t, xi);
+        if (iso_project_full(K, fmax(fabs(E.rmax), fabs(E.rmin)), x, rho_t, xi) > R2S_ISO_MAXIT) atomicAdd(n_fail, 1u);
         double N[8], xp[3];
         hex8_shape(xi, N);
 #pragma unroll
@@ -2425,9 +2431,9 @@ static int iso_project_hex(r2s_plan* P, hipStream_t st, uint32_t n_items, uint32
     P->fast_timed = true;
     // two persistent wavefronts per SIMD pull entries from the list (counters[14]); those that find none leave at once
     static const int strag_wpc = getenv("R2S_STRAG_WPC") ? std::min(std::max(atoi(getenv("R2S_STRAG_WPC")), 1), 32) : 8;   // tuning knob (4-16: +-1 %)
-    iso_straggler_kernel<<<(uint32_t)P->n_cu * (uint32_t)strag_wpc, 64, 0, st>>>(list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, counters + 14);
+    iso_straggler_kernel<<<(uint32_t)P->n_cu * (uint32_t)strag_wpc, 64, 0, st>>>(list, cap, counters + 12, erec, rho_t, res, res_xp, abort_flag, counters + 14, counters + 16);
     iso_sweep_kernel<<<(uint32_t)P->n_cu * 2u, 256, 0, st>>>(items, n_items, chunk_off, n_chunks, perm, erec, g, s, rho_t, res, res_xp,
-                                                             counters + 13, abort_flag);
+                                                             counters + 13, abort_flag, counters + 16);
     return 0;
 }
 
@@ -2509,7 +2515,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     ENSURE(P->active_tri, sizeof(uint32_t) * (size_t)ntiles);
     ENSURE(P->tri, (size_t)ntiles + 1);
     ENSURE(P->hot, (size_t)ntiles + 1);
-    ENSURE(P->counters, 64);
+    ENSURE(P->counters, 128);
     uint32_t* counters = P->counters.as<uint32_t>();  // [0] bad IEN flag, [1] band tiles, [2] sign tiles, [15] abort flag
     const uint32_t* abort_flag = counters + 15;
     // ---- speculation on the sizes the host used to wait for (see read_back_kernel) ----
@@ -2531,7 +2537,7 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     HIP_TRY(hipEventRecord(P->ev[0], st));
     // ---- node -> element CSR (second stream) beside the element records, classes, item counts ----
     zero_many(st, {{P->deg.p, sizeof(uint32_t) * (size_t)(nnp + 1)}, {P->cursor.p, sizeof(uint32_t) * (size_t)(nnp + 1)},
-                   {counters, 64}, {P->nitems.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
+                   {counters, 128}, {P->nitems.p, sizeof(uint32_t) * (size_t)(nel + 1)}});
     HIP_TRY(hipEventRecord(P->ev2[0], st));
     // (host order: the long kernel of this stream first, then the chain of short ones for the other stream)
     elem_prep_kernel<ET><<<(unsigned)((nel + 127) / 128), 128, 0, st>>>(
@@ -2930,6 +2936,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
     {
         ReadBack rb3;   // the abort flag travels with the sizes
         rb3.add(counters + 15, 1, 16);
+        rb3.add(counters + 16, 1, 17);   // [16] runs of the complete solver that ended without a KKT point
+        rb3.add(counters + 12, 1, 18);   // [12] pairs the fast lane machine handed over
         SpecExpect none;
         memset(&none, 0, sizeof none);
         read_back_kernel<<<1, 64, 0, st>>>(rb3, P->d_pinned, none, counters + 15);
@@ -2968,6 +2976,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         stats->n_active_sign_tiles = n_active_sign;
         stats->n_any_tiles = P->last_n_any;
         stats->n_sign_only_tiles = P->last_n_sonly;
+        stats->n_iso_fail = P->h_pinned[17];
+        stats->n_iso_straggler = P->h_pinned[18];
         float ms = 0;
         if (hipEventElapsedTime(&ms, P->ev[0], P->ev[1]) == hipSuccess) stats->ms_prep = ms;
         if (hipEventElapsedTime(&ms, P->ev[1], P->ev[2]) == hipSuccess) stats->ms_bins = ms;

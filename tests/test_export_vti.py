@@ -254,3 +254,67 @@ def test_mat_import(pkg, tmp_path, compress):
         pkg.MeshInformations(p)
     with pytest.raises(pkg._lib.R2SError, match="MAT file not found"):
         pkg.MeshInformations(str(tmp_path / "none.mat"))
+
+
+def _read_vti_stdlib(path):
+    """A reader that shares nothing with the library: the XML head through xml.etree, the appended block by the VTK XML
+    rules (header_type words; vtkZLibDataCompressor: [blocks, block size, last block size, compressed sizes...] then the
+    zlib streams).  What WriteVTK 1.21 writes for `vtk_grid(name, x, y, z)` + `vtk_point_data` (ExportToVTI.jl:55-64):
+    ImageData, version 1.0, LittleEndian, UInt64 headers, one appended raw block per array, offset 0 for the first."""
+    import xml.etree.ElementTree as ET
+    import zlib
+    raw = open(path, "rb").read()
+    cut = raw.index(b'<AppendedData')
+    tag_end = raw.index(b">", cut) + 1
+    root = ET.fromstring(raw[:tag_end] + b"</AppendedData></VTKFile>")
+    assert raw[tag_end:tag_end + 2] == b"\n_"
+    payload = raw[tag_end + 2:]
+    assert root.tag == "VTKFile" and root.attrib["type"] == "ImageData" and root.attrib["version"] == "1.0"
+    assert root.attrib["byte_order"] == "LittleEndian" and root.attrib["header_type"] == "UInt64"
+    img = root.find("ImageData")
+    piece = img.find("Piece")
+    arrays = piece.find("PointData").findall("DataArray")
+    assert len(arrays) == 1 and piece.find("CellData") is None
+    da = arrays[0].attrib
+    assert da["format"] == "appended" and da["offset"] == "0"
+    assert root.find("AppendedData").attrib["encoding"] == "raw"
+    dt = {"Float32": "<f4", "Float64": "<f8"}[da["type"]]
+    if root.attrib.get("compressor") == "vtkZLibDataCompressor":
+        nblocks, bsize, last = (int(v) for v in np.frombuffer(payload[:24], dtype="<u8"))
+        csizes = [int(v) for v in np.frombuffer(payload[24:24 + 8 * nblocks], dtype="<u8")]
+        pos, out = 24 + 8 * nblocks, b""
+        for b, cs in enumerate(csizes):
+            blk = zlib.decompress(payload[pos:pos + cs])
+            assert len(blk) == (bsize if b < nblocks - 1 or last == 0 else last)
+            out += blk
+            pos += cs
+        data, rest = np.frombuffer(out, dtype=dt), payload[pos:]
+    else:
+        assert "compressor" not in root.attrib
+        nbytes = int(np.frombuffer(payload[:8], dtype="<u8")[0])
+        data, rest = np.frombuffer(payload[8:8 + nbytes], dtype=dt), payload[8 + nbytes:]
+    assert rest.strip() == b"</AppendedData>\n</VTKFile>".replace(b"\n", b"") or rest.split() == [b"</AppendedData>", b"</VTKFile>"]
+    return img.attrib, piece.attrib, da, data
+
+
+@pytest.mark.parametrize("compress", [0, 1])
+@pytest.mark.parametrize("smooth,dtype", [(None, np.float64), (2, np.float32)])
+def test_vti_independent_reader(pkg, tmp_path, smooth, dtype, compress):
+    """f3: the .vti as a foreign reader sees it - extents, origin, spacing (printed as Float64 whatever the array's type: the
+    coordinates are `range(origin, step=spacing)` of Float64, ExportToVTI.jl:50-52), array name / type, block
+    sizes and the payload bytes, raw and zlib-compressed"""
+    g = pkg.Grid(np.array([-1.0, 0.5, 2.0]), np.array([3.0, 2.5, 2.75]), 9, 2)
+    s = smooth or 1
+    dims = tuple(int(n) * s + 1 for n in g.c.N)
+    rng = np.random.default_rng(11)
+    vals = np.round(rng.normal(size=dims[2] * dims[1] * dims[0]), 2).astype(dtype)   # (compressible)
+    path = pkg.exportSdfToVTI(str(tmp_path / "f"), g, vals.reshape(dims[2], dims[1], dims[0]), "distance", smooth, compress)
+    img, piece, da, data = _read_vti_stdlib(path)
+    ext = f"0 {dims[0] - 1} 0 {dims[1] - 1} 0 {dims[2] - 1}"
+    assert img["WholeExtent"] == ext and piece["Extent"] == ext
+    assert [float(v) for v in img["Origin"].split()] == [float(v) for v in g.AABB_min]
+    assert [float(v) for v in img["Spacing"].split()] == [g.cell_size / s] * 3
+    # Float64 text: 17 significant digits round-trip, also when the field itself is Float32
+    assert all(repr(float(v)) == repr(float(w)) for v, w in zip(img["Origin"].split(), g.AABB_min))
+    assert da["Name"] == "distance" and da["type"] == ("Float32" if dtype == np.float32 else "Float64")
+    assert data.tobytes() == vals.tobytes()
