@@ -188,6 +188,12 @@ int r2s_rho2sdf(const double *X, int64_t nnp, const int64_t *IEN, int64_t nel, c
  * at PCIe rate with no staging.  Any other host pointer works too (staged, multi-threaded).  The fused field of
  * r2s_sdf (one device, >= 4 M voxels) does not cross PCIe whole: host threads write the sentinel -1e10 into the caller's
  * array while the device works and only the tiles that can differ from it are transferred (R2S_HOST_SPARSE=0: dense). */
+/* Host phases of the calling thread's last host-pointer SDF call on ONE device (r2s_eval_distances / r2s_sign_detection /
+ * r2s_sdf), in ms: [0] upload of the mesh, [1] run (launches + the waits of the plan), [2] packing of the non-sentinel tiles
+ * and issue of their copies, [3] wait for the host threads' sentinel fill, [4] wait for the copies, [5] scatter into the
+ * caller's array (dense download: the whole transfer), [6] the whole call, [7] host threads used.  A diagnostic: where the
+ * end-to-end time of a call went (the sparse download's floor is the host's DRAM write bandwidth, not the GPU). */
+void r2s_last_host_phases(double out[8]);
 void *r2s_host_alloc(size_t bytes);
 void r2s_host_free(void *p);
 

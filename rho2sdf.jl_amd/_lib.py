@@ -110,6 +110,7 @@ SYMBOLS = [
     ("r2s_default_options", None, [ctypes.POINTER(R2SOptions)]),
     ("r2s_rho2sdf", ctypes.c_int, _MESH + [c_double_p, ctypes.POINTER(R2SOptions), ctypes.POINTER(R2SGrid), c_double_p,
                                            c_double_p, c_double_p, c_float_p, ctypes.POINTER(R2SRunInfo)]),
+    ("r2s_last_host_phases", None, [c_double_p]),
     ("r2s_host_alloc", ctypes.c_void_p, [ctypes.c_size_t]),
     ("r2s_host_free", None, [ctypes.c_void_p]),
     ("r2s_remove_artifacts", ctypes.c_int, [c_double_p, ctypes.POINTER(R2SGrid), ctypes.c_double, ctypes.c_double,

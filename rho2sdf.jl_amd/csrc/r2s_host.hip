@@ -238,6 +238,10 @@ bool is_pinned(const void* p)
     return a.type == hipMemoryTypeHost;
 }
 
+// host phases of the calling thread's last r2s_sdf-type call (r2s_last_host_phases): upload, run (kernels, host waits),
+// pack + copies issued, wait for the sentinel fill, wait for the pieces, scatter, whole call [ms], fill threads
+thread_local double g_phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 struct Segment {   // one contiguous piece of a result: device source -> host destination
     char* dst;
     const char* src;
@@ -509,6 +513,11 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
             fprintf(stderr, "[r2s host] upload %.2f run %.2f pack+copy (%.1f MB) %.2f wait for the fill %.2f scatter %.2f ms, %d threads\n",
                     t1 - t0, t2 - t1, bytes / 1e6, t3 - t2, t4 - t3, now_ms() - t4, S->pool->size()),
             fprintf(stderr, "[r2s host]   waiting for the pieces %.2f, scattering %.2f ms\n", t_ev, t_sc);
+        {
+            const double t5 = now_ms();
+            const double ph[8] = {t1 - t0, t2 - t1, t3 - t2, t4 - t3, t_ev, t_sc, t5 - t0, (double)S->pool->size()};
+            memcpy(g_phases, ph, sizeof ph);
+        }
         if (ms3) { ms3[0] = t1 - t0; ms3[1] = t2 - t1; ms3[2] = now_ms() - t2; }
         return 0;
     }
@@ -519,6 +528,11 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
             layer_segments(c.grid, G, r, (const char*)S->out[i].p, (char*)host[i], eb, segs, nullptr);
             if ((rc = download(S, segs, is_pinned(host[i])))) return rc;
         }
+    {
+        const double t5 = now_ms();
+        const double ph[8] = {t1 - t0, t2 - t1, 0.0, 0.0, 0.0, t5 - t2, t5 - t0, 0.0};   // (dense download: all of it under "scatter")
+        memcpy(g_phases, ph, sizeof ph);
+    }
     if (ms3) { ms3[0] = t1 - t0; ms3[1] = t2 - t1; ms3[2] = now_ms() - t2; }
     return 0;
 }
@@ -594,6 +608,11 @@ void release_host_sessions()
 }  // namespace r2s_int
 
 extern "C" {
+
+void r2s_last_host_phases(double out[8])
+{
+    if (out) memcpy(out, g_phases, sizeof g_phases);
+}
 
 void* r2s_host_alloc(size_t bytes)
 {

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -160,6 +161,122 @@ __global__ void ccl_flip_kernel(double* __restrict__ sdf, const uint32_t* __rest
     }
 }
 
+// ---- single device: the same labelling with less traffic around it ------------------------------------------------
+// (the Z-slab version below keeps the kernels above: it merges labels over the slab interfaces through root[] / size[])
+// * the heads that are their own root are listed as they are found (a few hundred components), their size counters
+//   zeroed there: no 0.5 GB memset, and the largest size / smallest root having it / interior count come from the list
+//   in one small kernel instead of two sweeps over 134 M counters;
+// * no root[] array: the count and the flip read a voxel's root through L[L[v]] (the second read hits the head's line).
+__global__ void __launch_bounds__(256) ccl_compress_heads_roots_kernel(uint32_t* __restrict__ L, uint32_t n, int nx, uint32_t* __restrict__ size,
+                                                                      uint32_t* __restrict__ roots, uint32_t roots_cap,
+                                                                      uint32_t* __restrict__ nroots)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    if (L[v] == NOLABEL) return;
+    const bool head = (threadIdx.x & 63) == 0 || v % (uint32_t)nx == 0u || L[v - 1] == NOLABEL;
+    if (head) {
+        const uint32_t r = uf_find(L, v);
+        if (r != v) {
+            __hip_atomic_store(L + v, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an ancestor: walks through v stay valid)
+        } else {
+            size[v] = 0u;
+            const uint32_t at = atomicAdd(nroots, 1u);
+            if (at < roots_cap) roots[at] = v;
+        }
+    }
+}
+// sizes only (ccl_flatten_count_kernel without the root[] array)
+__global__ void __launch_bounds__(256) ccl_count_kernel(const uint32_t* __restrict__ L, uint32_t n, uint32_t* __restrict__ size)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t cur = NOLABEL, cnt = 0;   // wave-uniform
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint64_t v = base + threadIdx.x;
+        uint32_t r = (v < n) ? L[v] : NOLABEL;
+        if (r != NOLABEL)
+            while (L[r] != r) r = L[r];
+        bool pending = r != NOLABEL;
+        while (__any(pending)) {
+            const unsigned long long todo = __ballot(pending);
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lr = __shfl(r, leader, 64);
+            const unsigned long long same = __ballot(pending && r == lr);
+            const uint32_t c = (uint32_t)__popcll(same);
+            if (lr == cur) {
+                cnt += c;
+            } else {
+                if (cnt && lane == 0) atomicAdd(&size[cur], cnt);
+                cur = lr;
+                cnt = c;
+            }
+            if (r == lr) pending = false;
+        }
+    }
+    if (cnt && lane == 0) atomicAdd(&size[cur], cnt);
+}
+// counters: [0] largest size, [1] smallest root having it, [3] interior count - from the list of roots (one workgroup)
+__global__ void __launch_bounds__(1024) ccl_roots_max_kernel(const uint32_t* __restrict__ size, const uint32_t* __restrict__ roots,
+                                                            const uint32_t* __restrict__ nroots, uint32_t* __restrict__ counters)
+{
+    __shared__ uint32_t s_max, s_arg, s_sum;
+    if (threadIdx.x == 0) { s_max = 0u; s_arg = NOLABEL; s_sum = 0u; }
+    __syncthreads();
+    const uint32_t m = *nroots;
+    uint32_t mx = 0, sum = 0;
+    for (uint32_t q = threadIdx.x; q < m; q += blockDim.x) {
+        const uint32_t sz = size[roots[q]];
+        mx = sz > mx ? sz : mx;
+        sum += sz;
+    }
+    atomicMax(&s_max, mx);
+    atomicAdd(&s_sum, sum);
+    __syncthreads();
+    const uint32_t gmax = s_max;
+    uint32_t arg = NOLABEL;
+    for (uint32_t q = threadIdx.x; q < m; q += blockDim.x) {
+        const uint32_t r = roots[q];
+        if (gmax && size[r] == gmax && r < arg) arg = r;
+    }
+    atomicMin(&s_arg, arg);
+    __syncthreads();
+    if (threadIdx.x == 0) { counters[0] = s_max; counters[1] = s_arg; counters[3] = s_sum; }
+}
+__global__ void ccl_flip_l_kernel(double* __restrict__ sdf, const uint32_t* __restrict__ L, const uint32_t* __restrict__ size, uint32_t n,
+                                  uint32_t largest_root, uint32_t min_size, uint32_t* __restrict__ counters)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    bool flip = false;
+    if (v < n) {
+        uint32_t r = L[v];
+        if (r != NOLABEL) {
+            while (L[r] != r) r = L[r];   // (head -> root: one step after ccl_compress_heads_roots_kernel)
+            flip = r != largest_root && size[r] < min_size;   // SdfArtifactRemoval.jl:220
+        }
+        if (flip) sdf[v] = -fabs(sdf[v]);                     // :234
+    }
+    const unsigned long long m = __ballot(flip);
+    if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&counters[2], (uint32_t)__popcll(m));
+}
+
+// the work arrays of remove_artifacts_dev, kept between calls per device (r2s_release_cache frees them): allocating and
+// freeing 1.6 GB per call cost as much as a kernel of the stage
+struct CclWork {
+    DevBuf L, size, roots, cnt;
+};
+static std::mutex g_ccl_mutex;
+static std::map<int, CclWork> g_ccl_work;
+static void release_ccl_work()
+{
+    std::lock_guard<std::mutex> lock(g_ccl_mutex);
+    for (auto& kv : g_ccl_work) {
+        (void)hipSetDevice(kv.first);
+        kv.second.L.release(); kv.second.size.release(); kv.second.roots.release(); kv.second.cnt.release();
+    }
+    g_ccl_work.clear();
+}
+
 static int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, double min_ratio,
                                 hipStream_t st, int64_t* n_flipped)
 {
@@ -167,40 +284,52 @@ static int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double thresho
     if (n64 <= 0 || n64 >= 0xFFFFFFFFll) return fail(R2S_ERR_ARG, "grid too large for 32-bit labels");
     const uint32_t n = (uint32_t)n64;
     const int nx = (int)g->N[0] + 1, ny = (int)g->N[1] + 1, nz = (int)g->N[2] + 1;
-    DevBuf L, root, size, cnt;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_ccl_mutex);   // (one call at a time uses the device's work arrays)
+    CclWork& Wk = g_ccl_work[dev];
+    DevBuf &L = Wk.L, &size = Wk.size, &roots = Wk.roots, &cnt = Wk.cnt;
+    // roots_cap: a component has a head that is its own root; more roots than this (noise at the voxel scale) -> the counters
+    // of the overflow are still zeroed, only the list is short: the sweeps over all counters take over (below)
+    const uint32_t roots_max = 1u << 22;
+    const char* cap_env = getenv("R2S_CCL_ROOTS_CAP");   // (tests: a short list exercises the overflow path)
+    const uint32_t roots_cap = cap_env && atoi(cap_env) > 0 ? std::min<uint32_t>((uint32_t)atoi(cap_env), roots_max) : roots_max;
     ENSURE(L, sizeof(uint32_t) * (size_t)n);
-    ENSURE(root, sizeof(uint32_t) * (size_t)n);
     ENSURE(size, sizeof(uint32_t) * (size_t)n);
+    ENSURE(roots, sizeof(uint32_t) * (size_t)roots_max);
     ENSURE(cnt, 64);
-    auto cleanup = [&]() { L.release(); root.release(); size.release(); cnt.release(); };
     const unsigned nb = (n + 255) / 256;
-    uint32_t h[4] = {0, NOLABEL, 0, 0};
-    hipError_t e = hipMemcpyAsync(cnt.p, h, sizeof h, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(size.p, 0, sizeof(uint32_t) * (size_t)n, st);
-    if (e != hipSuccess) { cleanup(); return fail(R2S_ERR_HIP, "%s", hipGetErrorString(e)); }
+    uint32_t h[8] = {0, NOLABEL, 0, 0, 0, 0, 0, 0};   // [4]: number of roots
+    HIP_TRY(hipMemcpyAsync(cnt.p, h, sizeof h, hipMemcpyHostToDevice, st));
     ccl_init_kernel<<<nb, 256, 0, st>>>(d_sdf, n, nx, threshold, L.as<uint32_t>());
     ccl_union_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), nx, ny, nz);
-    ccl_compress_heads_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), n, nx);
-    ccl_flatten_count_kernel<<<(nb < 4096u ? nb : 4096u), 256, 0, st>>>(L.as<uint32_t>(), n, root.as<uint32_t>(), size.as<uint32_t>());
-    ccl_max_kernel<<<nb, 256, 0, st>>>(size.as<uint32_t>(), n, cnt.as<uint32_t>());
-    ccl_argmax_kernel<<<nb, 256, 0, st>>>(size.as<uint32_t>(), n, cnt.as<uint32_t>());
-    e = hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { cleanup(); return fail(R2S_ERR_HIP, "%s", hipGetErrorString(e)); }
+    ccl_compress_heads_roots_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), n, nx, size.as<uint32_t>(), roots.as<uint32_t>(), roots_cap,
+                                                       cnt.as<uint32_t>() + 4);
+    ccl_count_kernel<<<(nb < 4096u ? nb : 4096u), 256, 0, st>>>(L.as<uint32_t>(), n, size.as<uint32_t>());
+    ccl_roots_max_kernel<<<1, 1024, 0, st>>>(size.as<uint32_t>(), roots.as<uint32_t>(), cnt.as<uint32_t>() + 4, cnt.as<uint32_t>());
+    HIP_TRY(hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h[4] > roots_cap) {   // (noise at the voxel scale: more components than the list holds - the sweeps over all counters)
+        uint32_t h0[8] = {0, NOLABEL, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(cnt.p, h0, sizeof h0, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(size.p, 0, sizeof(uint32_t) * (size_t)n, st));
+        ccl_count_kernel<<<(nb < 4096u ? nb : 4096u), 256, 0, st>>>(L.as<uint32_t>(), n, size.as<uint32_t>());
+        ccl_max_kernel<<<nb, 256, 0, st>>>(size.as<uint32_t>(), n, cnt.as<uint32_t>());
+        ccl_argmax_kernel<<<nb, 256, 0, st>>>(size.as<uint32_t>(), n, cnt.as<uint32_t>());
+        HIP_TRY(hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     int64_t flipped = 0;
     if (h[3] != 0) {   // interior_count == 0 -> nothing to do (:150-153)
         // min_component_size = max(1, round(Int, ratio*largest)), Julia round = ties to even (:206)
         long long ms = (long long)std::nearbyint(min_ratio * (double)h[0]);
         if (ms < 1) ms = 1;
         const uint32_t min_size = ms > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)ms;
-        ccl_flip_kernel<<<nb, 256, 0, st>>>(d_sdf, root.as<uint32_t>(), size.as<uint32_t>(), n, h[1], min_size,
-                                          cnt.as<uint32_t>());
-        e = hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { cleanup(); return fail(R2S_ERR_HIP, "%s", hipGetErrorString(e)); }
+        ccl_flip_l_kernel<<<nb, 256, 0, st>>>(d_sdf, L.as<uint32_t>(), size.as<uint32_t>(), n, h[1], min_size, cnt.as<uint32_t>());
+        HIP_TRY(hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         flipped = h[2];
     }
-    cleanup();
     if (n_flipped) *n_flipped = flipped;
     return 0;
 }
@@ -576,8 +705,8 @@ __global__ void __launch_bounds__(256) volume_narrow_kernel(const float* __restr
 
 static int vol_grid()
 {
-    static const int g = getenv("R2S_VOL_GRID") ? atoi(getenv("R2S_VOL_GRID")) : 2048;
-    return g > 0 ? g : 2048;
+    static const int g = getenv("R2S_VOL_GRID") ? atoi(getenv("R2S_VOL_GRID")) : 16384;
+    return g > 0 ? g : 16384;
 }
 struct VolumeWork {
     DevBuf partial, result, segmn, segmx, qpts, live[2], cnt, cfull;
@@ -656,7 +785,7 @@ struct VolumeWork {
             int rc = points(jac, st);
             if (rc) return rc;
         }
-        // (a fixed grid of persistent workgroups: each sets up the quadrature tables once and takes rows in turn)
+        // (a bounded grid: workgroups set up the quadrature tables once and take rows in turn; 16 384 measured best at 512^3)
         volume_rowwave_kernel<<<std::min((nrows + 3) / 4, vol_grid()), 256, 0, st>>>(
             d_sdf, nx, ny, nz, shift, iso, elvol, jac, q, partial.as<float>(), 0, nrows, segs ? segmn.as<float>() : nullptr,
             segs ? segmx.as<float>() : nullptr, qpts.as<float4>(), listed ? live[cur].as<int>() : nullptr,
@@ -2944,6 +3073,7 @@ void r2s_release_cache(void)
         std::lock_guard<std::mutex> lock(g_rbf_kv_mutex);
         g_rbf_kv.release();
     }
+    release_ccl_work();
     r2s_int::release_host_sessions();
 }
 

@@ -89,6 +89,34 @@ def test_remove_artifacts(pkg, oracle):
         pkg.remove_sdf_artifacts(np.zeros(7), pg)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap", [None, "16"])
+def test_remove_artifacts_many_components(pkg, oracle, monkeypatch, cap):
+    """a noisy field: thousands of components of all sizes, ties in the largest size, components cut by the 64-voxel
+    pieces of the labelling; with a short list of roots (R2S_CCL_ROOTS_CAP) the sweeps over all counters take over"""
+    if cap:
+        monkeypatch.setenv("R2S_CCL_ROOTS_CAP", cap)
+    rng = np.random.default_rng(23)
+    pg = pkg.Grid(np.zeros(3), np.array([2.0, 1.3, 0.9]), 70, 1)
+    og = oracle.grid_make(np.zeros(3), np.array([2.0, 1.3, 0.9]), 70, 1)
+    nx, ny, nz = pg.dims
+    f = rng.normal(size=(nz, ny, nx))
+    for ax in range(3):                                   # a little smoothing: components of many sizes
+        f = f + np.roll(f, 1, axis=ax)
+    sdf = (f - 0.8).ravel()
+    for ratio in (0.01, 0.5):
+        a, b = sdf.copy(), sdf.copy()
+        na = pkg.remove_sdf_artifacts(a, pg, min_component_ratio=ratio)
+        nb = oracle.remove_artifacts(b, og, 0.0, ratio)
+        assert na == nb > 0 and np.array_equal(a, b)
+    two = -np.ones((nz, ny, nx))                          # two components of the same (largest) size: the first one stays
+    two[1:3, 1:3, 1:3] = 1.0
+    two[5:7, 5:7, 5:7] = 1.0
+    a, b = two.ravel().copy(), two.ravel().copy()
+    assert pkg.remove_sdf_artifacts(a, pg, min_component_ratio=2.0) == oracle.remove_artifacts(b, og, 0.0, 2.0)
+    assert np.array_equal(a, b)
+
+
 def _set_rbf_mode(monkeypatch, mode, names=("R2S_RBF_MATVEC", "R2S_RBF_APPLY")):
     """mode "walk" = the default kernels (row walk, r2s_rbf_walk.hpp): no environment override"""
     for name in names:

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/e2eprof
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2eprof -- python3 $ROOT/tools/e2e_wall.py > $OUT/e2e_wall_trace.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2eprof -- python3 $ROOT/tools/e2e_wall.py > $OUT/e2e_wall_trace.txt
 cp $(ls $OUT/e2eprof/*/*kernel_stats.csv | head -1) $OUT/e2e_stats.csv
 cp $(ls $OUT/e2eprof/*/*kernel_trace.csv | head -1) $OUT/e2e_trace.csv
 rm -rf $OUT/e2eprof
