@@ -1801,7 +1801,7 @@ __global__ void __launch_bounds__(256) cg_update_xr_dot_kernel(float* __restrict
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 // r -= alpha q and the parts of dot(r, r): cg_update_xr_dot_kernel without the weights' step (which the next product takes
-// over, RbfWalkArgs::wacc) - the same grid, assignment and order of additions
+// over, cg_update_wu_kernel) - the same grid, assignment and order of additions
 __global__ void __launch_bounds__(256) cg_update_r_dot_kernel(float* __restrict__ r, const float* __restrict__ q, float alpha, int64_t plane,
                                                              double* __restrict__ partial)
 {
@@ -1822,6 +1822,26 @@ __global__ void __launch_bounds__(256) cg_update_r_dot_kernel(float* __restrict_
         __syncthreads();
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// w += alpha_prev u (the step of the previous iteration) and u = r + beta u in one pass (16 bytes read, 8 written per voxel)
+__global__ void __launch_bounds__(256) cg_update_wu_kernel(float* __restrict__ w, float* __restrict__ u, const float* __restrict__ r,
+                                                          float alpha_prev, float beta, int64_t n)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        float4 W = *(const float4*)(w + i), U = *(const float4*)(u + i);
+        const float4 Rr = *(const float4*)(r + i);
+        W.x += alpha_prev * U.x; W.y += alpha_prev * U.y; W.z += alpha_prev * U.z; W.w += alpha_prev * U.w;
+        U.x = Rr.x + beta * U.x; U.y = Rr.y + beta * U.y; U.z = Rr.z + beta * U.z; U.w = Rr.w + beta * U.w;
+        *(float4*)(w + i) = W;
+        *(float4*)(u + i) = U;
+    } else {
+        for (int64_t q = i; q < n; ++q) {
+            const float uo = u[q];
+            w[q] += alpha_prev * uo;
+            u[q] = r[q] + beta * uo;
+        }
+    }
 }
 __global__ void cg_axpy_kernel(float* __restrict__ x, const float* __restrict__ u, float alpha, int64_t n)
 {
@@ -1878,7 +1898,7 @@ static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
 }
 
 struct RbfWork {   // the device buffers of one rbf_smooth_host call
-    DevBuf b[35];
+    DevBuf b[34];
     VolumeWork vw;
     void release()
     {
@@ -1908,7 +1928,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
            &d_tx = W.b[8], &d_ty = W.b[9], &d_tz = W.b[10], &d_st = W.b[11], &d_cnt = W.b[12], &d_r = W.b[13], &d_u = W.b[14], &d_q = W.b[15],
            &d_part = W.b[16], &d_sum = W.b[17], &d_lut = W.b[18], &d_luta = W.b[19], &d_vx = W.b[20], &d_vy = W.b[21], &d_vz = W.b[22],
            &d_lutf = W.b[23], &d_fvx = W.b[24], &d_fvy = W.b[25], &d_fvz = W.b[26], &d_lv = W.b[27], &d_lvf = W.b[28], &d_luta16 = W.b[29],
-           &d_wt = W.b[30], &d_wa = W.b[31], &d_waf = W.b[32], &d_part2 = W.b[33], &d_u2 = W.b[34];
+           &d_wt = W.b[30], &d_wa = W.b[31], &d_waf = W.b[32], &d_part2 = W.b[33];
     VolumeWork& vw = W.vw;
     auto cleanup = [&]() {
         if (!ws) W.release();
@@ -2156,12 +2176,10 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         RbfWalkArgs WAr;
         const bool fused = !mv_env && LG.WT && walk_ok && rbf_walk_planes(LG, 0, -1, 0, -1, &WAr) && !getenv("R2S_RBF_CG_UNFUSED");
         if (fused) {
-            // the product kernel forms u = r + beta u_old itself (written to the other of two buffers), takes the weights' step
-            // of the PREVIOUS iteration (w += alpha u_old) and leaves the parts of dot(u, q); the residual's step and
-            // dot(r, r) are one more pass.  Same operations on the same numbers as the loop below, three passes fewer.
-            ENSURE_C(d_u2, sizeof(float) * (size_t)n);
+            // three passes per iteration: [w += alpha_prev u, u = r + beta u] (the weights take the step of the PREVIOUS
+            // iteration here, where u is read anyway), the product with the parts of dot(u, q), [r -= alpha q with the parts of
+            // dot(r, r)].  Same operations on the same numbers as the loop below (five passes).
             float* ucur = d_u.as<float>();
-            float* unext = d_u2.as<float>();
             float alpha_prev = 0.0f;
             auto r_dot = [&](float alpha, float* out) -> int {
                 cg_update_r_dot_kernel<<<nz * DOT_PARTS, 256, 0, st>>>(d_r.as<float>(), d_q.as<float>(), alpha, (int64_t)nx * ny, d_part.as<double>());
@@ -2174,9 +2192,8 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             };
             while (!(residual <= tol) && its < its_cap) {
                 const float beta = (residual * residual) / (prev * prev);
-                WAr.T = LG.WT; WAr.x = nullptr; WAr.y = d_q.as<float>(); WAr.dot_partial = d_part2.as<double>();
-                WAr.r = d_r.as<float>(); WAr.u_old = ucur; WAr.u_new = unext; WAr.wacc = d_w.as<float>();
-                WAr.beta = beta; WAr.alpha_prev = alpha_prev;
+                cg_update_wu_kernel<<<(unsigned)((n / 4 + 256) / 256), 256, 0, st>>>(d_w.as<float>(), ucur, d_r.as<float>(), alpha_prev, beta, n);
+                WAr.T = LG.WT; WAr.x = ucur; WAr.y = d_q.as<float>(); WAr.dot_partial = d_part2.as<double>();
                 rbf_walk_launch(0, RBF_NV, WAr, st);
                 float uq;
                 TRY_C(sum_parts2(&uq));
@@ -2186,7 +2203,6 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
                 residual = std::sqrt(rr);
                 its++;
                 alpha_prev = alpha;
-                std::swap(ucur, unext);
             }
             if (its > 0) cg_axpy_kernel<<<nb, 256, 0, st>>>(d_w.as<float>(), ucur, alpha_prev, n);   // the last iteration's step
         } else

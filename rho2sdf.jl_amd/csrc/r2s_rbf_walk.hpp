@@ -39,13 +39,6 @@ struct RbfWalkArgs {
     int L, nchunk, nxt;            // rows per walk, walks per plane, workgroups per row
     float add;                     // MODE 1: constant added to every output
     double* dot_partial;           // MODE 0: sum of x*y per workgroup [(k - k_begin) * nchunk * nxt + ...], or null
-    // the CG's vector updates folded into the product (single device, variant digit FUSE): the input vector is formed on the
-    // fly as u = r + beta u_old (and stored), and the weights take the step of the previous iteration, w += alpha_prev u_old
-    const float* r;
-    const float* u_old;
-    float* u_new;
-    float* wacc;
-    float beta, alpha_prev;
 };
 
 template <int R>
@@ -129,7 +122,6 @@ __device__ __forceinline__ float rbf_dpp_next(float v)
 template <int R, int D2, int MODE, int NV, int NW, int DPP>
 struct RbfWalk {
     static constexpr int W = 2 * R + 1;
-    static constexpr int FUSE = (DPP / 100) % 10;         // the CG's vector updates folded in (see RbfWalkArgs)
     static constexpr int WS = DPP ? 1 : W;                // shifted copies kept per window row
     static constexpr int OUTW = DPP ? 64 - 2 * R : 64;    // outputs per wavefront
     typedef typename std::conditional<MODE == 0, float, double>::type TE;
@@ -165,45 +157,18 @@ struct RbfWalk {
         uint32_t sdst[NROUND];    // ... and where they go in the LDS image
         rbf_u32x4 tv[NROUND];     // staged chunks in flight
         __amdgpu_buffer_rsrc_t rx;
-        // FUSE: r and u_old of the rows in flight (one per plane), the weights of the centre plane's row, their descriptors
-        float pr[FUSE ? W : 1], pu[FUSE ? W : 1], pw;
-        __amdgpu_buffer_rsrc_t rr, ru;
     };
 
     __device__ static __forceinline__ void load_row(const RbfWalkArgs& A, State& S, int p, int slot, int jrow)
     {
         const int jj = jrow < 0 ? 0 : (jrow >= A.ny ? A.ny - 1 : jrow);
         const int soff = (S.kp[p] * A.ny + jj) * A.nx * 4;
-        if constexpr (FUSE) {
-            S.pr[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rr, (int)S.xoff[R], soff, 0));
-            S.pu[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.ru, (int)S.xoff[R], soff, 0));
-        } else if constexpr (DPP) {
+        if constexpr (DPP) {
             S.xw[p][slot][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rx, (int)S.xoff[R], soff, 0));
         } else {
 #pragma unroll
             for (int d = 0; d < W; ++d)
                 S.xw[p][slot][d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(S.rx, (int)S.xoff[d], soff, 0));
-        }
-    }
-    // FUSE: the rows loaded by load_row (row jrow of every plane) enter the window as u = r + beta u_old; the centre plane's
-    // row is this workgroup's to store if it is one of its output rows [j0, j0 + Lc): u_new, and the weights' step
-    __device__ static __forceinline__ void finish_rows(const RbfWalkArgs& A, State& S, int slot, int jrow, int k, int j0, int Lc, int i, bool valid)
-    {
-        if constexpr (FUSE) {
-#pragma unroll
-            for (int p = 0; p < W; ++p) S.xw[p][slot][0] = S.pr[p] + A.beta * S.pu[p];
-            if (valid && jrow >= j0 && jrow < j0 + Lc) {
-                const int64_t o = ((int64_t)k * A.ny + jrow) * A.nx + i;
-                A.u_new[o] = S.xw[R][slot][0];
-                A.wacc[o] = S.pw + A.alpha_prev * S.pu[R];
-            }
-        }
-    }
-    __device__ static __forceinline__ void load_wacc(const RbfWalkArgs& A, State& S, int jrow, int k, int j0, int Lc, int i, bool valid)
-    {
-        if constexpr (FUSE) {
-            S.pw = 0.0f;
-            if (valid && jrow >= j0 && jrow < j0 + Lc) S.pw = A.wacc[((int64_t)k * A.ny + jrow) * A.nx + i];
         }
     }
     __device__ static __forceinline__ void table_fetch(const RbfWalkArgs& A, State& S, const uint8_t* sB, int sn)
@@ -311,10 +276,7 @@ struct RbfWalk {
                         for (int di = R - m; di <= R + m; ++di) acc += wq[g & 1][di][rr] * S.xw[p][(P + dj) % W][di];
                     }
                     // the plane's last row has been used: the slot of its dj = -R row takes the row of the next step
-                    if (row + 1 == NROW || RL.dk[row + 1] != p) {
-                        load_row(A, S, p, P % W, jnew);
-                        if (p == R) load_wacc(A, S, jnew, C.k, C.j0, C.Lc, C.i, C.valid);
-                    }
+                    if (row + 1 == NROW || RL.dk[row + 1] != p) load_row(A, S, p, P % W, jnew);
                 }
                 asm volatile("" : "+v"(acc));   // (pins the products of the group between the two barriers)
                 __builtin_amdgcn_sched_barrier(0);
@@ -402,12 +364,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DP
     const int64_t plane = (int64_t)A.nx * A.ny;
     {
         const int64_t avail = (int64_t)(A.xk_hi - kbase + 1) * plane * 4, want = (int64_t)W * plane * 4;
-        if constexpr (K::FUSE) {
-            S.rr = __builtin_amdgcn_make_buffer_rsrc((void*)(A.r + (int64_t)kbase * plane), 0, (int)(avail < want ? avail : want), 0x00020000);
-            S.ru = __builtin_amdgcn_make_buffer_rsrc((void*)(A.u_old + (int64_t)kbase * plane), 0, (int)(avail < want ? avail : want), 0x00020000);
-        } else {
-            S.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(A.x + (int64_t)kbase * plane), 0, (int)(avail < want ? avail : want), 0x00020000);
-        }
+        S.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(A.x + (int64_t)kbase * plane), 0, (int)(avail < want ? avail : want), 0x00020000);
     }
     // ---- row variants of the walk, staging bookkeeping ----
     for (int e = (int)tid; e < W * Lc; e += NT) {
@@ -436,12 +393,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DP
     if (Lc > 1) K::table_fetch(A, S, sB, 1);
     // ---- the window of step 0 ----
 #pragma unroll
-    for (int rr = 0; rr < W; ++rr) {
+    for (int rr = 0; rr < W; ++rr)
 #pragma unroll
         for (int p = 0; p < W; ++p) K::load_row(A, S, p, rr, j0 + rr - R);
-        K::load_wacc(A, S, j0 + rr - R, k, j0, Lc, i, valid);
-        K::finish_rows(A, S, rr, j0 + rr - R, k, j0, Lc, i, valid);
-    }
     float* __restrict__ yrow = A.y + ((int64_t)k * A.ny + j0) * A.nx + i;
     double dsum = 0.0;
     const typename K::Ctx ctx = {k, j0, Lc, i, valid};
@@ -451,7 +405,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DP
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
         if (s + 1 < Lc) K::table_store(S, sT, (s + 1) & 1, tid);                                                \
         if (s + 2 < Lc) K::table_fetch(A, S, sB, s + 2);                                                        \
-        if (K::FUSE && s > 0) K::finish_rows(A, S, ((P) + W - 1) % W, j0 + s + R, k, j0, Lc, i, valid);         \
         const float xc = S.xw[R][((P) + R) % W][DPP ? 0 : R];                                                   \
         const float acc = K::template step<(P)>(A, S, sT, s, ctx);                                              \
         asm volatile("" ::"v"(acc)); /* (keeps the sum where it is: otherwise it sinks into the branch of the store) */ \
@@ -570,16 +523,6 @@ static void rbf_walk_launch_nw(const RbfWalkArgs& A, int NW, unsigned nb, hipStr
 }
 static void rbf_walk_launch_dpp(const RbfWalkArgs& A, int NW, unsigned nb, hipStream_t st)
 {
-    if (A.u_new) {   // the CG's vector updates folded in
-        switch (NW) {
-        case 1: rbf_walk_kernel<2, 7, 0, 16, 1, 101><<<nb, 64, 0, st>>>(A); break;
-        case 2: rbf_walk_kernel<2, 7, 0, 16, 2, 101><<<nb, 128, 0, st>>>(A); break;
-        case 3: rbf_walk_kernel<2, 7, 0, 16, 3, 101><<<nb, 192, 0, st>>>(A); break;
-        case 5: rbf_walk_kernel<2, 7, 0, 16, 5, 101><<<nb, 320, 0, st>>>(A); break;
-        default: rbf_walk_kernel<2, 7, 0, 16, 9, 101><<<nb, 576, 0, st>>>(A); break;
-        }
-        return;
-    }
     switch (NW) {
     case 1: rbf_walk_kernel<2, 7, 0, 16, 1, 1><<<nb, 64, 0, st>>>(A); break;
     case 2: rbf_walk_kernel<2, 7, 0, 16, 2, 1><<<nb, 128, 0, st>>>(A); break;
