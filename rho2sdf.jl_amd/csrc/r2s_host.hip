@@ -135,6 +135,8 @@ struct HostSession {
     DevBuf pk;                     // packed tiles of the sparse download (device)
     void* pk_host = nullptr;       // ... and their pinned landing zone
     size_t pk_host_cap = 0;
+    void* fine_host = nullptr;     // pinned landing zone of the smoothed field before its level shift (r2s_rho2sdf)
+    size_t fine_host_cap = 0;
 
     int init(int dev)
     {
@@ -167,6 +169,9 @@ struct HostSession {
         for (DevBuf* b : all) b->release();
         if (pk_host) (void)hipHostFree(pk_host);
         pk_host = nullptr;
+        if (fine_host) (void)hipHostFree(fine_host);
+        fine_host = nullptr;
+        fine_host_cap = 0;
         pk_host_cap = 0;
         for (int i = 0; i < 2; ++i) {
             if (stage[i]) (void)hipHostFree(stage[i]);
@@ -905,6 +910,17 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
         for (int i = 0; i < 3; ++i) nfine *= (size_t)(grid->N[i] * o.rbf_smooth + 1);
     }
     const bool pin_f = fine_sdf_out && is_pinned(fine_sdf_out);
+    // The smoothed field is evaluated BEFORE the level bisection and travels while the level is found (it needs the weights
+    // only); the host threads add the level shift afterwards.  Needs pinned memory for the field without its shift.
+    static const bool early_env = !(getenv("R2S_FINE_EARLY") && atoi(getenv("R2S_FINE_EARLY")) == 0);
+    bool early = early_env && !o.skip_rbf && fine_sdf_out && nfine >= ((size_t)1 << 22);
+    if (early && !pin_f && S->fine_host_cap < sizeof(float) * nfine) {
+        if (S->fine_host) (void)hipHostFree(S->fine_host);
+        S->fine_host = nullptr;
+        S->fine_host_cap = 0;
+        if (hipHostMalloc(&S->fine_host, sizeof(float) * nfine, hipHostMallocDefault) == hipSuccess) S->fine_host_cap = sizeof(float) * nfine;
+        else { (void)hipGetLastError(); early = false; }
+    }
     if (sdf_dists_out && pin_d) {
         HIP_TRY(hipMemcpyAsync(sdf_dists_out, S->out[2].p, sizeof(double) * (size_t)ngp, hipMemcpyDeviceToHost, S->cs));
         dists_in_flight = true;
@@ -928,8 +944,11 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
                     c = queue[next++];
                 }
                 if (hipEventSynchronize(c.ev) != hipSuccess) { dl_rc = R2S_ERR_HIP; dl_err = "hipEventSynchronize failed"; return; }
-                std::vector<Segment> segs{{(char*)(fine_sdf_out + c.t0), (const char*)(S->fine.as<float>() + c.t0), sizeof(float) * (size_t)(c.t1 - c.t0)}};
-                dl_rc = download(S, segs, pin_f);
+                // (early: the chunk lands in pinned memory - the caller's array if it is pinned, else the landing zone - and gets its
+                //  level shift from the host threads once the level is known)
+                float* land = early ? (pin_f ? fine_sdf_out : (float*)S->fine_host) : fine_sdf_out;
+                std::vector<Segment> segs{{(char*)(land + c.t0), (const char*)(S->fine.as<float>() + c.t0), sizeof(float) * (size_t)(c.t1 - c.t0)}};
+                dl_rc = download(S, segs, early ? true : pin_f);
                 if (dl_rc) { dl_err = g_err; return; }
             }
         });
@@ -967,7 +986,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
             return 0;
         };
         rc = r2s_int::rbf_smooth_dev(S->out[2].as<double>(), grid, o.rbf_interp, o.rbf_smooth, o.rbf_kernel_threshold,
-                                     ri.V_frac * ri.V_domain, S->fine.as<float>(), &ri.level_shift, &its, &forward, S->rbf_ws);
+                                     ri.V_frac * ri.V_domain, S->fine.as<float>(), &ri.level_shift, &its, &forward, S->rbf_ws, early);
         if (rc) { (void)join_dl(); return rc; }
         ri.cg_iters = its;
     }
@@ -975,6 +994,31 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     ri.ms_rbf = t5 - t4;
     // ---- rest of the results to the caller ----
     if ((rc = join_dl())) return rc;
+    if (early) {   // the level shift: fine = raw + th (Float32), by the host threads, into the caller's array
+        ensure_pool(S);
+        const float th = ri.level_shift;
+        const float* src = pin_f ? fine_sdf_out : (const float*)S->fine_host;
+        float* dst = fine_sdf_out;
+        const size_t nf = nfine;
+        S->pool->start([=](int id, int n) {
+            // (whole 16-byte pieces per thread; streaming stores when the destination is another array: no read-for-ownership)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const size_t nq = nf / 4, a = nq * (size_t)id / (size_t)n, b = nq * (size_t)(id + 1) / (size_t)n;
+            const bool vec = (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0;
+            if (vec && src != dst) {
+                for (size_t q = a; q < b; ++q) {
+                    const v4f v = reinterpret_cast<const v4f*>(src)[q];
+                    __builtin_nontemporal_store(v + th, reinterpret_cast<v4f*>(dst) + q);
+                }
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+            } else {
+                for (size_t q = 4 * a; q < 4 * b; ++q) dst[q] = src[q] + th;
+            }
+            if (id == n - 1)
+                for (size_t q = 4 * nq; q < nf; ++q) dst[q] = src[q] + th;
+        });
+        S->pool->wait();
+    }
     if (sdf_dists_out && !dists_in_flight) {
         std::vector<Segment> segs{{(char*)sdf_dists_out, (const char*)S->out[2].p, sizeof(double) * (size_t)ngp}};
         if ((rc = download(S, segs, false))) return rc;

@@ -36,9 +36,13 @@ int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, dou
 // fine_chunk (optional): the output field is evaluated in a few Z chunks; after the launch of each one (default stream)
 // fine_chunk(first, last) is called with the range [first, last) of d_fine_out that kernel fills, so that the caller
 // can send finished chunks to the host while the next one is computed.  A non-zero return aborts.
+// fine_early: the chunks are evaluated BEFORE the level bisection and forwarded WITHOUT the level shift (the evaluation needs
+// the weights only; the caller adds *th_out to what it received - the same Float32 sum); d_fine_out then stays WITHOUT the
+// shift (its chunks may still be travelling when the level is known).
 int rbf_smooth_dev(const double* d_sdf, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
                    float* d_fine_out, float* th_out, int* cg_iters,
-                   const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr, void* workspace = nullptr);
+                   const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr, void* workspace = nullptr,
+                   bool fine_early = false);
 // workspace (optional): the call's device buffers, kept between calls on the CURRENT device (create / release there)
 void* rbf_workspace_create();
 void rbf_workspace_release(void* workspace);

@@ -1910,7 +1910,8 @@ struct RbfWork {   // the device buffers of one rbf_smooth_host call
 static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, int smooth, double kthr,
                            double target_volume, float* fine_out, float* th_out, int* cg_iters, float* lsf_out,
                            bool sdf_dev = false, bool out_dev = false,
-                           const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr, RbfWork* ws = nullptr)
+                           const std::function<int(int64_t, int64_t)>* fine_chunk = nullptr, RbfWork* ws = nullptr,
+                           bool fine_early = false)
 {
     if (!sdf || !g || !fine_out) return fail(R2S_ERR_ARG, "null argument");
     if (smooth < 1 || smooth > 4) return fail(R2S_ERR_ARG, "smooth must be 1..4");
@@ -2227,6 +2228,30 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         HIP_C(hipMemcpy(d_w.p, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice));   // :353
     }
     if (cg_iters) *cg_iters = its;
+    // the output field (:363-366) + `add`
+    // (smooth = 1: one target per lattice point - through the table of ITS coordinate differences)
+    // In RBF_FINE_CHUNKS Z chunks when the caller wants to forward finished chunks (fine_chunk), else in one launch.
+    auto eval_fine = [&](float add) -> int {
+        const int nchunk = (fine_chunk && fz >= 4 * RBF_FINE_CHUNKS) ? RBF_FINE_CHUNKS : 1;
+        for (int c = 0; c < nchunk; ++c) {
+            const int f0 = (int)((int64_t)fz * c / nchunk), f1 = (int)((int64_t)fz * (c + 1) / nchunk);
+            const int64_t t0 = (int64_t)f0 * fx * fy, t1 = (int64_t)f1 * fx * fy;
+            const unsigned nbc = (unsigned)((t1 - t0 + 255) / 256);
+            if (!(fine_one_to_one && launch_rbf_apply_lut(G, LGF, sts[1], nbc, st, d_w.as<float>(), d_tx.as<float>(), d_ty.as<float>(),
+                                                          d_tz.as<float>(), d_st.as<Stencil>() + 1, add, dfine, t0, t1)))
+                rbf_apply_kernel<<<nbc, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
+                                                     d_tz.as<float>(), d_st.as<Stencil>() + 1, add, dfine, t0, t1);
+            if (fine_chunk) {
+                const int rcc = (*fine_chunk)(t0, t1);
+                if (rcc) return rcc;
+            }
+        }
+        return 0;
+    };
+    // fine_early: the field WITHOUT the level shift first (it needs the weights only), so that its chunks travel to the host
+    // while the level is found; the caller adds the shift to what it received (x + 0 + th = x + th: the same Float32 sum).
+    // The device array stays WITHOUT it (the chunks may still be on their way when the level is known)
+    if (fine_early) TRY_C(eval_fine(0.0f));
     // ---- LSF on the coarse grid (:357) and the volume-preserving level (:359, :265-300) ----
     if (!launch_rbf_apply_lut(G, LG, sts[0], nb, st, d_w.as<float>(), d_cx.as<float>(), d_cy.as<float>(), d_cz.as<float>(),
                               d_st.as<Stencil>(), 0.0f, d_lsf.as<float>()))
@@ -2257,24 +2282,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     th = -th;
     if (th_out) *th_out = th;
     // ---- fine grid (:363-366) ----
-    // (smooth = 1: one target per lattice point - through the table of ITS coordinate differences)
-    // In RBF_FINE_CHUNKS Z chunks when the caller wants to forward finished chunks (fine_chunk), else in one launch.
-    {
-        const int nchunk = (fine_chunk && fz >= 4 * RBF_FINE_CHUNKS) ? RBF_FINE_CHUNKS : 1;
-        for (int c = 0; c < nchunk; ++c) {
-            const int f0 = (int)((int64_t)fz * c / nchunk), f1 = (int)((int64_t)fz * (c + 1) / nchunk);
-            const int64_t t0 = (int64_t)f0 * fx * fy, t1 = (int64_t)f1 * fx * fy;
-            const unsigned nbc = (unsigned)((t1 - t0 + 255) / 256);
-            if (!(fine_one_to_one && launch_rbf_apply_lut(G, LGF, sts[1], nbc, st, d_w.as<float>(), d_tx.as<float>(), d_ty.as<float>(),
-                                                          d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine, t0, t1)))
-                rbf_apply_kernel<<<nbc, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
-                                                     d_tz.as<float>(), d_st.as<Stencil>() + 1, th, dfine, t0, t1);
-            if (fine_chunk) {
-                const int rcc = (*fine_chunk)(t0, t1);
-                if (rcc) { cleanup(); return rcc; }
-            }
-        }
-    }
+    if (!fine_early) TRY_C(eval_fine(th));   // (fine_early: done above, the shift is the caller's)
     HIP_C(hipGetLastError());
     if (out_dev) HIP_C(hipDeviceSynchronize());
     else HIP_C(hipMemcpy(fine_out, d_fine.p, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost));
@@ -2993,10 +3001,10 @@ int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double threshold, dou
 }
 int rbf_smooth_dev(const double* d_sdf, const r2s_grid* g, int is_interp, int smooth, double kthr, double target_volume,
                    float* d_fine_out, float* th_out, int* cg_iters, const std::function<int(int64_t, int64_t)>* fine_chunk,
-                   void* workspace)
+                   void* workspace, bool fine_early)
 {
     return rbf_smooth_host(d_sdf, g, is_interp, smooth, kthr, target_volume, d_fine_out, th_out, cg_iters, nullptr, true, true,
-                           fine_chunk, (RbfWork*)workspace);
+                           fine_chunk, (RbfWork*)workspace, fine_early);
 }
 void* rbf_workspace_create() { return new RbfWork(); }
 void rbf_workspace_release(void* w)
