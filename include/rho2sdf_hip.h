@@ -74,6 +74,12 @@ typedef struct {
      * element holding the point (max|xi| < 1.01) has rho >= rho_t (instead of SignDetection.jl:56-69's
      * improving-sequence rule).  dist_true <= dist_ordered everywhere; see DESIGN.md for the measured deviation. */
     int32_t true_min;
+    /* HEX8 sign pass: 1 = no inner-region shortcut (every candidate pair runs its inverse map and the ordered walk of
+     * SignDetection.jl:41-68) - for OVERLAPPING / non-conforming meshes, where the shortcut's precondition does not hold
+     * (see r2s_sign_detection below).  0 = shortcut on.  The environment variable R2S_SIGN_NO_INNER=1 forces it for every
+     * call of the process. */
+    int32_t sign_no_inner;
+    int32_t reserved_;
 } r2s_params;
 
 /* per-call counters (optional; pass NULL) */
@@ -159,7 +165,8 @@ typedef struct {
                                             slab-distributed (planes move between devices as peer copies over xGMI; nothing is gathered on one device) */
     int32_t skip_rbf;                    /* 1: stop after artifact removal (fine_sdf_out may be NULL) */
     int32_t true_min;                    /* r2s_params.true_min for the raw SDF */
-    int32_t reserved[4];
+    int32_t sign_no_inner;               /* r2s_params.sign_no_inner for the raw SDF */
+    int32_t reserved[3];
 } r2s_options;
 
 typedef struct {

@@ -23,7 +23,8 @@ class R2SGrid(ctypes.Structure):
 class R2SParams(ctypes.Structure):
     _fields_ = [("band_factor", ctypes.c_double), ("elem_type", ctypes.c_int32),
                 ("device", ctypes.c_int32), ("zstride", ctypes.c_int32), ("zphase", ctypes.c_int32),
-                ("n_gpus", ctypes.c_int32), ("true_min", ctypes.c_int32)]
+                ("n_gpus", ctypes.c_int32), ("true_min", ctypes.c_int32), ("sign_no_inner", ctypes.c_int32),
+                ("reserved_", ctypes.c_int32)]
 
 
 class R2SOptions(ctypes.Structure):
@@ -32,7 +33,8 @@ class R2SOptions(ctypes.Structure):
                 ("artifact_min_component_ratio", ctypes.c_double), ("rbf_kernel_threshold", ctypes.c_double),
                 ("elem_type", ctypes.c_int32), ("rbf_interp", ctypes.c_int32), ("rbf_smooth", ctypes.c_int32),
                 ("remove_artifacts", ctypes.c_int32), ("device", ctypes.c_int32), ("n_gpus", ctypes.c_int32),
-                ("skip_rbf", ctypes.c_int32), ("true_min", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+                ("skip_rbf", ctypes.c_int32), ("true_min", ctypes.c_int32), ("sign_no_inner", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 3)]
 
 
 class R2SRunInfo(ctypes.Structure):

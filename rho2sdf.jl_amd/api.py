@@ -75,7 +75,7 @@ def _i(a):
     return a.ctypes.data_as(L.c_int64_p)
 
 
-def _params(mesh, band_factor, device, n_gpus=1, true_min=False):
+def _params(mesh, band_factor, device, n_gpus=1, true_min=False, sign_no_inner=False):
     p = L.R2SParams()
     L.lib().r2s_default_params(ctypes.byref(p))
     p.band_factor = float(band_factor)
@@ -83,6 +83,7 @@ def _params(mesh, band_factor, device, n_gpus=1, true_min=False):
     p.device = int(device)
     p.n_gpus = int(n_gpus)
     p.true_min = int(bool(true_min))
+    p.sign_no_inner = int(bool(sign_no_inner))
     return p
 
 
@@ -132,12 +133,12 @@ def evalDistances(mesh, grid, rho_n, rho_t, *, band_factor=1.1, want_xp=True, de
     return dist, xp
 
 
-def Sign_Detection(mesh, grid, rho_n, rho_t, *, device=-1, stats=None, n_gpus=1, out=None, true_min=False):
+def Sign_Detection(mesh, grid, rho_n, rho_t, *, device=-1, stats=None, n_gpus=1, out=None, true_min=False, sign_no_inner=False):
     """Sign_Detection(mesh, grid, points, rho_n, rho_t) -> signs  (SignDetection.jl:275-283)"""
     r = _rho(mesh, rho_n)
     s = _out(out, grid.ngp)
     st = L.R2SStats()
-    p = _params(mesh, 1.1, device, n_gpus, true_min)
+    p = _params(mesh, 1.1, device, n_gpus, true_min, sign_no_inner)
     L.check(L.lib().r2s_sign_detection(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(rho_t),
                                        ctypes.byref(grid.c), ctypes.byref(p), _d(s), ctypes.byref(st)))
     if stats is not None:
@@ -145,12 +146,12 @@ def Sign_Detection(mesh, grid, rho_n, rho_t, *, device=-1, stats=None, n_gpus=1,
     return s
 
 
-def sdf_fused(mesh, grid, rho_n, rho_t, *, band_factor=1.1, device=-1, stats=None, n_gpus=1, out=None, true_min=False):
+def sdf_fused(mesh, grid, rho_n, rho_t, *, band_factor=1.1, device=-1, stats=None, n_gpus=1, out=None, true_min=False, sign_no_inner=False):
     """`dists .* signs` in one pass (RhoToSDF.jl:169-171).  `out`: result array to fill (e.g. from host_array)."""
     r = _rho(mesh, rho_n)
     out = _out(out, grid.ngp)
     st = L.R2SStats()
-    p = _params(mesh, band_factor, device, n_gpus, true_min)
+    p = _params(mesh, band_factor, device, n_gpus, true_min, sign_no_inner)
     L.check(L.lib().r2s_sdf(_d(mesh.X), mesh.nnp, _i(mesh.IEN), mesh.nel, _d(r), float(rho_t),
                             ctypes.byref(grid.c), ctypes.byref(p), _d(out), ctypes.byref(st)))
     if stats is not None:

@@ -63,7 +63,8 @@ class CopyPool {
     // every thread runs fn(id, n); returns at once - wait() before the next start()
     void start(std::function<void(int, int)> fn)
     {
-        std::lock_guard<std::mutex> l(mu_);
+        std::unique_lock<std::mutex> l(mu_);
+        done_.wait(l, [this] { return pending_ == 0; });   // (a generation that was never waited for: finish it first)
         fn_ = std::move(fn);
         pending_ = n_;
         ++gen_;
@@ -434,11 +435,10 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
         // of the list instead of slabs: 9 instead of 4-5 ms.)
         constexpr int NPIECE = 2;
         static const bool mask_skip = !(getenv("R2S_HOST_MASKSKIP") && atoi(getenv("R2S_HOST_MASKSKIP")) == 0);
-        if (S->evf.size() < (size_t)NPIECE) {
-            const size_t have = S->evf.size();
-            S->evf.resize(NPIECE, nullptr);
-            for (size_t q = have; q < (size_t)NPIECE; ++q)
-                if (hipEventCreateWithFlags(&S->evf[q], hipEventDisableTiming) != hipSuccess) return bail(fail(R2S_ERR_HIP, "hipEventCreate failed"));
+        while (S->evf.size() < (size_t)NPIECE) {   // (an event joins the list only once it exists)
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail(R2S_ERR_HIP, "hipEventCreate failed"));
+            S->evf.push_back(e);
         }
         char* const hpk_w = (char*)S->pk_host;
         const int64_t f0[NPIECE + 1] = {0, 0, nf}, m0[NPIECE + 1] = {0, nm, nm};   // phase 0: masks, phase 1: band tiles
@@ -742,6 +742,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     prm.band_factor = o.band_factor;
     prm.elem_type = o.elem_type;
     prm.true_min = o.true_min;
+    prm.sign_no_inner = o.sign_no_inner;
     prm.device = dev0;
     r2s_stats st;
     if (G == 1) {

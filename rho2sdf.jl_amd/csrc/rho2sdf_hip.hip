@@ -2560,7 +2560,8 @@ static int run_impl(r2s_plan* P, const double* dX, int64_t nnp, const int64_t* d
         HIP_TRY(hipStreamWaitEvent(P->st2, P->ev2[5], 0));   // element records (first stream) before the sign counts
         HIP_TRY(hipStreamWaitEvent(P->st3, P->ev2[5], 0));
         static const int no_inner_env = getenv("R2S_SIGN_NO_INNER") ? atoi(getenv("R2S_SIGN_NO_INNER")) : 0;
-        hex_planes_kernel<<<(unsigned)((nel * 6 + 255) / 256), 256, 0, P->st3>>>(P->erec.as<ElemRec>(), nel, no_inner_env);
+        hex_planes_kernel<<<(unsigned)((nel * 6 + 255) / 256), 256, 0, P->st3>>>(P->erec.as<ElemRec>(), nel,
+                                                                                 (no_inner_env || prm.sign_no_inner) ? 1 : 0);
         HIP_TRY(hipEventRecord(P->ev2[5], P->st3));   // from here on: "planes done"
     }
     // HEX8 sign pass: which tiles are hot, how long their candidate lists get and the boxes of the inverse maps depend on

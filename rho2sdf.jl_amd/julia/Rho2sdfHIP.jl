@@ -26,6 +26,7 @@ using Rho2sdf.ShapeFunctions
 using Rho2sdf.DataExport
 
 const LIB = Ref{String}("librho2sdf_hip.so")
+const SIGN_NO_INNER = Ref(false)      # true: HEX8 sign pass without the inner-region shortcut (overlapping / non-conforming meshes)
 const N_GPUS = Ref{Int32}(1)          # devices one call fans out over (single process; r2s_params.n_gpus)
 
 # mirrors r2s_grid / Grid (src/MeshGrid/Grid.jl:2-7)
@@ -46,10 +47,12 @@ struct R2SParams                      # mirrors r2s_params
     zphase::Int32
     n_gpus::Int32                     # host-pointer entry points: devices 0..n_gpus-1 share the call
     true_min::Int32                   # 1 = order-independent semantics (SURVEY 8(f)4); 0 = the reference's
+    sign_no_inner::Int32              # 1 = HEX8 sign pass without the inner-region shortcut (overlapping / non-conforming meshes)
+    reserved_::Int32
 end
 etype(::Type{HEX8}) = Int32(0)
 etype(::Type{TET4}) = Int32(1)
-params(::Type{T}; band_factor = 1.1) where {T} = R2SParams(band_factor, etype(T), -1, 0, 0, N_GPUS[], 0)
+params(::Type{T}; band_factor = 1.1) where {T} = R2SParams(band_factor, etype(T), -1, 0, 0, N_GPUS[], 0, SIGN_NO_INNER[] ? 1 : 0, 0)
 
 struct R2SOptions                     # mirrors r2s_options (= Rho2sdfOptions, RhoToSDF.jl:9-77)
     threshold_density::Float64        # NaN = nothing
@@ -64,7 +67,8 @@ struct R2SOptions                     # mirrors r2s_options (= Rho2sdfOptions, R
     n_gpus::Int32
     skip_rbf::Int32
     true_min::Int32
-    reserved::NTuple{4,Int32}
+    sign_no_inner::Int32
+    reserved::NTuple{3,Int32}
 end
 
 struct R2SRunInfo                     # mirrors r2s_run_info
@@ -96,6 +100,30 @@ function pinned(::Type{T}, dims::Int...) where {T}
     return a
 end
 
+# fine_grid.  The reference materialises one heap Vector{Float32} per grid point (create_smooth_grid, RBFs4Smoothing.jl:60-74:
+# 134 M allocations = several seconds and 10 GB at 512^3) although only fine_grid[2,1,1] - fine_grid[1,1,1] is ever read
+# (CalcVolumeFromSDF.jl:37).  LAZY_GRID[] = true returns the same points as an AbstractArray{Vector{Float32},3} over the three
+# coordinate vectors instead - element for element equal to the reference's array (same explicit Float32 arithmetic), built
+# on demand.  Default false: the reference's own calculate_volume_from_sdf is declared for Array{Vector{Float32},3} and would
+# not accept it (the _hip method below does).
+const LAZY_GRID = Ref(false)
+struct LazyFineGrid <: AbstractArray{Vector{Float32},3}
+    x::Vector{Float32}
+    y::Vector{Float32}
+    z::Vector{Float32}
+end
+Base.size(g::LazyFineGrid) = (length(g.x), length(g.y), length(g.z))
+Base.getindex(g::LazyFineGrid, i::Int, j::Int, k::Int) = Float32[g.x[i], g.y[j], g.z[k]]
+Base.IndexStyle(::Type{LazyFineGrid}) = IndexCartesian()
+function fine_grid_of(grid::MeshGrid.Grid, smooth::Int)
+    LAZY_GRID[] || return SdfSmoothing.create_smooth_grid(grid, smooth)[2]
+    nx, ny, nz = (grid.N * smooth) .+ 1                                   # RBFs4Smoothing.jl:61-73, operation for operation
+    xmin, ymin, zmin = Float32.(grid.AABB_min)
+    xmax = Float32(grid.AABB_max[1])
+    dx = (xmax - xmin) / (nx - 1)
+    return LazyFineGrid([xmin + (i - 1) * dx for i in 1:nx], [ymin + (j - 1) * dx for j in 1:ny], [zmin + (k - 1) * dx for k in 1:nz])
+end
+
 # ---------------------------------------------------------------------------------------------------
 # rho2sdf (src/RhoToSDF.jl:116-242): same signature, same return value, same files written
 # ---------------------------------------------------------------------------------------------------
@@ -110,7 +138,8 @@ function rho2sdf_hip(taskName::String, X::Vector{Vector{Float64}}, IEN::Vector{V
     smooth = options.rbf_grid == :same ? 1 : 2                                     # :222
     o = R2SOptions(options.threshold_density === nothing ? NaN : Float64(options.threshold_density), 1.1,
                    options.artifact_min_component_ratio, 1e-3, etype(T), Int32(options.rbf_interp), Int32(smooth),
-                   Int32(options.remove_artifacts), Int32(-1), N_GPUS[], Int32(0), Int32(0), (0, 0, 0, 0))
+                   Int32(options.remove_artifacts), Int32(-1), N_GPUS[], Int32(0), Int32(0), Int32(SIGN_NO_INNER[] ? 1 : 0),
+                   (0, 0, 0))
     ρₙ = Vector{Float64}(undef, mesh.nnp)
     sdf_dists = pinned(Float64, sdf_grid.ngp)
     fine_sdf = pinned(Float32, ((sdf_grid.N .* smooth) .+ 1)...)
@@ -135,7 +164,7 @@ function rho2sdf_hip(taskName::String, X::Vector{Vector{Float64}}, IEN::Vector{V
     if options.export_raw_sdf                                                      # :211-219
         exportSdfToVTI(taskName * "_SDF_$(element_name)_CellSize-" * string(B) * ".vti", sdf_grid, sdf_dists, "distance")
     end
-    (_, fine_grid) = SdfSmoothing.create_smooth_grid(sdf_grid, smooth)             # the point list of RBFs4Smoothing.jl:341
+    fine_grid = fine_grid_of(sdf_grid, smooth)                                     # the point list of RBFs4Smoothing.jl:341
     Rho2sdf.export_sdf_results_with_element_type(fine_sdf, fine_grid, sdf_grid, taskName, smooth,
                                                  options.rbf_interp, T)            # :230-238
     return (fine_sdf, fine_grid, sdf_grid, sdf_dists)
@@ -238,7 +267,7 @@ end
 
 # calculate_volume_from_sdf (src/SdfSmoothing/CalcVolumeFromSDF.jl:26-125); `grid` is the reference's array of
 # per-voxel coordinate vectors - only the spacing is used (:36-39)
-function calculate_volume_from_sdf_hip(sdf::Array{Float32,3}, grid::Array{Vector{Float32},3}; iso_threshold = 0.0f0,
+function calculate_volume_from_sdf_hip(sdf::Array{Float32,3}, grid::AbstractArray{Vector{Float32},3}; iso_threshold = 0.0f0,
                                        detailed_quad_order = 9)
     @assert size(grid) == size(sdf) "Dimensions of fine_sdf and fine_grid must match"
     d = grid[2, 1, 1] .- grid[1, 1, 1]
@@ -255,7 +284,7 @@ end
 function RBFs_smoothing_hip(mesh::Mesh, dist::Vector{Float64}, grid::MeshGrid.Grid, is_interp::Bool,
                             smooth::Int, taskName::String, threshold::Float64 = 1e-3)
     dim = (grid.N .* smooth) .+ 1
-    (_, fine_grid) = SdfSmoothing.create_smooth_grid(grid, smooth)      # point list only (:341), stays in Julia
+    fine_grid = fine_grid_of(grid, smooth)                              # point list only (:341), stays in Julia
     fine = pinned(Float32, dim...)
     check(ccall((:r2s_rbf_smooth, LIB[]), Cint,
                 (Ptr{Float64}, Ref{R2SGrid}, Int32, Int32, Float64, Float64, Int32, Ptr{Float32}, Ptr{Float32},

@@ -171,6 +171,20 @@ def test_straggler_list_overflow(pkg, oracle):
         od, _, _ = O.eval_distances(X, IEN, rn, 0.5, og, 1.1, want_xp=False)
         assert np.array_equal(d, od), int((d != od).sum())
         print("overflow path OK", int((od < 1e9).sum()))
+        # many items: the sweep's chunk -> item search, tile slots and store offsets, and the projection points it writes
+        from rho2sdf_jl_amd import synthetic
+        X, IEN, _ = synthetic.hex_mesh(7, jitter=.30, seed=20240502)
+        rn = np.clip(np.random.default_rng(1).normal(0.5, 0.35, len(X)), 0, 1)
+        nmax = synthetic.grid_n_max_for_points(48)
+        pg = pkg.Grid(X.min(0), X.max(0), nmax, 3); og = O.grid_make(X.min(0), X.max(0), nmax, 3)
+        st = {}
+        d, xp = pkg.evalDistances(pkg.Mesh(X, IEN), pg, rn, 0.5, band_factor=1.1, stats=st)
+        od, oxp, ost = O.eval_distances(X, IEN, rn, 0.5, og, 1.1)
+        real = od < 1e9
+        assert np.array_equal(d, od), int((d != od).sum())
+        assert np.allclose(xp[real], oxp[real], rtol=0, atol=1e-9) and not xp[~real].any()
+        assert st["n_iso_straggler"] > 64 and st["n_iso_fail"] == ost["n_iso_fail"]
+        print("overflow path, distorted mesh OK", int(real.sum()), "handed over", st["n_iso_straggler"], "without KKT point", st["n_iso_fail"])
     ''') % (ROOT, os.path.join(ROOT, "tests"))
     env = dict(os.environ, R2S_ISO_STRAGGLER_CAP="64")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
@@ -205,6 +219,17 @@ def test_overlapping_elements_without_the_inner_region_shortcut(pkg, oracle):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     print(r.stdout.strip())
+    # the same switch per call (r2s_params.sign_no_inner), in this process
+    X1, I1 = block_mesh([3, 3, 3])
+    X2 = X1 + 0.37 * (2.0 / 3.0) * np.array([1.0, 0.6, -0.8])
+    X = np.vstack([X1, X2]); IEN = np.vstack([I1, I1 + len(X1)])
+    rng = np.random.default_rng(5)
+    rn = np.concatenate([np.clip(1.2 - np.linalg.norm(X1, axis=1), 0, 1), rng.uniform(0.0, 1.0, len(X2))])
+    pg = pkg.Grid(X.min(0), X.max(0), 30, 3); og = oracle.grid_make(X.min(0), X.max(0), 30, 3)
+    so = oracle.sign_detection(X, IEN, rn, 0.5, og)
+    assert np.array_equal(pkg.Sign_Detection(pkg.Mesh(X, IEN), pg, rn, 0.5, sign_no_inner=True), so)
+    od, _, _ = oracle.eval_distances(X, IEN, rn, 0.5, og, 1.1, want_xp=False)
+    assert np.array_equal(pkg.sdf_fused(pkg.Mesh(X, IEN), pg, rn, 0.5, sign_no_inner=True), od * so)
 
 
 def test_synthetic_jittered_hex(pkg, oracle):
