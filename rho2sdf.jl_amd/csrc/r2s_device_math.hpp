@@ -994,7 +994,7 @@ R2S_DEV int iso_project_full(const ER& E, double rmax_abs, const double x[3], do
                 continue;
             }
             if (fbest < INFINITY) { xi[0] = xbest[0]; xi[1] = xbest[1]; xi[2] = xbest[2]; }
-            return it + 1;
+            return R2S_ISO_MAXIT + 1;   // (a stall no restoration repairs: no KKT point - the oracle's return value, counted by the callers)
         }
         if (stop == 3 || stop == 4) return it + 1;
 #pragma unroll

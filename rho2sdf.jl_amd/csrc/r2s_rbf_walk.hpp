@@ -323,7 +323,7 @@ struct RbfWalk {
 
 // (DPP: at most 96 registers, so that two workgroups of nine wavefronts share a CU)
 template <int R, int D2, int MODE, int NV, int NW, int DPP>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DPP ? 5 : 1))) rbf_walk_kernel(const RbfWalkArgs A)
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(DPP && NW >= 3 ? 5 : 1))) rbf_walk_kernel(const RbfWalkArgs A)
 {
     typedef RbfWalk<R, D2, MODE, NV, NW, DPP> K;
     typedef typename K::TE TE;

@@ -121,6 +121,14 @@ SLSQP_FIELD_COUNTS = {"1hex_el": (5832, 99, 0, 2253, 2162), "beam_vfrac_03": (92
                       "chapadlo": (17875, 58, 11, 1226, 1163)}
 
 
+# (measured with this oracle: the product never lies farther from the iso-surface than converged SLSQP on 1hex_el / beam,
+#  on 11 voxels of chapadlo by up to 9.3 % = 0.24 cell (another local minimum from the same start); it lies NEARER by up to
+#  0.81 / 0.0006 / 0.77 cell.  Against SLSQP stopped at the reference's 1e-5 tolerances the largest difference is the same
+#  0.81 / 0.0006 / 0.77 cell: that field is the one that has not converged.)
+SLSQP_FIELD_SIZES = {"1hex_el": (0.0, 0.8074, 290, 86, 0.8074), "beam_vfrac_03": (0.0, 0.000618, 55, 4, 0.000618),
+                     "chapadlo": (0.0927, 0.7720, 161, 67, 0.7720)}
+
+
 @pytest.mark.parametrize("name", sorted(SLSQP_FIELD_COUNTS))
 def test_fields_against_independent_slsqp(oracle, name):
     """the whole evalDistances field of the reference's 1hex_el input (runtests.jl:51-86) and of two fixtures
@@ -157,3 +165,17 @@ def test_fields_against_independent_slsqp(oracle, name):
     print(f"{name}: {band} band voxels; vs converged SLSQP on the surface ({int(on.sum())} voxels): nearer {near}, farther {far}"
           f" (max {rel.max():.2e}); beyond 1e-6 of SLSQP at 1e-5: {ref}; SLSQP 1e-5 vs converged: {self_}")
     assert far <= n_far and abs(near - n_near) <= 3 and ref <= n_ref + 5 and abs(self_ - n_self) <= 5
+    # ... and the SIZES of those differences (round-3 verdict: counts alone hide them).  fixture -> against converged SLSQP:
+    # largest relative "farther", largest "nearer" in cells; against SLSQP at the reference's 1e-5 tolerances (the closest
+    # stand-in for what NLopt returns): voxels beyond 1e-4 / 1e-2 relative, largest difference in cells
+    far_rel_max, near_cells_max, n_1e4, n_1e2, ref_cells_max = SLSQP_FIELD_SIZES[name]
+    cells = (d[on] - r[on]) / g.cell
+    relref = np.abs(d[real] - rr[real]) / np.maximum(rr[real], 1e-300)
+    refcells = np.abs(d[real] - rr[real]) / g.cell
+    print(f"{name}: farther by at most {max(rel.max(), 0.0):.3e} relative / {max(cells.max(), 0.0):.3e} cell, nearer by at most "
+          f"{-cells.min():.4f} cell; vs SLSQP@1e-5: {int((relref > 1e-4).sum())} voxels beyond 1e-4, {int((relref > 1e-2).sum())} beyond 1e-2, "
+          f"max {refcells.max():.4f} cell")
+    assert rel.max() <= far_rel_max * 1.01 + 1e-8
+    assert -cells.min() <= near_cells_max * 1.01
+    assert int((relref > 1e-4).sum()) <= n_1e4 + 3 and int((relref > 1e-2).sum()) <= n_1e2 + 2
+    assert refcells.max() <= ref_cells_max * 1.01

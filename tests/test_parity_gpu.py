@@ -183,7 +183,7 @@ def test_straggler_list_overflow(pkg, oracle):
         real = od < 1e9
         assert np.array_equal(d, od), int((d != od).sum())
         assert np.allclose(xp[real], oxp[real], rtol=0, atol=1e-9) and not xp[~real].any()
-        assert st["n_iso_straggler"] > 64 and st["n_iso_fail"] == ost["n_iso_fail"]
+        assert st["n_iso_straggler"] > 64 and st["n_iso_fail"] == ost["n_iso_fail"], (st["n_iso_straggler"], st["n_iso_fail"], ost["n_iso_fail"])
         print("overflow path, distorted mesh OK", int(real.sum()), "handed over", st["n_iso_straggler"], "without KKT point", st["n_iso_fail"])
     ''') % (ROOT, os.path.join(ROOT, "tests"))
     env = dict(os.environ, R2S_ISO_STRAGGLER_CAP="64")
