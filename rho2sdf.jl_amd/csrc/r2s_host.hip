@@ -904,6 +904,7 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     std::mutex qmu;
     std::condition_variable qcv;
     std::vector<Chunk> queue;   // chunks of the smoothed field whose kernels have been launched
+    std::vector<std::pair<int64_t, int64_t>> landed;   // early: chunks that have arrived in pinned memory (guarded by qmu)
     bool q_done = false;
     size_t nfine = 0;
     if (!o.skip_rbf) {
@@ -951,6 +952,13 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
                 std::vector<Segment> segs{{(char*)(land + c.t0), (const char*)(S->fine.as<float>() + c.t0), sizeof(float) * (size_t)(c.t1 - c.t0)}};
                 dl_rc = download(S, segs, early ? true : pin_f);
                 if (dl_rc) { dl_err = g_err; return; }
+                if (early) {
+                    {
+                        std::lock_guard<std::mutex> lk(qmu);
+                        landed.push_back({c.t0, c.t1});
+                    }
+                    qcv.notify_all();
+                }
             }
         });
         if (dists_here) dists_in_flight = true;
@@ -994,32 +1002,51 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     double t5 = now_ms();
     ri.ms_rbf = t5 - t4;
     // ---- rest of the results to the caller ----
-    if ((rc = join_dl())) return rc;
-    if (early) {   // the level shift: fine = raw + th (Float32), by the host threads, into the caller's array
+    if (early) {   // the level shift: fine = raw + th (Float32), by the host threads, chunk by chunk as the chunks arrive
         ensure_pool(S);
         const float th = ri.level_shift;
         const float* src = pin_f ? fine_sdf_out : (const float*)S->fine_host;
         float* dst = fine_sdf_out;
-        const size_t nf = nfine;
-        S->pool->start([=](int id, int n) {
-            // (whole 16-byte pieces per thread; streaming stores when the destination is another array: no read-for-ownership)
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const size_t nq = nf / 4, a = nq * (size_t)id / (size_t)n, b = nq * (size_t)(id + 1) / (size_t)n;
-            const bool vec = (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0;
-            if (vec && src != dst) {
-                for (size_t q = a; q < b; ++q) {
-                    const v4f v = reinterpret_cast<const v4f*>(src)[q];
-                    __builtin_nontemporal_store(v + th, reinterpret_cast<v4f*>(dst) + q);
-                }
-                std::atomic_thread_fence(std::memory_order_seq_cst);
-            } else {
-                for (size_t q = 4 * a; q < 4 * b; ++q) dst[q] = src[q] + th;
+        {
+            std::lock_guard<std::mutex> lk(qmu);
+            q_done = true;   // (no further chunk will be queued: the smoothing has returned)
+        }
+        qcv.notify_all();
+        size_t next = 0, total = 0;
+        {
+            std::lock_guard<std::mutex> lk(qmu);
+            total = queue.size();
+        }
+        while (next < total) {
+            std::pair<int64_t, int64_t> ch;
+            {
+                std::unique_lock<std::mutex> lk(qmu);
+                // (polling wait: the download thread sets dl_rc and leaves without a signal when a copy fails)
+                while (!qcv.wait_for(lk, std::chrono::milliseconds(20), [&] { return next < landed.size() || dl_rc != 0; })) {}
+                if (dl_rc) break;
+                ch = landed[next++];
             }
-            if (id == n - 1)
-                for (size_t q = 4 * nq; q < nf; ++q) dst[q] = src[q] + th;
-        });
-        S->pool->wait();
+            const size_t c0 = (size_t)ch.first, cn = (size_t)(ch.second - ch.first);
+            S->pool->start([=](int id, int n) {
+                // (16-byte pieces where both sides are aligned; streaming stores into another array: no read-for-ownership)
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const float* s0 = src + c0;
+                float* d0 = dst + c0;
+                const size_t a = cn * (size_t)id / (size_t)n, b = cn * (size_t)(id + 1) / (size_t)n;
+                size_t q = a;
+                if (s0 != d0) {
+                    while (q < b && (((uintptr_t)(d0 + q)) & 15u)) { d0[q] = s0[q] + th; ++q; }
+                    if ((((uintptr_t)(s0 + q)) & 15u) == 0)
+                        for (; q + 4 <= b; q += 4)
+                            __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(s0 + q) + th, reinterpret_cast<v4f*>(d0 + q));
+                }
+                for (; q < b; ++q) d0[q] = s0[q] + th;
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+            });
+            S->pool->wait();
+        }
     }
+    if ((rc = join_dl())) return rc;
     if (sdf_dists_out && !dists_in_flight) {
         std::vector<Segment> segs{{(char*)sdf_dists_out, (const char*)S->out[2].p, sizeof(double) * (size_t)ngp}};
         if ((rc = download(S, segs, false))) return rc;

@@ -480,19 +480,23 @@ struct RbfWalkPlan {
 // dpp: wavefronts of 60 outputs, NW in {1, 2, 3, 5, 9}; else 64 outputs, NW in {1, 2, 4, 8}
 // (nplanes: the planes of the WHOLE lattice - a Z-slab of a multi-device run cuts its walks like the single-device run, so
 //  that the partial sums of the dot product come out the same)
-static RbfWalkPlan rbf_walk_plan(int nx, int ny, int nplanes, bool dpp)
+static RbfWalkPlan rbf_walk_plan(int nx, int ny, int nplanes, bool dpp, int stage_chunks = 420)
 {
     static const int nw_dpp[] = {1, 2, 3, 5, 9}, nw_std[] = {1, 2, 4, 8};
     const int* cand = dpp ? nw_dpp : nw_std;
     const int ncand = dpp ? 5 : 4, outw = dpp ? 60 : 64;
     RbfWalkPlan P;
-    // wavefronts per workgroup: the fewest wavefronts per row, then the widest workgroup (one staged table per row piece)
+    // wavefronts per workgroup: the cheapest row.  A wavefront-step costs 1; the table rows of a step are staged once per
+    // workgroup (16-byte chunks: 420 for the product, 840 / 3 360 for the evaluation), ~0.12 per round of a thread -
+    // narrow workgroups stage the same rows again for every piece of a row (nx = 257: one wavefront per workgroup took
+    // 0.68 ms where eight take less although half their lanes idle)
     P.NW = cand[0];
-    int64_t best = -1;
+    double best = -1.0;
     for (int c = 0; c < ncand; ++c) {
         const int nw = cand[c];
-        const int64_t waves = (int64_t)((nx + outw * nw - 1) / (outw * nw)) * nw;
-        if (best < 0 || waves <= best) { best = waves; P.NW = nw; }
+        const double waves = (double)((nx + outw * nw - 1) / (outw * nw)) * nw;
+        const double cost = waves * (1.0 + 0.12 * (double)((stage_chunks + 64 * nw - 1) / (64 * nw)));
+        if (best < 0.0 || cost <= best) { best = cost; P.NW = nw; }
     }
     if (const char* e = getenv("R2S_RBF_WALK_NW")) {   // (experiments)
         const int nw = atoi(e);
@@ -535,7 +539,7 @@ static void rbf_walk_launch_dpp(const RbfWalkArgs& A, int NW, unsigned nb, hipSt
 static void rbf_walk_launch(int mode, int nv, RbfWalkArgs A, hipStream_t st)
 {
     const bool dpp = mode == 0;
-    const RbfWalkPlan P = rbf_walk_plan(A.nx, A.ny, A.nz, dpp);
+    const RbfWalkPlan P = rbf_walk_plan(A.nx, A.ny, A.nz, dpp, mode == 0 ? 420 : (nv == 16 ? 840 : 3360));
     A.L = P.L; A.nchunk = P.nchunk; A.nxt = P.nxt;
     const unsigned nb = (unsigned)((int64_t)(A.k_end - A.k_begin) * P.nchunk * P.nxt);
     if (nb == 0) return;
