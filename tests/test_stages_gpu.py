@@ -270,6 +270,33 @@ def test_rbf_lds_kernels_on_a_wide_grid(pkg, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(4, 3, 5), (61, 7, 5), (5, 67, 3), (130, 9, 8), (311, 6, 6), (64, 64, 5)])
+def test_rbf_walk_kernels_on_odd_lattices(pkg, monkeypatch, dims):
+    """the row-walk kernels on lattices that are smaller than their tiles in one direction or another (fewer columns than a
+    wavefront, fewer rows than a walk, fewer planes than the stencil reaches, widths just beyond a multiple of the 60 / 64
+    outputs of a wavefront): CG + both evaluations against neighbour-by-neighbour evaluation, bit for bit"""
+    nx, ny, nz = dims
+    lo = np.array([0.375, -0.25, 0.125])   # (dyadic numbers: the cell count of `Grid` comes out exact)
+    g = pkg.Grid(lo, lo + 0.125 * (np.array(dims) - 1.0), max(dims) - 1, 0)
+    assert g.dims == dims
+    ax = [g.AABB_min[i] + g.cell_size * np.arange(n) for i, n in enumerate(dims)]
+    c = [0.5 * (a[0] + a[-1]) for a in ax]
+    r = np.sqrt((ax[0][None, None, :] - c[0]) ** 2 + (ax[1][None, :, None] - c[1]) ** 2 + (ax[2][:, None, None] - c[2]) ** 2)
+    sdf = 0.3 * g.cell_size * max(dims) - r
+    sdf = np.where(np.abs(sdf) < 3 * g.cell_size, sdf, np.sign(sdf) * 1e10).ravel()
+    target = max(float((sdf > 0).sum()), 1.0) * g.cell_size ** 3
+    outs = {}
+    for mode in ("walk", "fly"):
+        _set_rbf_mode(monkeypatch, mode)
+        info = {}
+        outs[mode] = (pkg.RBFs_smoothing(sdf, g, True, 1, target, info=info), info["cg_iterations"], info["th"], info["lsf"])
+    assert outs["fly"][1] == outs["walk"][1] and outs["fly"][2] == outs["walk"][2]
+    assert np.array_equal(outs["fly"][0], outs["walk"][0]) and np.array_equal(outs["fly"][3], outs["walk"][3])
+    assert np.isfinite(outs["walk"][0]).all()
+    pkg._lib.lib().r2s_release_cache()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("interp", [False, True])
 def test_rbf_evaluation_table_is_bit_identical(pkg, oracle, monkeypatch, interp):
     """same-grid evaluation (the LSF of the level bisection and the output field at smooth = 1) through the table of
