@@ -552,14 +552,10 @@ __global__ void __launch_bounds__(256) volume_rowwave_kernel(const float* __rest
     // only on iq - formed once per cell (4 n along x, 2 n^2 along y, n^3 along z) instead of once per point (7 n^3), from the
     // same operands by the same expressions: the same values, a fifth of the arithmetic
     const bool tensor = qpts != nullptr && npts <= 12 * 64 && 4 * n <= 64;
-    __shared__ float4 sQ[12 * 64];     // per quadrature point: zeta, weight, (jq n + iq) as an integer, -
+    __shared__ float sW[12 * 64];      // weight per quadrature point (kq n^2 + jq n + iq)
     __shared__ float sG[32];           // (gp + 1) / 2 per index
-    __shared__ float sC[4][2][96];     // per wavefront: the y-interpolated values c0, c1 of the cell in hand, per (jq, iq)
     if (tensor) {
-        for (int p = tid; p < npts; p += 256) {
-            const float4 B = qpts[2 * p + 1];   // zeta, 1 - zeta, weight
-            sQ[p] = make_float4(B.x, B.z, __int_as_float(p % nn), 0.0f);
-        }
+        for (int p = tid; p < npts; p += 256) sW[p] = qpts[2 * p + 1].z;   // (zeta, 1 - zeta, weight, -)
         if (tid < n) sG[tid] = (q.gp[tid] + 1) / 2;
         __syncthreads();
     }
@@ -624,7 +620,8 @@ __global__ void __launch_bounds__(256) volume_rowwave_kernel(const float* __rest
                             const float cB = pr == 0 ? d100 : (pr == 1 ? d101 : (pr == 2 ? d110 : d111));
                             s1 = cA * (1.0f - xi) + cB * xi;
                         }
-                        // along y: c0, c1 per (jq, iq) into the wavefront's LDS rows (every lane takes part in the shuffles)
+                        // along y and z: lane e (and e + 64, ...) holds c0, c1 of its (jq, iq) pair - every lane takes part in
+                        // the shuffles - and adds the weights of ITS column of Gauss points (kq ascending) that lie inside
                         for (int e0 = 0; e0 < nn; e0 += 64) {
                             const int e = e0 + lane < nn ? e0 + lane : nn - 1;
                             const int jq = e / n, iq = e - jq * n;
@@ -633,15 +630,13 @@ __global__ void __launch_bounds__(256) volume_rowwave_kernel(const float* __rest
                                         c11 = __shfl(s1, 3 * n + iq, 64);
                             const float c0 = c00 * (1.0f - eta) + c10 * eta;
                             const float c1 = c01 * (1.0f - eta) + c11 * eta;
-                            if (e0 + lane < nn) { sC[wave][0][e] = c0; sC[wave][1][e] = c1; }
-                        }
-                        // along z, per point (the wavefront's LDS operations complete in order: the rows are there)
-                        for (int p = lane; p < npts; p += 64) {
-                            const float4 Q = sQ[p];
-                            const int ij = __float_as_int(Q.z);
-                            const float zeta = Q.x;
-                            const float pv = sC[wave][0][ij] * (1.0f - zeta) + sC[wave][1][ij] * zeta;
-                            if (pv >= iso) part += Q.y;
+                            if (e0 + lane < nn) {
+                                for (int kq = 0; kq < n; ++kq) {
+                                    const float zeta = sG[kq];
+                                    const float pv = c0 * (1.0f - zeta) + c1 * zeta;
+                                    if (pv >= iso) part += sW[kq * nn + e];
+                                }
+                            }
                         }
                     } else {
                         for (int p = lane; p < npts; p += 64) {
