@@ -36,13 +36,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_VOXEL = 8.0      # one Float64 store per voxel; + mesh bytes / ngp
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 FLOP x 2.4 GHz)
 DOMINANT_KERNEL = {"HEX8": "iso_project_hex_pl_kernel", "TET4": "iso_project_kernel"}
-PROFILE_ROUND = "r03"          # profiles/<round>_traffic.json, <round>_valu_counters.json (tools/collect_traffic.py)
+PROFILE_ROUND = "r04"          # profiles/<round>_traffic.json, <round>_valu_counters.json (tools/collect_traffic.py)
 
 
 def load_committed_profile(kernel):
     """PMC figures of the dominant kernel from the committed rocprofv3 passes of this same command (separate --pmc runs,
     tools/collect_traffic.py): they are NOT measured in the timed run and are labelled so.  None when absent."""
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r03", "r02"):
         tfile = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
         vfile = os.path.join(ROOT, "profiles", f"{rnd}_valu_counters.json")
         if not (os.path.exists(tfile) and os.path.exists(vfile)):
