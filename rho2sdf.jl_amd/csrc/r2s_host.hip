@@ -125,6 +125,7 @@ struct HostSession {
     std::mutex mu;   // one host call at a time per device
     r2s_plan* plan = nullptr;
     DevBuf dX, dI, dR, dE;
+    DevBuf pre_ws[7];   // node -> element lists and centroids of the nodal densities, element volumes (r2s_rho2sdf)
     DevBuf out[4];   // dist, sign, sdf, xp
     DevBuf fine, raw, slab;
     void* stage[2] = {nullptr, nullptr};
@@ -166,7 +167,8 @@ struct HostSession {
         (void)hipSetDevice(device);
         if (plan) r2s_plan_destroy(plan);
         plan = nullptr;
-        DevBuf* all[] = {&dX, &dI, &dR, &dE, &out[0], &out[1], &out[2], &out[3], &fine, &raw, &slab, &pk};
+        DevBuf* all[] = {&dX, &dI, &dR, &dE, &out[0], &out[1], &out[2], &out[3], &fine, &raw, &slab, &pk,
+                         &pre_ws[0], &pre_ws[1], &pre_ws[2], &pre_ws[3], &pre_ws[4], &pre_ws[5], &pre_ws[6]};
         for (DevBuf* b : all) b->release();
         if (pk_host) (void)hipHostFree(pk_host);
         pk_host = nullptr;
@@ -718,11 +720,13 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     ri.ms_upload = t - t_start;
     // ---- pre-stage: mesh volume (:128), nodal densities (:148), threshold (:151-156) ----
     if ((rc = r2s_int::mesh_volume_dev(S->dX.as<double>(), S->dI.as<int64_t>(), nel, o.elem_type, S->dE.as<double>(),
-                                       &ri.V_domain, &ri.V_frac)))
+                                       &ri.V_domain, &ri.V_frac, S->pre_ws + 5)))
         return rc;
-    if ((rc = r2s_int::dense_in_nodes_dev(S->dX.as<double>(), nnp, S->dI.as<int64_t>(), IEN, nel, o.elem_type,
-                                          S->dE.as<double>(), S->dR.as<double>())))
+    const double tp1 = now_ms();
+    if ((rc = r2s_int::dense_in_nodes_dev(S->dX.as<double>(), nnp, S->dI.as<int64_t>(), nel, o.elem_type, S->dE.as<double>(),
+                                          S->dR.as<double>(), S->pre_ws)))
         return rc;
+    const double tp2 = now_ms();
     if (std::isnan(o.threshold_density)) {
         int it = 0;
         if ((rc = r2s_int::find_threshold_dev(S->dX.as<double>(), S->dI.as<int64_t>(), nel, o.elem_type, S->dR.as<double>(),
@@ -735,6 +739,12 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     if (rho_n_out) HIP_TRY(hipMemcpy(rho_n_out, S->dR.p, sizeof(double) * (size_t)nnp, hipMemcpyDeviceToHost));
     double t2 = now_ms();
     ri.ms_pre = t2 - t;
+    {
+        static const bool timing_env = getenv("R2S_HOST_TIMING") && atoi(getenv("R2S_HOST_TIMING"));
+        if (timing_env)
+            fprintf(stderr, "r2s pre: mesh volume %.2f ms, nodal densities %.2f, threshold %.2f (%d iterations)\n", tp1 - t, tp2 - tp1,
+                    t2 - tp2, ri.threshold_iters);
+    }
     // ---- raw SDF = dists .* signs (:169-171) ----
     if (G == 1 && S->out[2].ensure_exact(sizeof(double) * (size_t)ngp)) return fail(R2S_ERR_NOMEM, "hipMalloc of the SDF volume failed");
     r2s_params prm;

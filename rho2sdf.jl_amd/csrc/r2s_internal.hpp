@@ -12,12 +12,12 @@ namespace r2s_int {
 
 // calculate_mesh_volume (MeshVolume.jl:4-42): d_rho_e[nel] element densities
 int mesh_volume_dev(const double* dX, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_e,
-                    double* V_domain, double* V_frac);
+                    double* V_domain, double* V_frac, DevBuf* ws = nullptr);
 
-// DenseInNodes (NodalDensities.jl:89-218); hIEN is the HOST copy of the connectivity (the ascending node ->
-// element lists are built on the host, mesh-sized)
-int dense_in_nodes_dev(const double* dX, int64_t nnp, const int64_t* dIEN, const int64_t* hIEN, int64_t nel,
-                       int elem_type, const double* d_rho_e, double* d_rho_n_out);
+// DenseInNodes (NodalDensities.jl:89-218); the ascending node -> element lists are built on the device.
+// ws: five buffers the caller keeps between calls (nullptr: temporaries of the call)
+int dense_in_nodes_dev(const double* dX, int64_t nnp, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_e,
+                       double* d_rho_n_out, DevBuf* ws = nullptr);
 
 // find_threshold_for_volume (Isocontour_volume.jl:77-154); TET4: the same bisection over the TET4 iso-volume
 // (the reference has none, SURVEY 8(f)2 - see r2s_pre.hip)

@@ -372,20 +372,122 @@ __global__ void __launch_bounds__(128) dense_in_nodes_kernel(const double* __res
 }
 
 // node -> element CSR in ascending element order (nodeToElementConnectivity, MeshInformations.jl:69-77)
-static int build_ine_host(const int64_t* IEN, int64_t nel, int nen, int64_t nnp, std::vector<uint32_t>& ptr,
-                          std::vector<uint32_t>& ine)
+// ---- node -> elements CSR on the device (each node's elements in ascending order, as a sequential fill leaves them:
+// the sums of dense_in_nodes_kernel run in that order) ----
+__global__ void __launch_bounds__(256) ine_count_kernel(const int64_t* __restrict__ IEN, int64_t total, int64_t nnp,
+                                                       uint32_t* __restrict__ cnt, uint32_t* __restrict__ bad)
 {
-    ptr.assign((size_t)nnp + 1, 0);
-    for (int64_t t = 0; t < nel * nen; ++t) {
-        const int64_t n = IEN[t] - 1;
-        if (n < 0 || n >= nnp) return fail(R2S_ERR_ARG, "IEN contains node ids outside 1..nnp");
-        ptr[(size_t)n + 1]++;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t n = IEN[t] - 1;
+    if (n < 0 || n >= nnp) { *bad = 1u; return; }
+    atomicAdd(&cnt[n], 1u);
+}
+
+#define R2S_SCAN_TILE 1024
+// inclusive scan of one value per thread over a 1024-thread workgroup; `total` = the sum of the workgroup
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave /* 16 */, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
     }
-    for (int64_t n = 0; n < nnp; ++n) ptr[(size_t)n + 1] += ptr[(size_t)n];
-    ine.resize((size_t)nel * nen);
-    std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
-    for (int64_t e = 0; e < nel; ++e)
-        for (int a = 0; a < nen; ++a) ine[cur[(size_t)(IEN[e * nen + a] - 1)]++] = (uint32_t)e;
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t x = s_wave[w];
+        if (w < wave) before += x;
+        all += x;
+    }
+    __syncthreads();
+    total = all;
+    return v + before;
+}
+
+__global__ void __launch_bounds__(R2S_SCAN_TILE) scan_tile_sums_kernel(const uint32_t* __restrict__ in, int64_t n, uint32_t* __restrict__ sums)
+{
+    __shared__ uint32_t s_wave[16];
+    const int64_t i = (int64_t)blockIdx.x * R2S_SCAN_TILE + threadIdx.x;
+    uint32_t total;
+    (void)block_scan_1024(i < n ? in[i] : 0u, s_wave, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(R2S_SCAN_TILE) scan_sums_kernel(uint32_t* __restrict__ sums, int64_t nb)   // one workgroup, in place, exclusive
+{
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    for (int64_t base = 0; base < nb; base += R2S_SCAN_TILE) {
+        const int64_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? sums[i] : 0u;
+        uint32_t total;
+        const uint32_t inc = block_scan_1024(v, s_wave, total);
+        if (i < nb) sums[i] = carry + inc - v;
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(R2S_SCAN_TILE) scan_tiles_kernel(const uint32_t* __restrict__ in, int64_t n, const uint32_t* __restrict__ sums,
+                                                                 uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t s_wave[16];
+    const int64_t i = (int64_t)blockIdx.x * R2S_SCAN_TILE + threadIdx.x;
+    const uint32_t v = i < n ? in[i] : 0u;
+    uint32_t total;
+    const uint32_t inc = block_scan_1024(v, s_wave, total);
+    if (i < n) out[i] = sums[blockIdx.x] + inc - v;
+}
+
+__global__ void __launch_bounds__(256) ine_scatter_kernel(const int64_t* __restrict__ IEN, int64_t total, int nen, int64_t nnp,
+                                                         const uint32_t* __restrict__ ptr, uint32_t* __restrict__ cursor,
+                                                         uint32_t* __restrict__ ine)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t n = IEN[t] - 1;
+    if (n < 0 || n >= nnp) return;
+    ine[ptr[n] + atomicAdd(&cursor[n], 1u)] = (uint32_t)(t / nen);
+}
+
+__global__ void __launch_bounds__(256) ine_sort_kernel(const uint32_t* __restrict__ ptr, uint32_t* __restrict__ ine, int64_t nnp)
+{
+    const int64_t nd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nd >= nnp) return;
+    const uint32_t p0 = ptr[nd], p1 = ptr[nd + 1];
+    for (uint32_t i = p0 + 1; i < p1; ++i) {   // (a handful of entries per node)
+        const uint32_t v = ine[i];
+        uint32_t j = i;
+        for (; j > p0 && ine[j - 1] > v; --j) ine[j] = ine[j - 1];
+        ine[j] = v;
+    }
+}
+
+// ws: [0] ptr (nnp + 1), [1] counts / cursors (nnp + 1), [2] ine, [3] tile sums + the flag
+static int build_ine_dev(const int64_t* dIEN, int64_t nel, int nen, int64_t nnp, DevBuf* ws)
+{
+    const int64_t total = nel * nen, np1 = nnp + 1, nb = (np1 + R2S_SCAN_TILE - 1) / R2S_SCAN_TILE;
+    if (ws[0].ensure(4 * (size_t)np1) || ws[1].ensure(4 * (size_t)np1) || ws[2].ensure(4 * (size_t)total) || ws[3].ensure(4 * (size_t)(nb + 1)))
+        return fail(R2S_ERR_NOMEM, "hipMalloc failed");
+    uint32_t* ptr = ws[0].as<uint32_t>();
+    uint32_t* cnt = ws[1].as<uint32_t>();
+    uint32_t* sums = ws[3].as<uint32_t>();
+    uint32_t* bad = sums + nb;
+    HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)np1, nullptr));
+    HIP_TRY(hipMemsetAsync(bad, 0, 4, nullptr));
+    ine_count_kernel<<<(unsigned)((total + 255) / 256), 256>>>(dIEN, total, nnp, cnt, bad);
+    scan_tile_sums_kernel<<<(unsigned)nb, R2S_SCAN_TILE>>>(cnt, np1, sums);
+    scan_sums_kernel<<<1, R2S_SCAN_TILE>>>(sums, nb);
+    scan_tiles_kernel<<<(unsigned)nb, R2S_SCAN_TILE>>>(cnt, np1, sums, ptr);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)np1, nullptr));
+    ine_scatter_kernel<<<(unsigned)((total + 255) / 256), 256>>>(dIEN, total, nen, nnp, ptr, cnt, ws[2].as<uint32_t>());
+    ine_sort_kernel<<<(unsigned)((nnp + 255) / 256), 256>>>(ptr, ws[2].as<uint32_t>(), nnp);
+    uint32_t h_bad = 0;
+    HIP_TRY(hipMemcpy(&h_bad, bad, 4, hipMemcpyDeviceToHost));
+    if (h_bad) return fail(R2S_ERR_ARG, "IEN contains node ids outside 1..nnp");
     return 0;
 }
 
@@ -415,12 +517,14 @@ static void tables(GaussTab& g3, GaussTab& g15)
 namespace r2s_int {
 
 int mesh_volume_dev(const double* dX, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_e,
-                    double* V_domain, double* V_frac)
+                    double* V_domain, double* V_frac, DevBuf* ws)
 {
-    DevBuf vol, part;
+    DevBuf own[2];   // (ws: two buffers the caller keeps between calls)
+    DevBuf& vol = ws ? ws[0] : own[0];
+    DevBuf& part = ws ? ws[1] : own[1];
     GaussTab g3, g15;
     tables(g3, g15);
-    auto done = [&](int r) { vol.release(); part.release(); return r; };
+    auto done = [&](int r) { own[0].release(); own[1].release(); return r; };
     if (vol.ensure(sizeof(double) * (size_t)nel)) return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
     if (elem_type == R2S_HEX8)
         elem_volume_kernel<<<(unsigned)((nel + 3) / 4), 256>>>(dX, dIEN, nullptr, nel, 0, 0.0, g3, g15, vol.as<double>());
@@ -434,23 +538,19 @@ int mesh_volume_dev(const double* dX, const int64_t* dIEN, int64_t nel, int elem
     return done(0);
 }
 
-int dense_in_nodes_dev(const double* dX, int64_t nnp, const int64_t* dIEN, const int64_t* hIEN, int64_t nel,
-                       int elem_type, const double* d_rho_e, double* d_rho_n_out)
+int dense_in_nodes_dev(const double* dX, int64_t nnp, const int64_t* dIEN, int64_t nel, int elem_type, const double* d_rho_e,
+                       double* d_rho_n_out, DevBuf* ws)
 {
     const int nen = elem_type == R2S_HEX8 ? 8 : 4;
-    std::vector<uint32_t> ptr, ine;
-    int rc = build_ine_host(hIEN, nel, nen, nnp, ptr, ine);
-    if (rc) return rc;
-    DevBuf dptr, dine, C;
-    auto done = [&](int r) { dptr.release(); dine.release(); C.release(); return r; };
-    if (dptr.ensure(4 * ptr.size()) || dine.ensure(4 * ine.size()) || C.ensure(sizeof(double) * 3 * (size_t)nel))
-        return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
-    if (hipMemcpy(dptr.p, ptr.data(), 4 * ptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dine.p, ine.data(), 4 * ine.size(), hipMemcpyHostToDevice) != hipSuccess)
-        return done(fail(R2S_ERR_HIP, "hipMemcpy failed"));
-    centroid_kernel<<<(unsigned)((nel + 255) / 256), 256>>>(dX, dIEN, nel, nen, C.as<double>());
-    dense_in_nodes_kernel<<<(unsigned)((nnp + 127) / 128), 128>>>(dX, nnp, dptr.as<uint32_t>(), dine.as<uint32_t>(),
-                                                                 C.as<double>(), d_rho_e, d_rho_n_out);
+    DevBuf own[5];   // (ws: five buffers the caller keeps between calls)
+    DevBuf* b = ws ? ws : own;
+    auto done = [&](int r) { for (DevBuf& x : own) x.release(); return r; };
+    int rc = build_ine_dev(dIEN, nel, nen, nnp, b);
+    if (rc) return done(rc);
+    if (b[4].ensure(sizeof(double) * 3 * (size_t)nel)) return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
+    centroid_kernel<<<(unsigned)((nel + 255) / 256), 256>>>(dX, dIEN, nel, nen, b[4].as<double>());
+    dense_in_nodes_kernel<<<(unsigned)((nnp + 127) / 128), 128>>>(dX, nnp, b[0].as<uint32_t>(), b[2].as<uint32_t>(), b[4].as<double>(), d_rho_e,
+                                                                 d_rho_n_out);
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return done(fail(R2S_ERR_HIP, "dense_in_nodes kernels failed: %s", hipGetErrorString(e)));
@@ -562,7 +662,7 @@ int r2s_dense_in_nodes(const double* X, int64_t nnp, const int64_t* IEN, int64_t
         return done(fail(R2S_ERR_NOMEM, "hipMalloc failed"));
     if (hipMemcpy(rho.p, rho_e, sizeof(double) * (size_t)nel, hipMemcpyHostToDevice) != hipSuccess)
         return done(fail(R2S_ERR_HIP, "hipMemcpy failed"));
-    if ((rc = r2s_int::dense_in_nodes_dev(m.X.as<double>(), nnp, m.IEN.as<int64_t>(), IEN, nel, elem_type, rho.as<double>(),
+    if ((rc = r2s_int::dense_in_nodes_dev(m.X.as<double>(), nnp, m.IEN.as<int64_t>(), nel, elem_type, rho.as<double>(),
                                           out.as<double>())))
         return done(rc);
     if (hipMemcpy(rho_n_out, out.p, sizeof(double) * (size_t)nnp, hipMemcpyDeviceToHost) != hipSuccess)

@@ -23,6 +23,27 @@ def test_mesh_volume_and_nodal_densities(pkg, oracle, name):
         assert rn.mean() == pytest.approx(0.29490556408887564, rel=1e-10, abs=1e-12)
 
 
+def test_nodal_densities_node_lists_from_the_device(pkg, oracle):
+    """the node -> element lists of DenseInNodes are built on the device (counts, scan, scatter, per-node sort): the result
+    is the same number for number whatever order the scatter's atomics ran in, also on a shuffled connectivity, and node
+    ids outside 1..nnp are an error, not a fault"""
+    from rho2sdf_jl_amd import synthetic
+    X, IT, _ = synthetic.tet_mesh(9)
+    rng = np.random.default_rng(5)
+    rho = rng.random(len(IT))
+    a = pkg.DenseInNodes(pkg.Mesh(X, IT), rho)
+    for _ in range(3):
+        assert np.array_equal(pkg.DenseInNodes(pkg.Mesh(X, IT), rho), a)
+    assert np.abs(a - oracle.dense_in_nodes(X, IT, rho)).max() <= 1e-12
+    bad = IT.copy()
+    bad[7, 2] = len(X) + 1
+    with pytest.raises(pkg._lib.R2SError, match="outside 1..nnp"):
+        pkg.DenseInNodes(pkg.Mesh(X, bad), rho)
+    bad[7, 2] = 0
+    with pytest.raises(pkg._lib.R2SError, match="outside 1..nnp"):
+        pkg.DenseInNodes(pkg.Mesh(X, bad), rho)
+
+
 @pytest.mark.parametrize("name", ["beam_vfrac_03", "beam_vfrac_04"])
 def test_find_threshold(pkg, oracle, name):
     X, IEN, rho = load_fixture(name)
