@@ -1684,6 +1684,153 @@ static int rbf_lut_axis(const std::vector<float>& t, const std::vector<float>& c
     }
     return most;
 }
+// ---- the evaluation on a REFINED grid (rbf_grid = :fine, smooth = s >= 2) through tables ----------------------------
+// A target (i, j, k) of parity class (i % s, j % s, k % s) sees the sources around (i / s, j / s, k / s) through the
+// stencil of its class (build_stencil); the Float32 coordinate differences per axis, parity and offset take a few dozen
+// distinct values, so the kernel values of a class are a table [neighbour][z variant][y variant][x variant] evaluated once
+// with rbf_apply_kernel's arithmetic.  One WAVEFRONT = 64 targets of ONE parity in x of one row: the stencil, the y / z
+// variants and the table row are wave-uniform (scalar loads), the sources of a neighbour are 64 consecutive weights, and a
+// neighbour costs two vector loads + the Float64 product and sum instead of ~60 instructions of distance and exp.  Same
+// values, same order, same skips (sources outside the lattice; dist > max_distance <=> entry 0) => the same numbers.
+struct FineTap {
+    int32_t woff;              // (dk ny + dj) nx + di
+    signed char di, dj, dk, pad;
+};
+struct FineLut {
+    int s, fx, fy, nx, ny, nzc, nmx, nmy, nmz, nvf, nrec;
+    const uint64_t *idx, *idy, *idz;   // [parity][index / s]: the variant ids of the 8 offsets -3..4, a byte each (255: no such source)
+    const double* T;
+    const FineTap* taps;       // [class][512]
+    const int64_t* tbase;      // [class]: first entry of the class's table
+    const int* ntaps;          // [class]
+};
+
+static bool fine_lut_axis(const std::vector<float>& t, const std::vector<float>& c, int s, std::vector<uint64_t>& packs,
+                          std::vector<float>& vals /* [s][8][64] */, int& most)
+{
+    const int tn = (int)t.size(), cn = (int)c.size(), nm = (tn + s - 1) / s;
+    packs.assign((size_t)s * nm, ~0ull);
+    vals.assign((size_t)s * 8 * 64, NAN);
+    for (int p = 0; p < s; ++p)
+        for (int d8 = 0; d8 < 8; ++d8) {
+            const int d = d8 - 3;
+            std::vector<float> u;
+            for (int m = 0; m * s + p < tn; ++m)
+                if (m + d >= 0 && m + d < cn) u.push_back(t[(size_t)m * s + p] - c[(size_t)(m + d)]);   // px - G.cx[ci] of rbf_apply_point
+            std::sort(u.begin(), u.end());
+            u.erase(std::unique(u.begin(), u.end()), u.end());
+            if (u.size() > 63) return false;
+            most = std::max(most, (int)u.size());
+            for (size_t q = 0; q < u.size(); ++q) vals[((size_t)p * 8 + d8) * 64 + q] = u[q];
+            for (int m = 0; m * s + p < tn; ++m) {
+                if (m + d < 0 || m + d >= cn) continue;
+                const float v = t[(size_t)m * s + p] - c[(size_t)(m + d)];
+                const uint64_t id = (uint64_t)(std::lower_bound(u.begin(), u.end(), v) - u.begin());
+                uint64_t& pk = packs[(size_t)p * nm + m];
+                pk = (pk & ~(0xffull << (8 * d8))) | (id << (8 * d8));
+            }
+        }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) fine_lut_build_kernel(const FineTap* __restrict__ taps, int ntaps, const float* __restrict__ vx,
+                                                            const float* __restrict__ vy, const float* __restrict__ vz, double sigma,
+                                                            float max_distance, int nvf, double* __restrict__ T)
+{
+    __shared__ double etab[64];
+    if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_neg_64[threadIdx.x];
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)ntaps * nvf * nvf * nvf) return;
+    const int a = (int)(t % nvf), b = (int)((t / nvf) % nvf), c = (int)((t / ((int64_t)nvf * nvf)) % nvf);
+    const int q = (int)(t / ((int64_t)nvf * nvf * nvf));
+    const FineTap tp = taps[q];
+    const float dx = vx[(tp.di + 3) * 64 + a], dy = vy[(tp.dj + 3) * 64 + b], dz = vz[(tp.dk + 3) * 64 + c];
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    const double inv_sigma = 1.0 / sigma;
+    double val = 0.0;
+    if (dist <= max_distance) {   // (NaN differences of unused variant slots: false)
+        const double u = (double)dist * inv_sigma;
+        val = exp_neg_fast(u * u, etab);
+    }
+    T[t] = val;
+}
+
+__global__ void __launch_bounds__(256) rbf_apply_fine_lut_kernel(FineLut F, const float* __restrict__ w, float add, float* __restrict__ out,
+                                                                int kf0, int kf1)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    // per wavefront and neighbour: byte offset of its table row, byte offset of its weights, shift of the x variant id
+    // (F.nrec entries per wavefront: the longest list of the classes, rounded up to batches)
+    extern __shared__ u32x4 s_rec_all[];
+    u32x4* const s_rec = s_rec_all + (size_t)(threadIdx.x >> 6) * F.nrec;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t nseg = (uint32_t)(F.nmx + 63) / 64u;
+    const uint32_t per_row = (uint32_t)F.s * nseg;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);   // (the host keeps the count below 2^32)
+    const uint32_t row = wave / per_row;
+    const uint32_t rem = wave - row * per_row;
+    const int k = kf0 + (int)(row / (uint32_t)F.fy), j = (int)(row % (uint32_t)F.fy);
+    const bool live = k < kf1;   // (wavefronts past the end of the chunk keep the barrier company)
+    const int kk = live ? k : kf0;
+    const int pi = (int)(rem / nseg), seg = (int)(rem % nseg);
+    const int pk = kk % F.s, bk = kk / F.s, pj = j % F.s, bj = j / F.s;
+    const int m = seg * 64 + (int)lane, i = m * F.s + pi;
+    const bool active = live && i < F.fx;
+    const int cls = (pk * F.s + pj) * F.s + pi;
+    const FineTap* __restrict__ taps = F.taps + (size_t)cls * 512;
+    const int ntaps = __builtin_amdgcn_readfirstlane(F.ntaps[cls]);
+    const uint32_t nvf = (uint32_t)F.nvf;
+    // "no such source" is variant slot nvf - 1 on every axis: no difference has that id, its table entries are 0 (built
+    // from NaN differences) = "beyond max_distance", and whatever weight the address of such a neighbour holds is not used
+    const uint64_t pz = F.idz[(size_t)pk * F.nmz + bk], py = F.idy[(size_t)pj * F.nmy + bj];
+    const uint64_t px = active ? F.idx[(size_t)pi * F.nmx + m] : F.idx[(size_t)F.s * F.nmx];   // (an all-absent pack behind the axis)
+    // what is the same for the 64 targets of the wavefront, once per neighbour (lane q prepares neighbour q): everything
+    // but the x variant.  A batch of the loop below may run past the end of the list: such entries get a table offset
+    // beyond the class's table
+    const int nrec = (ntaps + 7) & ~7;
+    for (int q = (int)lane; q < nrec; q += 64) {
+        const FineTap tp = taps[q];
+        const uint32_t c = (uint32_t)(pz >> (8 * (tp.dk + 3))) & 255u, b = (uint32_t)(py >> (8 * (tp.dj + 3))) & 255u;
+        u32x4 r;
+        r.x = q < ntaps ? ((((uint32_t)q * nvf + c) * nvf + b) * nvf) * 8u : 0x80000000u;   // (no wrap-around when the x variant is added)
+        r.y = (uint32_t)tp.woff * 4u;
+        r.z = (uint32_t)(8 * (tp.di + 3));
+        r.w = 0u;
+        s_rec[q] = r;
+    }
+    __syncthreads();
+    if (!live) return;
+    // buffer loads: out-of-range offsets read 0
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((uint32_t)F.nx * (uint32_t)F.ny * (uint32_t)F.nzc * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)(F.T + F.tbase[cls]), 0, (int)((uint32_t)ntaps * nvf * nvf * nvf * 8u), 0x00020000);
+    const uint32_t wlane = (uint32_t)((((int64_t)bk * F.ny + bj) * F.nx + m) * 4);
+    float acc = 0.0f;
+    // batches of FINE_BATCH neighbours: the loads of a batch are in flight together (a neighbour at a time the kernel waits
+    // for two dependent loads per neighbour: 26 ms instead of the 22 of the on-the-fly evaluation at 257^3 -> 513^3)
+    // (issuing the loads of the next batch before the sums of this one: 9.8 instead of 8.8 ms)
+    constexpr int FINE_BATCH = 8;
+    for (int q0 = 0; q0 < ntaps; q0 += FINE_BATCH) {
+        uint32_t wb[FINE_BATCH];
+        u32x2 eb[FINE_BATCH];
+#pragma unroll
+        for (int u = 0; u < FINE_BATCH; ++u) {
+            const u32x4 r = s_rec[q0 + u];   // (one address for the wavefront: a broadcast read)
+            const uint32_t a = (uint32_t)(px >> r.z) & 255u;
+            wb[u] = __builtin_amdgcn_raw_buffer_load_b32(rW, (int)(wlane + r.y), 0, 0);
+            eb[u] = __builtin_amdgcn_raw_buffer_load_b64(rT, (int)(r.x + a * 8u), 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < FINE_BATCH; ++u) {
+            const double e = __hiloint2double((int)eb[u].y, (int)eb[u].x);
+            const float nv = (float)((double)acc + (double)__uint_as_float(wb[u]) * e);
+            acc = e != 0.0 ? nv : acc;   // (a select, not a branch: the skipped neighbours are few)
+        }
+    }
+    if (active) out[((int64_t)k * F.fy + j) * F.fx + i] = acc + add;
+}
+
 // process_vector (:15-22), pass 1: max |v| over |v| < 1e9 (as Float32 bits, all non-negative)
 __global__ void pv_max_kernel(const double* __restrict__ v, int64_t n, float* __restrict__ f, uint32_t* __restrict__ maxbits,
                               uint32_t* __restrict__ any)
@@ -1893,7 +2040,7 @@ static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
 }
 
 struct RbfWork {   // the device buffers of one rbf_smooth_host call
-    DevBuf b[34];
+    DevBuf b[40];
     VolumeWork vw;
     void release()
     {
@@ -1924,7 +2071,8 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
            &d_tx = W.b[8], &d_ty = W.b[9], &d_tz = W.b[10], &d_st = W.b[11], &d_cnt = W.b[12], &d_r = W.b[13], &d_u = W.b[14], &d_q = W.b[15],
            &d_part = W.b[16], &d_sum = W.b[17], &d_lut = W.b[18], &d_luta = W.b[19], &d_vx = W.b[20], &d_vy = W.b[21], &d_vz = W.b[22],
            &d_lutf = W.b[23], &d_fvx = W.b[24], &d_fvy = W.b[25], &d_fvz = W.b[26], &d_lv = W.b[27], &d_lvf = W.b[28], &d_luta16 = W.b[29],
-           &d_wt = W.b[30], &d_wa = W.b[31], &d_waf = W.b[32], &d_part2 = W.b[33];
+           &d_wt = W.b[30], &d_wa = W.b[31], &d_waf = W.b[32], &d_part2 = W.b[33], &d_fl_ids = W.b[34], &d_fl_vals = W.b[35],
+           &d_fl_T = W.b[36], &d_fl_taps = W.b[37], &d_fl_meta = W.b[38];
     VolumeWork& vw = W.vw;
     auto cleanup = [&]() {
         if (!ws) W.release();
@@ -2006,6 +2154,85 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         const double R2 = -std::log(kthr);                 // support radius^2 in cells (sigma = cell size)
         G.tap_d2 = (int)std::floor(R2 * 1.05 + 0.25);      // 1e-3 -> 7 (i.e. 6: 7 is not a sum of three squares)
         G.tap_r = (int)std::floor(std::sqrt((double)G.tap_d2));
+    }
+    // ---- refined output grid: the tables of its parity classes (R2S_RBF_APPLY=fly: on the fly, the tests compare) ----
+    FineLut FL;
+    memset(&FL, 0, sizeof FL);
+    if (smooth >= 2 && !(getenv("R2S_RBF_APPLY") && getenv("R2S_RBF_APPLY")[0] == 'f')) {
+        const int ncls = smooth * smooth * smooth;
+        std::vector<uint64_t> pkx, pky, pkz;
+        std::vector<float> vlx, vly, vlz;
+        int most = 1;
+        const bool fits = fine_lut_axis(tx, cx, smooth, pkx, vlx, most) && fine_lut_axis(ty, cy, smooth, pky, vly, most) &&
+                          fine_lut_axis(tz, cz, smooth, pkz, vlz, most);
+        const int nvf = most <= 15 ? 16 : (most <= 31 ? 32 : 64);
+        for (std::vector<uint64_t>* pkp : {&pkx, &pky, &pkz})   // "no such source" = the unused slot nvf - 1 (see the kernel)
+            for (uint64_t& v : *pkp)
+                for (int d8 = 0; d8 < 8; ++d8)
+                    if (((v >> (8 * d8)) & 255u) == 255u) v = (v & ~(0xffull << (8 * d8))) | ((uint64_t)(nvf - 1) << (8 * d8));
+        {
+            uint64_t none = 0;
+            for (int d8 = 0; d8 < 8; ++d8) none |= (uint64_t)(nvf - 1) << (8 * d8);
+            pkx.push_back(none);   // (the pack of the lanes beyond the end of a row)
+        }
+        std::vector<FineTap> taps((size_t)ncls * 512);
+        std::vector<int64_t> tbase((size_t)ncls);
+        std::vector<int> ntaps((size_t)ncls);
+        int64_t total = 0;
+        bool ok = fits;
+        for (int c = 0; c < ncls && ok; ++c) {
+            const Stencil& S = sts[1 + (size_t)c];
+            if (S.n > 512 - 8) ok = false;   // (the kernel reads its batches past the end of a list)
+            tbase[(size_t)c] = total;
+            ntaps[(size_t)c] = S.n;
+            total += (int64_t)S.n * nvf * nvf * nvf;
+            for (int q = 0; q < S.n && ok; ++q) {
+                FineTap& tp = taps[(size_t)c * 512 + q];
+                tp.di = S.off[q][0]; tp.dj = S.off[q][1]; tp.dk = S.off[q][2]; tp.pad = 0;
+                if (tp.di < -3 || tp.di > 4 || tp.dj < -3 || tp.dj > 4 || tp.dk < -3 || tp.dk > 4) ok = false;
+                tp.woff = (int32_t)(((int64_t)tp.dk * ny + tp.dj) * nx + tp.di);
+            }
+        }
+        const int64_t waves = (int64_t)fz * fy * smooth * (((fx + smooth - 1) / smooth + 63) / 64);
+        if (ok && total * 8 <= ((int64_t)8 << 30) && n * 4 < ((int64_t)1 << 32) && waves < ((int64_t)1 << 32)) {
+            const size_t nid = pkx.size() + pky.size() + pkz.size();
+            ENSURE_C(d_fl_ids, 8 * nid);
+            ENSURE_C(d_fl_vals, 4 * (vlx.size() + vly.size() + vlz.size()));
+            ENSURE_C(d_fl_T, 8 * (size_t)total);
+            ENSURE_C(d_fl_taps, sizeof(FineTap) * taps.size());
+            ENSURE_C(d_fl_meta, 8 * (size_t)ncls + 4 * (size_t)ncls);
+            uint64_t* dids = d_fl_ids.as<uint64_t>();
+            HIP_C(hipMemcpy(dids, pkx.data(), 8 * pkx.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(dids + pkx.size(), pky.data(), 8 * pky.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(dids + pkx.size() + pky.size(), pkz.data(), 8 * pkz.size(), hipMemcpyHostToDevice));
+            float* dv = d_fl_vals.as<float>();
+            HIP_C(hipMemcpy(dv, vlx.data(), 4 * vlx.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(dv + vlx.size(), vly.data(), 4 * vly.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(dv + vlx.size() + vly.size(), vlz.data(), 4 * vlz.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(d_fl_taps.p, taps.data(), sizeof(FineTap) * taps.size(), hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy(d_fl_meta.p, tbase.data(), 8 * (size_t)ncls, hipMemcpyHostToDevice));
+            HIP_C(hipMemcpy((char*)d_fl_meta.p + 8 * (size_t)ncls, ntaps.data(), 4 * (size_t)ncls, hipMemcpyHostToDevice));
+            const double sigma = g->cell_size;
+            const float maxd = (float)std::sqrt(-std::log(kthr) * sigma * sigma);
+            for (int c = 0; c < ncls; ++c) {
+                const int pi = c % smooth, pj = (c / smooth) % smooth, pk = c / (smooth * smooth);
+                const int64_t nt = (int64_t)ntaps[(size_t)c] * nvf * nvf * nvf;
+                if (!nt) continue;
+                fine_lut_build_kernel<<<(unsigned)((nt + 255) / 256), 256, 0, st>>>(
+                    d_fl_taps.as<FineTap>() + (size_t)c * 512, ntaps[(size_t)c], dv + (size_t)pi * 8 * 64, dv + vlx.size() + (size_t)pj * 8 * 64,
+                    dv + vlx.size() + vly.size() + (size_t)pk * 8 * 64, sigma, maxd, nvf, d_fl_T.as<double>() + tbase[(size_t)c]);
+            }
+            FL.s = smooth; FL.fx = fx; FL.fy = fy; FL.nx = nx; FL.ny = ny; FL.nzc = nz;
+            FL.nmx = (fx + smooth - 1) / smooth; FL.nmy = (fy + smooth - 1) / smooth; FL.nmz = (fz + smooth - 1) / smooth;
+            FL.nvf = nvf;
+            FL.nrec = 8;
+            for (int c = 0; c < ncls; ++c) FL.nrec = std::max(FL.nrec, (ntaps[(size_t)c] + 7) & ~7);
+            FL.idx = dids; FL.idy = dids + pkx.size(); FL.idz = dids + pkx.size() + pky.size();
+            FL.T = d_fl_T.as<double>();
+            FL.taps = d_fl_taps.as<FineTap>();
+            FL.tbase = (const int64_t*)d_fl_meta.p;
+            FL.ntaps = (const int*)((const char*)d_fl_meta.p + 8 * (size_t)ncls);
+        }
     }
     // ---- tables of the distinct kernel values: the CG matvec (T) and the evaluation on the same grid (TA) ----
     // (exact, no matrix in memory; R2S_RBF_MATVEC=k|fly and R2S_RBF_APPLY=fly force the other paths - the tests compare them)
@@ -2232,8 +2459,11 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             const int f0 = (int)((int64_t)fz * c / nchunk), f1 = (int)((int64_t)fz * (c + 1) / nchunk);
             const int64_t t0 = (int64_t)f0 * fx * fy, t1 = (int64_t)f1 * fx * fy;
             const unsigned nbc = (unsigned)((t1 - t0 + 255) / 256);
-            if (!(fine_one_to_one && launch_rbf_apply_lut(G, LGF, sts[1], nbc, st, d_w.as<float>(), d_tx.as<float>(), d_ty.as<float>(),
-                                                          d_tz.as<float>(), d_st.as<Stencil>() + 1, add, dfine, t0, t1)))
+            if (FL.T) {
+                const int64_t waves = (int64_t)(f1 - f0) * fy * smooth * ((FL.nmx + 63) / 64);
+                rbf_apply_fine_lut_kernel<<<(unsigned)((waves + 3) / 4), 256, (size_t)FL.nrec * 4 * 16, st>>>(FL, d_w.as<float>(), add, dfine, f0, f1);
+            } else if (!(fine_one_to_one && launch_rbf_apply_lut(G, LGF, sts[1], nbc, st, d_w.as<float>(), d_tx.as<float>(), d_ty.as<float>(),
+                                                                 d_tz.as<float>(), d_st.as<Stencil>() + 1, add, dfine, t0, t1)))
                 rbf_apply_kernel<<<nbc, 256, 0, st>>>(G, d_w.as<float>(), smooth, fx, fy, fz, d_tx.as<float>(), d_ty.as<float>(),
                                                      d_tz.as<float>(), d_st.as<Stencil>() + 1, add, dfine, t0, t1);
             if (fine_chunk) {

@@ -335,3 +335,30 @@ def test_rbf_evaluation_table_is_bit_identical(pkg, oracle, monkeypatch, interp)
         assert outs[mode][1] == outs["lut"][1]
         assert np.array_equal(outs[mode][0], outs["lut"][0]) and np.array_equal(outs[mode][2], outs["lut"][2])
     assert np.isfinite(outs["lut"][0]).all() and np.ptp(outs["lut"][0]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("smooth,dims", [(2, (40, 23, 17)), (3, (21, 30, 13)), (2, (131, 9, 70)), (4, (12, 11, 15))])
+def test_rbf_refined_grid_tables_are_bit_identical(pkg, monkeypatch, smooth, dims):
+    """rbf_grid = :fine (smooth >= 2): the output field through the tables of its parity classes (one wavefront = 64
+    targets of one parity of a row) vs neighbour-by-neighbour evaluation (R2S_RBF_APPLY=fly) - same values, same order,
+    on lattices whose sizes are no multiples of anything, with sentinels in the input"""
+    rng = np.random.default_rng(sum(dims) + smooth)
+    lo = np.array([0.375, -0.25, 0.125])   # (dyadic numbers: the cell count of `Grid` comes out exact)
+    pg = pkg.Grid(lo, lo + 0.125 * (np.array(dims) - 1.0), max(dims) - 1, 0)
+    assert pg.dims == dims
+    ax = [pg.AABB_min[i] + pg.cell_size * np.arange(n) for i, n in enumerate(dims)]
+    c = [0.45 * (a[0] + a[-1]) for a in ax]
+    r = np.sqrt((ax[0][None, None, :] - c[0]) ** 2 + (ax[1][None, :, None] - c[1]) ** 2 + (ax[2][:, None, None] - c[2]) ** 2)
+    sdf = (0.3 * pg.cell_size * max(dims) - r + 0.01 * rng.normal(size=r.shape)).ravel()
+    sdf[rng.random(sdf.size) < 0.05] = 1e10
+    vol = max(float((sdf > 0).sum()), 1.0) * pg.cell_size ** 3
+    outs = {}
+    for mode in ("walk", "fly"):
+        _set_rbf_mode(monkeypatch, mode, ("R2S_RBF_APPLY",))
+        info = {}
+        outs[mode] = (pkg.RBFs_smoothing(sdf, pg, True, smooth, vol, info=info), info["th"])
+    assert outs["walk"][0].size == np.prod([(d - 1) * smooth + 1 for d in dims])
+    assert outs["walk"][1] == outs["fly"][1]
+    assert np.array_equal(outs["walk"][0], outs["fly"][0])
+    assert np.isfinite(outs["walk"][0]).all() and np.ptp(outs["walk"][0]) > 0
