@@ -26,7 +26,15 @@ import os
 import sys
 import time
 
-import numpy as np
+# The CPU share of a GPU box is a cgroup quota (16 CPUs) on a host with 256 visible ones: libgomp / OpenBLAS under torch and
+# numpy start one thread per VISIBLE CPU, and their idle spinning after any parallel region uses the quota up - the whole
+# process is then throttled for tens of ms, which the host threads of the e2e legs (16 of them: fill, scatter, staged
+# copies) pay for (tools/throttle_check.sh: nr_throttled in cpu.stat, e2e 13-16 ms -> 9 ms with this setting).  Nothing in
+# this script needs OpenMP.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -269,12 +269,34 @@ void fill_stream(double* p, int64_t n, double v)
     std::atomic_thread_fence(std::memory_order_seq_cst);   // (sfence: the streamed lines are visible before the scatter)
 }
 
+// CPUs the process may actually use: a container's share is a cgroup quota (cpu.max: "1600000 100000" = 16 CPUs) on a
+// host that shows all of its CPUs to hardware_concurrency(); threads beyond the quota only get the process throttled
+static unsigned usable_cpus()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2
+        char q[32] = {0};
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+            n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, atoll(q) / period));
+        fclose(f);
+    } else {   // cgroup v1
+        long long quota = -1, period = 0;
+        if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+        if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+        if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, quota / period));
+    }
+    return n;
+}
+
 void ensure_pool(HostSession* S)
 {
     if (S->pool) return;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = usable_cpus();
     static const int env = getenv("R2S_HOST_THREADS") ? atoi(getenv("R2S_HOST_THREADS")) : 0;
-    S->pool = new CopyPool(env > 0 ? std::min(env, 64) : (int)std::min(16u, std::max(2u, hw / 2)));
+    // (default: 16, or the CPU quota of the container if that is smaller; a host without a quota: half of its CPUs at most)
+    const unsigned all = std::max(1u, std::thread::hardware_concurrency());
+    S->pool = new CopyPool(env > 0 ? std::min(env, 64) : (int)std::min(16u, std::max(2u, hw < all ? hw : all / 2)));
 }
 
 // device -> host.  Pinned destination: plain DMA.  Pageable: DMA into the two staging buffers, each staged chunk

@@ -31,6 +31,9 @@ cp $(ls $OUT/prof_$TAG/rbf/*/*kernel_stats.csv | head -1) $OUT/${TAG}_rbf_kernel
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_$TAG/rbf_fetch -- python3 $ROOT/tools/rbf_bench.py --interp --reps 1 > /dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_$TAG/rbf_write -- python3 $ROOT/tools/rbf_bench.py --interp --reps 1 > /dev/null
 python3 $ROOT/tools/collect_traffic.py $OUT/prof_$TAG/rbf_fetch $OUT/prof_$TAG/rbf_write $OUT/${TAG}_rbf_traffic.json
+# the output field on a refined grid (rbf_grid = :fine, BASELINE config 3's shape: 257^3 -> 513^3)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/rbf_fine -- python3 $ROOT/tools/rbf_bench.py --interp --grid 256 --smooth 2 --reps 2 > $OUT/${TAG}_rbf_fine_bench.json
+cp $(ls $OUT/prof_$TAG/rbf_fine/*/*kernel_stats.csv | head -1) $OUT/${TAG}_rbf_fine_kernel_stats.csv
 # ... and their SQ / TA / TCP counters (tools/rbf_pmc.sh: one --pmc pass per counter group)
 bash $ROOT/tools/rbf_pmc.sh ${TAG}_rbf > /dev/null
 # the whole rho2sdf() call: kernel stats per call
