@@ -698,6 +698,49 @@ __global__ void __launch_bounds__(256) volume_narrow_kernel(const float* __restr
     }
 }
 
+// Small results back to the host WITHOUT the copy engine: a kernel writes them into pinned host memory and the host waits
+// for the stream.  (A hipMemcpy of a few KB queues behind whatever bulk transfer the engine is busy with - in r2s_rho2sdf the
+// cleaned field, 1.07 GB in 32 MB pieces, travels while the CG runs, and each of its ~25 scalar read-backs waited up to
+// 0.6 ms for a piece to finish: the RBF stage took 38 or 46 ms depending on which engine the runtime had picked.)
+struct HostMailbox {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        release();
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+        cap = bytes;
+        return true;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+__global__ void __launch_bounds__(256) mailbox_copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t nwords)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nwords) dst[i] = src[i];
+}
+// host <- device, `bytes` a multiple of 4 and small; orders like a hipMemcpy on `st` followed by a stream synchronisation
+static int d2h_small(void* host, const void* dev, size_t bytes, hipStream_t st, HostMailbox& mb)
+{
+    static const bool off = getenv("R2S_MAILBOX") && atoi(getenv("R2S_MAILBOX")) == 0;   // (A/B switch)
+    if (off || bytes == 0 || (bytes & 3u) || bytes > ((size_t)1 << 20) || !mb.ensure(std::max<size_t>(bytes, (size_t)64 << 10))) {
+        HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
+    const size_t nw = bytes / 4;
+    mailbox_copy_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>((const uint32_t*)dev, (uint32_t*)mb.p, nw);
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(host, mb.p, bytes);
+    return 0;
+}
+
 static int vol_grid()
 {
     static const int g = getenv("R2S_VOL_GRID") ? atoi(getenv("R2S_VOL_GRID")) : 16384;
@@ -705,6 +748,7 @@ static int vol_grid()
 }
 struct VolumeWork {
     DevBuf partial, result, segmn, segmx, qpts, live[2], cnt, cfull;
+    HostMailbox mb;
     float qpts_jac = -1.0f;             // the Jacobian the point table was built with
     const float* seg_field = nullptr;   // the field the segment extrema were computed for (prepare)
     int cur = -1;                       // live[cur]: the rows the levels still work on (-1: all rows)
@@ -786,12 +830,11 @@ struct VolumeWork {
             segs ? segmx.as<float>() : nullptr, qpts.as<float4>(), listed ? live[cur].as<int>() : nullptr,
             listed ? cnt.as<uint32_t>() + cur : nullptr);
         sum_f32_kernel<<<1, 1024, 0, st>>>(partial.as<float>(), nrows, result.as<float>());
-        HIP_TRY(hipMemcpyAsync(out, result.p, sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return 0;
+        return d2h_small(out, result.p, sizeof(float), st, mb);
     }
     void release()
     {
+        mb.release();
         partial.release(); result.release(); segmn.release(); segmx.release(); qpts.release(); live[0].release(); live[1].release();
         cnt.release(); cfull.release();
         seg_field = nullptr; qpts_jac = -1.0f; cur = -1;
@@ -2042,8 +2085,10 @@ static void coarse_coords(double mn, double mx, int n, std::vector<float>& c)
 struct RbfWork {   // the device buffers of one rbf_smooth_host call
     DevBuf b[40];
     VolumeWork vw;
+    HostMailbox mb;
     void release()
     {
+        mb.release();
         for (DevBuf& x : b) x.release();
         vw.release();
     }
@@ -2105,7 +2150,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     const unsigned nb = (unsigned)((n + 255) / 256);
     pv_max_kernel<<<(nb < 2048u ? nb : 2048u), 256, 0, st>>>(dsdf, n, d_f.as<float>(), d_cnt.as<uint32_t>(), d_cnt.as<uint32_t>() + 1);
     uint32_t hc[2];
-    HIP_C(hipMemcpy(hc, d_cnt.p, 8, hipMemcpyDeviceToHost));
+    TRY_C(d2h_small(hc, d_cnt.p, 8, st, W.mb));
     if (!hc[1]) { cleanup(); return fail(R2S_ERR_ARG, "every SDF value is a sentinel: nothing to smooth"); }   // A15
     pv_replace_kernel<<<nb, 256, 0, st>>>(d_f.as<float>(), n, d_cnt.as<uint32_t>());
     // ---- geometry ----
@@ -2334,7 +2379,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         auto dot = [&](const float* a, const float* b, float* out) -> int {
             dot_planes_kernel<<<nz * DOT_PARTS, 256, 0, st>>>(a, b, (int64_t)nx * ny, d_part.as<double>());
             std::vector<double> hp((size_t)nz * DOT_PARTS);
-            HIP_TRY(hipMemcpy(hp.data(), d_part.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
+            { const int rc_ = d2h_small(hp.data(), d_part.p, sizeof(double) * hp.size(), st, W.mb); if (rc_) return rc_; }
             double h = 0.0;
             for (double v : hp) h += v;   // parts in (k, part) order (see dot_planes_kernel)
             *out = (float)h;
@@ -2344,7 +2389,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             cg_update_xr_dot_kernel<<<nz * DOT_PARTS, 256, 0, st>>>(d_w.as<float>(), d_r.as<float>(), d_u.as<float>(), d_q.as<float>(), alpha,
                                                                    (int64_t)nx * ny, d_part.as<double>());
             std::vector<double> hp((size_t)nz * DOT_PARTS);
-            HIP_TRY(hipMemcpy(hp.data(), d_part.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
+            { const int rc_ = d2h_small(hp.data(), d_part.p, sizeof(double) * hp.size(), st, W.mb); if (rc_) return rc_; }
             double h = 0.0;
             for (double v : hp) h += v;
             *out = (float)h;
@@ -2385,7 +2430,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
         ENSURE_C(d_part2, sizeof(double) * std::max(nparts, (size_t)1));
         std::vector<double> hp2(nparts);
         auto sum_parts2 = [&](float* out) -> int {
-            HIP_TRY(hipMemcpy(hp2.data(), d_part2.p, sizeof(double) * nparts, hipMemcpyDeviceToHost));
+            { const int rc_ = d2h_small(hp2.data(), d_part2.p, sizeof(double) * nparts, st, W.mb); if (rc_) return rc_; }
             double h = 0.0;
             for (double v : hp2) h += v;   // in (k, walk, row piece) order
             *out = (float)h;
@@ -2407,7 +2452,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
             auto r_dot = [&](float alpha, float* out) -> int {
                 cg_update_r_dot_kernel<<<nz * DOT_PARTS, 256, 0, st>>>(d_r.as<float>(), d_q.as<float>(), alpha, (int64_t)nx * ny, d_part.as<double>());
                 std::vector<double> hp((size_t)nz * DOT_PARTS);
-                HIP_TRY(hipMemcpy(hp.data(), d_part.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
+                { const int rc_ = d2h_small(hp.data(), d_part.p, sizeof(double) * hp.size(), st, W.mb); if (rc_) return rc_; }
                 double h = 0.0;
                 for (double v : hp) h += v;
                 *out = (float)h;
@@ -2454,7 +2499,9 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     // (smooth = 1: one target per lattice point - through the table of ITS coordinate differences)
     // In RBF_FINE_CHUNKS Z chunks when the caller wants to forward finished chunks (fine_chunk), else in one launch.
     auto eval_fine = [&](float add) -> int {
-        const int nchunk = (fine_chunk && fz >= 4 * RBF_FINE_CHUNKS) ? RBF_FINE_CHUNKS : 1;
+        static const int chunks_env = getenv("R2S_FINE_CHUNKS") ? std::min(std::max(atoi(getenv("R2S_FINE_CHUNKS")), 1), 64) : 0;   // tuning knob
+        const int want = chunks_env ? chunks_env : RBF_FINE_CHUNKS;
+        const int nchunk = (fine_chunk && fz >= 4 * want) ? want : 1;
         for (int c = 0; c < nchunk; ++c) {
             const int f0 = (int)((int64_t)fz * c / nchunk), f1 = (int)((int64_t)fz * (c + 1) / nchunk);
             const int64_t t0 = (int64_t)f0 * fx * fy, t1 = (int64_t)f1 * fx * fy;
@@ -2486,7 +2533,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     int mmh[2] = {0x7FFFFFFF, (int)0x80000000};
     HIP_C(hipMemcpy(d_cnt.p, mmh, 8, hipMemcpyHostToDevice));
     minmax_kernel<<<(nb < 2048u ? nb : 2048u), 256, 0, st>>>(d_lsf.as<float>(), n, d_cnt.as<int>());
-    HIP_C(hipMemcpy(mmh, d_cnt.p, 8, hipMemcpyDeviceToHost));
+    TRY_C(d2h_small(mmh, d_cnt.p, 8, st, W.mb));
     auto dec = [](int b) { b = b >= 0 ? b : (b ^ 0x7FFFFFFF); float f; memcpy(&f, &b, 4); return f; };
     float lo = dec(mmh[0]), hi = dec(mmh[1]);
     TRY_C(vw.init(9));
