@@ -444,7 +444,17 @@ __global__ void __launch_bounds__(1024) sum_f32_kernel(const float* __restrict__
 {
     __shared__ float red[1024];
     float acc = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 1024) acc += in[i];
+    // (16 loads in flight, the additions in the same order: one load at a time the loop waited 250 ns per element, 65 us
+    //  per level of the bisection)
+    int i = threadIdx.x;
+    for (; i + 15 * 1024 < n; i += 16 * 1024) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = in[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; i < n; i += 1024) acc += in[i];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
