@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -45,48 +46,57 @@ double now_ms()
 
 // ---- a small persistent pool of host threads: staged chunks into pageable memory, sentinel fill and tile scatter of
 // the sparse download ----
-// CPUs of a NUMA node ("0-63,128-191" in /sys/devices/system/node/nodeN/cpulist); empty when it cannot be read
-static std::vector<int> node_cpus(int node)
+// the CPUs of every NUMA node ("0-63,128-191" in /sys/devices/system/node/nodeN/cpulist); empty when sysfs says nothing
+static std::vector<std::vector<int>> numa_node_cpus()
 {
-    std::vector<int> cpus;
-    char path[96];
-    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
-    FILE* f = fopen(path, "r");
-    if (!f) return cpus;
-    char buf[4096] = {0};
-    if (fgets(buf, sizeof buf, f)) {
-        for (char* p = buf; *p && *p != '\n';) {
-            char* e = nullptr;
-            const long a = strtol(p, &e, 10);
-            if (e == p) break;
-            long b = a;
-            p = e;
-            if (*p == '-') { b = strtol(p + 1, &e, 10); p = e; }
-            for (long c = a; c <= b && c < CPU_SETSIZE; ++c) cpus.push_back((int)c);
-            if (*p == ',') ++p;
+    std::vector<std::vector<int>> nodes;
+    for (int node = 0; node < 64; ++node) {
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+        FILE* f = fopen(path, "r");
+        if (!f) break;
+        std::vector<int> cpus;
+        char buf[4096] = {0};
+        if (fgets(buf, sizeof buf, f)) {
+            for (char* p = buf; *p && *p != '\n';) {
+                char* e = nullptr;
+                const long a = strtol(p, &e, 10);
+                if (e == p) break;
+                long b = a;
+                p = e;
+                if (*p == '-') { b = strtol(p + 1, &e, 10); p = e; }
+                for (long c = a; c <= b && c < CPU_SETSIZE; ++c) cpus.push_back((int)c);
+                if (*p == ',') ++p;
+            }
         }
+        fclose(f);
+        if (!cpus.empty()) nodes.push_back(cpus);
     }
-    fclose(f);
-    return cpus;
+    return nodes;
 }
 
 class CopyPool {
   public:
-    // node >= 0: the threads stay on the CPUs of that NUMA node (the one next to the device: its pinned buffers live there,
-    // and the pages of the caller's array that these threads touch first)
-    explicit CopyPool(int n, int node = -1) : n_(n)
+    // spread: thread i stays on the CPUs of NUMA node i % nodes.  The threads stream through a gigabyte per call: they need
+    // the memory channels of every socket, and the pages of a fresh result array belong to the node of the thread that
+    // touches them first.  Left to the scheduler the split varies from process to process (tools/numa_where.py: a pageable
+    // array with 1/3 of its pages on one node 11 ms per call, with all of them on one node 14.6-21 ms; all threads on the
+    // node next to the device 18-20 ms).
+    explicit CopyPool(int n, bool spread = false) : n_(n)
     {
-        const std::vector<int> cpus = node >= 0 ? node_cpus(node) : std::vector<int>();
-        for (int i = 0; i < n_; ++i)
+        const std::vector<std::vector<int>> nodes = spread ? numa_node_cpus() : std::vector<std::vector<int>>();
+        for (int i = 0; i < n_; ++i) {
+            const std::vector<int> cpus = nodes.size() > 1 ? nodes[(size_t)i % nodes.size()] : std::vector<int>();
             th_.emplace_back([this, i, cpus] {
                 if (!cpus.empty()) {
                     cpu_set_t set;
                     CPU_ZERO(&set);
                     for (int c : cpus) CPU_SET(c, &set);
-                    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);   // (refused: the threads run where they may)
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);   // (refused: the thread runs where it may)
                 }
                 loop(i);
             });
+        }
     }
     ~CopyPool()
     {
@@ -335,13 +345,8 @@ void ensure_pool(HostSession* S)
     static const int env = getenv("R2S_HOST_THREADS") ? atoi(getenv("R2S_HOST_THREADS")) : 0;
     // (default: 16, or the CPU quota of the container if that is smaller; a host without a quota: half of its CPUs at most)
     const unsigned all = std::max(1u, std::thread::hardware_concurrency());
-    int node = -1;
-    static const bool numa_env = !(getenv("R2S_HOST_NUMA") && atoi(getenv("R2S_HOST_NUMA")) == 0);
-    if (numa_env && (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, S->device) != hipSuccess || node < 0)) {
-        (void)hipGetLastError();
-        node = -1;
-    }
-    S->pool = new CopyPool(env > 0 ? std::min(env, 64) : (int)std::min(16u, std::max(2u, hw < all ? hw : all / 2)), numa_env ? node : -1);
+    static const bool spread_env = !(getenv("R2S_HOST_SPREAD") && atoi(getenv("R2S_HOST_SPREAD")) == 0);
+    S->pool = new CopyPool(env > 0 ? std::min(env, 64) : (int)std::min(16u, std::max(2u, hw < all ? hw : all / 2)), spread_env);
 }
 
 // device -> host.  Pinned destination: plain DMA.  Pageable: DMA into the two staging buffers, each staged chunk

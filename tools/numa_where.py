@@ -40,4 +40,4 @@ for kind in ("pageable", "pinned", "pageable", "pinned"):
         ts.append((time.perf_counter() - t0) * 1e3)
     print(kind, "ms per call", [round(t, 2) for t in ts], "pages on nodes", nodes_of(out), flush=True)
     del out
-print("cpu of the main thread", os.sched_getcpu(), "gpu numa nodes", [open(p).read().strip() for p in sorted(__import__("glob").glob("/sys/class/drm/card*/device/numa_node"))])
+print("gpu numa nodes", [open(p).read().strip() for p in sorted(__import__("glob").glob("/sys/class/drm/card*/device/numa_node"))])
