@@ -56,7 +56,10 @@ __device__ __forceinline__ void uf_union(uint32_t* L, uint32_t a, uint32_t b)
 // their roots.  The result - every voxel labelled with the smallest index of its component - is that of one union per
 // pair of neighbouring voxels (round 1: three CAS loops per voxel, 5.0 + 5.3 ms at 512^3), with ~100 times fewer
 // atomics and no pointer chasing outside the heads.  All three kernels use the same voxel <-> lane mapping.
-__global__ void __launch_bounds__(256) ccl_init_kernel(const double* __restrict__ sdf, uint32_t n, int nx, double thr, uint32_t* __restrict__ L)
+// piece_len != nullptr: the head of every run piece also gets the piece's length (the single-device labelling sums
+// component sizes over heads, ccl_compress_heads_sizes_kernel)
+__global__ void __launch_bounds__(256) ccl_init_kernel(const double* __restrict__ sdf, uint32_t n, int nx, double thr, uint32_t* __restrict__ L,
+                                                      uint32_t* __restrict__ piece_len = nullptr)
 {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -68,6 +71,11 @@ __global__ void __launch_bounds__(256) ccl_init_kernel(const double* __restrict_
     if (v < n) {
         const unsigned long long below = m_head & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));   // heads at or below this lane
         L[v] = in ? v - (uint32_t)lane + (uint32_t)(63 - __clzll((long long)below)) : NOLABEL;
+        if (piece_len && head) {
+            // the piece ends before the next lane that is outside or a head itself (or with the wavefront)
+            const unsigned long long stop = lane == 63 ? 0ull : ((~m_in | m_head) & (~0ull << (lane + 1)));
+            piece_len[v] = (uint32_t)((stop ? __ffsll((long long)stop) - 1 : 64) - lane);
+        }
     }
 }
 
@@ -186,6 +194,56 @@ __global__ void __launch_bounds__(256) ccl_compress_heads_roots_kernel(uint32_t*
         }
     }
 }
+// ccl_compress_heads_roots_kernel + the component sizes in the same pass: size[] holds the length of every run piece at
+// its head (ccl_init_kernel); a head that is not a root adds its length to its root's counter - a fixed grid strides over
+// the voxels and every wavefront keeps a running (root, count) pair that it flushes when the root changes, so the one big
+// component costs a few thousand same-address atomics, not one per piece - and a root keeps its own length as the start
+// of the sum.  No pass over all voxels that resolves every voxel's root just to count it (ccl_count_kernel: 0.29 ms).
+__global__ void __launch_bounds__(256) ccl_compress_heads_sizes_kernel(uint32_t* __restrict__ L, uint32_t n, int nx, uint32_t* __restrict__ size,
+                                                                      uint32_t* __restrict__ roots, uint32_t roots_cap,
+                                                                      uint32_t* __restrict__ nroots)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t cur = NOLABEL, cnt = 0;   // wave-uniform
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint64_t v64 = base + threadIdx.x;
+        const uint32_t v = (uint32_t)v64;
+        const uint32_t lv = v64 < n ? L[v] : NOLABEL;
+        const uint32_t lp = __shfl_up(lv, 1, 64);   // (lane 0 is a head whatever came before: pieces end with the wavefront)
+        const bool head = lv != NOLABEL && (lane == 0 || v % (uint32_t)nx == 0u || lp == NOLABEL);
+        uint32_t r = NOLABEL, len = 0;
+        if (head) {
+            r = uf_find(L, v);
+            if (r != v) {
+                __hip_atomic_store(L + v, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an ancestor: walks through v stay valid)
+                len = size[v];
+            } else {
+                const uint32_t at = atomicAdd(nroots, 1u);
+                if (at < roots_cap) roots[at] = v;
+                r = NOLABEL;   // (its own length is in size[v] already)
+            }
+        }
+        bool pending = r != NOLABEL;
+        while (__any(pending)) {
+            const unsigned long long todo = __ballot(pending);
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lr = __shfl(r, leader, 64);
+            unsigned long long same = __ballot(pending && r == lr);
+            uint32_t c = 0;
+            for (unsigned long long m = same; m; m &= m - 1) c += __shfl(len, __ffsll((long long)m) - 1, 64);   // (a few heads per wavefront)
+            if (lr == cur) {
+                cnt += c;
+            } else {
+                if (cnt && lane == 0) atomicAdd(&size[cur], cnt);
+                cur = lr;
+                cnt = c;
+            }
+            if (r == lr) pending = false;
+        }
+    }
+    if (cnt && lane == 0) atomicAdd(&size[cur], cnt);
+}
 // sizes only (ccl_flatten_count_kernel without the root[] array)
 __global__ void __launch_bounds__(256) ccl_count_kernel(const uint32_t* __restrict__ L, uint32_t n, uint32_t* __restrict__ size)
 {
@@ -301,11 +359,17 @@ static int remove_artifacts_dev(double* d_sdf, const r2s_grid* g, double thresho
     const unsigned nb = (n + 255) / 256;
     uint32_t h[8] = {0, NOLABEL, 0, 0, 0, 0, 0, 0};   // [4]: number of roots
     HIP_TRY(hipMemcpyAsync(cnt.p, h, sizeof h, hipMemcpyHostToDevice, st));
-    ccl_init_kernel<<<nb, 256, 0, st>>>(d_sdf, n, nx, threshold, L.as<uint32_t>());
+    static const bool split_env = getenv("R2S_CCL_SPLIT") && atoi(getenv("R2S_CCL_SPLIT"));   // (tests / A-B: sizes in a pass of their own)
+    ccl_init_kernel<<<nb, 256, 0, st>>>(d_sdf, n, nx, threshold, L.as<uint32_t>(), split_env ? nullptr : size.as<uint32_t>());
     ccl_union_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), nx, ny, nz);
-    ccl_compress_heads_roots_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), n, nx, size.as<uint32_t>(), roots.as<uint32_t>(), roots_cap,
-                                                       cnt.as<uint32_t>() + 4);
-    ccl_count_kernel<<<(nb < 4096u ? nb : 4096u), 256, 0, st>>>(L.as<uint32_t>(), n, size.as<uint32_t>());
+    if (split_env) {
+        ccl_compress_heads_roots_kernel<<<nb, 256, 0, st>>>(L.as<uint32_t>(), n, nx, size.as<uint32_t>(), roots.as<uint32_t>(), roots_cap,
+                                                           cnt.as<uint32_t>() + 4);
+        ccl_count_kernel<<<(nb < 4096u ? nb : 4096u), 256, 0, st>>>(L.as<uint32_t>(), n, size.as<uint32_t>());
+    } else {
+        ccl_compress_heads_sizes_kernel<<<(nb < 8192u ? nb : 8192u), 256, 0, st>>>(L.as<uint32_t>(), n, nx, size.as<uint32_t>(), roots.as<uint32_t>(),
+                                                                                  roots_cap, cnt.as<uint32_t>() + 4);
+    }
     ccl_roots_max_kernel<<<1, 1024, 0, st>>>(size.as<uint32_t>(), roots.as<uint32_t>(), cnt.as<uint32_t>() + 4, cnt.as<uint32_t>());
     HIP_TRY(hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
