@@ -2025,7 +2025,15 @@ __global__ void __launch_bounds__(256) dot_planes_kernel(const float* __restrict
     const float* __restrict__ pa = a + k * plane;
     const float* __restrict__ pb = b + k * plane;
     double acc = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += (double)pa[i] * (double)pb[i];
+    int64_t i = lo + threadIdx.x;
+    for (; i + 7 * 256 < hi; i += 8 * 256) {   // (8 pairs of loads in flight, the additions in the same order)
+        float va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { va[u] = pa[i + u * 256]; vb[u] = pb[i + u * 256]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)va[u] * (double)vb[u];
+    }
+    for (; i < hi; i += 256) acc += (double)pa[i] * (double)pb[i];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
