@@ -2621,7 +2621,7 @@ static int rbf_smooth_host(const double* sdf, const r2s_grid* g, int is_interp, 
     HIP_C(hipMemcpyAsync(d_cnt.p, mmh, 16, hipMemcpyHostToDevice, st));
     const int64_t nsegs = vw.seg_field ? (int64_t)(ny - 1) * (nz - 1) * ((nx - 1 + 63) / 64) : 0;
     if (nsegs > 0) {
-        const unsigned nbs = (unsigned)std::min<int64_t>((nsegs + 255) / 256, 2048);
+        const unsigned nbs = (unsigned)std::min<int64_t>((nsegs + 255) / 256, 128);   // (two same-address atomics per wavefront at the end: few wavefronts)
         minmax_kernel<<<nbs, 256, 0, st>>>(vw.segmn.as<float>(), nsegs, d_cnt.as<int>());
         minmax_kernel<<<nbs, 256, 0, st>>>(vw.segmx.as<float>(), nsegs, d_cnt.as<int>() + 2);
     } else {
