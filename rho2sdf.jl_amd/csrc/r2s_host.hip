@@ -31,6 +31,9 @@
 #include <mutex>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -219,9 +222,9 @@ struct HostSession {
         DevBuf* all[] = {&dX, &dI, &dR, &dE, &out[0], &out[1], &out[2], &out[3], &fine, &raw, &slab, &pk,
                          &pre_ws[0], &pre_ws[1], &pre_ws[2], &pre_ws[3], &pre_ws[4], &pre_ws[5], &pre_ws[6]};
         for (DevBuf* b : all) b->release();
-        if (pk_host) (void)hipHostFree(pk_host);
+        if (pk_host) r2s_host_free(pk_host);
         pk_host = nullptr;
-        if (fine_host) (void)hipHostFree(fine_host);
+        if (fine_host) r2s_host_free(fine_host);
         fine_host = nullptr;
         fine_host_cap = 0;
         pk_host_cap = 0;
@@ -486,11 +489,11 @@ int run_host_device(const HostCall& c, int device, int G, int r, r2s_stats* stat
         auto bail = [&](int code) { S->pool->wait(); return code; };
         if (S->pk.ensure(std::max<size_t>(bytes, 8))) return bail(fail(R2S_ERR_NOMEM, "hipMalloc of the packed tiles failed"));
         if (S->pk_host_cap < bytes) {
-            if (S->pk_host) (void)hipHostFree(S->pk_host);
+            if (S->pk_host) r2s_host_free(S->pk_host);
             S->pk_host = nullptr;
             S->pk_host_cap = 0;
             const size_t want = bytes + bytes / 4 + 4096;
-            if (hipHostMalloc(&S->pk_host, want, hipHostMallocDefault) != hipSuccess) {
+            if (!(S->pk_host = r2s_host_alloc(want))) {   // (pages interleaved over the NUMA nodes: the scatter threads are spread)
                 (void)hipGetLastError();
                 return bail(fail(R2S_ERR_NOMEM, "hipHostMalloc of the landing zone of the packed tiles failed"));
             }
@@ -719,10 +722,60 @@ void r2s_last_host_phases(double out[8])
     if (out) memcpy(out, g_phases, sizeof g_phases);
 }
 
+// Pinned result arrays with their pages INTERLEAVED over the NUMA nodes: hipHostMalloc puts every page on the node next
+// to the device (and ignores the caller's memory policy, also with hipHostMallocNumaUser), so the 16 host threads that
+// fill and scatter into such an array - spread over the sockets - all write to one socket's memory: 13-16 ms per call
+// against 10.4-12 into a pageable array whose pages they touch first, half on each node (tools/numa_where.py).  So: an
+// anonymous mapping with the interleave policy (mbind), registered with the runtime.  Any step that fails: hipHostMalloc.
+static std::mutex g_reg_mu;
+static std::map<void*, size_t> g_reg;   // mappings of r2s_host_alloc that r2s_host_free has to unregister and unmap
+
+static void* host_alloc_interleaved(size_t bytes)
+{
+#if defined(__linux__) && defined(__x86_64__)
+    static const bool on = !(getenv("R2S_HOST_INTERLEAVE") && atoi(getenv("R2S_HOST_INTERLEAVE")) == 0);
+    if (!on || bytes < ((size_t)1 << 20)) return nullptr;
+    unsigned long mask = 0;
+    if (FILE* f = fopen("/sys/devices/system/node/online", "r")) {   // "0-1", "0", "0-3", "0,2"
+        char buf[256] = {0};
+        if (fgets(buf, sizeof buf, f)) {
+            for (char* c = buf; *c && *c != '\n';) {
+                char* e = nullptr;
+                const long a = strtol(c, &e, 10);
+                if (e == c) break;
+                long b = a;
+                c = e;
+                if (*c == '-') { b = strtol(c + 1, &e, 10); c = e; }
+                for (long q = a; q <= b && q < 64; ++q) mask |= 1ul << q;
+                if (*c == ',') ++c;
+            }
+        }
+        fclose(f);
+    }
+    if (!mask || !(mask & (mask - 1))) return nullptr;   // one node: nothing to interleave
+    const size_t size = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+    void* p = mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return nullptr;
+    if (syscall(237 /* mbind */, p, size, 3 /* MPOL_INTERLEAVE */, &mask, 65ul, 0u) != 0 ||
+        hipHostRegister(p, size, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        munmap(p, size);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    g_reg[p] = size;
+    return p;
+#else
+    (void)bytes;
+    return nullptr;
+#endif
+}
+
 void* r2s_host_alloc(size_t bytes)
 {
     void* p = nullptr;
     if (check_device(0)) return nullptr;
+    if ((p = host_alloc_interleaved(bytes))) return p;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         fail(R2S_ERR_NOMEM, "hipHostMalloc of %zu bytes failed", bytes);
@@ -733,7 +786,19 @@ void* r2s_host_alloc(size_t bytes)
 
 void r2s_host_free(void* p)
 {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    size_t size = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_reg_mu);
+        auto it = g_reg.find(p);
+        if (it != g_reg.end()) { size = it->second; g_reg.erase(it); }
+    }
+    if (size) {
+        (void)hipHostUnregister(p);
+        munmap(p, size);
+    } else {
+        (void)hipHostFree(p);
+    }
 }
 
 int r2s_eval_distances(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, const double* rho_n,
@@ -1025,10 +1090,10 @@ int r2s_rho2sdf(const double* X, int64_t nnp, const int64_t* IEN, int64_t nel, c
     static const bool early_env = !(getenv("R2S_FINE_EARLY") && atoi(getenv("R2S_FINE_EARLY")) == 0);
     bool early = early_env && !o.skip_rbf && fine_sdf_out && nfine >= ((size_t)1 << 22);
     if (early && !pin_f && S->fine_host_cap < sizeof(float) * nfine) {
-        if (S->fine_host) (void)hipHostFree(S->fine_host);
+        if (S->fine_host) r2s_host_free(S->fine_host);
         S->fine_host = nullptr;
         S->fine_host_cap = 0;
-        if (hipHostMalloc(&S->fine_host, sizeof(float) * nfine, hipHostMallocDefault) == hipSuccess) S->fine_host_cap = sizeof(float) * nfine;
+        if ((S->fine_host = r2s_host_alloc(sizeof(float) * nfine))) S->fine_host_cap = sizeof(float) * nfine;
         else { (void)hipGetLastError(); early = false; }
     }
     if (sdf_dists_out && pin_d) {

@@ -15,7 +15,7 @@ SYS_move_pages = 279
 
 def nodes_of(arr, samples=64):
     base = arr.ctypes.data
-    step = max(4096, (arr.nbytes // samples) & ~4095)
+    step = max(4096, (arr.nbytes // samples) & ~4095) | 4096   # (an odd number of pages: interleaved pages are not all sampled on one node)
     addrs = [(base + i * step) & ~4095 for i in range(samples) if i * step < arr.nbytes]
     pages = (ctypes.c_void_p * len(addrs))(*addrs)
     status = (ctypes.c_int * len(addrs))()
