@@ -303,6 +303,14 @@ struct TetT {
     }
 };
 
+// an element outside this call's share of the grid: what of its (cleared) record says "no sign candidate anywhere"
+__device__ __forceinline__ void mark_skipped(ElemRec&) {}   // (HEX8: the sign bins go by the AABB, which the skip path stores)
+__device__ __forceinline__ void mark_skipped(TetRec& E)     // (TET4: by the bin range of ET::finish - an empty one)
+{
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) { E.blo[ax] = 1; E.bhi[ax] = 0; }
+}
+
 // 1 thread / element: gather record, classify (sdfOnDensityField.jl:197-201,312), boundary
 // faces (:511-519), work-item count, lattice range of the element AABB for the sign bins.
 template <class ET>
@@ -348,6 +356,18 @@ __global__ void elem_prep_kernel(const double* __restrict__ X, const int64_t* __
         if (b > g.nz - 1) b = g.nz - 1;
         int la, lb;
         if (a > b || !slab_local_range(sl, a, b, la, lb)) {
+            // The rest of the record is CLEARED, not left as it was, and marked as holding no sign candidate: the plan's
+            // arrays outlive a call, and the TET4 sign bins go by a field this path did not write (TetRec::blo / bhi) -
+            // what an earlier call (another mesh, another share of the grid) had stored at this index became a
+            // candidate of a later one.  Found by tools/fuzz_fan_out.py: a TET4 call on 8 devices after a TET4 call on
+            // 5 - 145 signs differed from the one-device result until the plans were released.
+            {
+                uint64_t* w = reinterpret_cast<uint64_t*>(&erec[el]);
+                static_assert(sizeof(typename ET::Rec) % 8 == 0, "element records are cleared in 8-byte words");
+#pragma unroll 8
+                for (size_t q = 0; q < sizeof(typename ET::Rec) / 8; ++q) w[q] = 0ull;
+            }
+            mark_skipped(erec[el]);
 #pragma unroll
             for (int i = 0; i < 3; ++i) { erec[el].mn[i] = R.mn[i]; erec[el].mx[i] = R.mx[i]; }   // (the bin kernels look at the AABB)
             erec[el].rmax = rmax;

@@ -258,3 +258,24 @@ def test_single_process_fan_out(pkg, oracle, G, monkeypatch):
         assert np.array_equal(a[3], b[3]), (G, interp, smooth, "sdf_dists")
         assert np.array_equal(a[0], b[0]), (G, interp, smooth, "fine_sdf")
     pkg._lib.lib().r2s_release_cache()
+
+
+def test_fan_out_after_another_mesh_on_other_shares(pkg, monkeypatch):
+    """the plans of the logical devices outlive a call: a TET4 call on 8 devices after a TET4 call on 5 (another mesh, other
+    shares of the grid) must not see anything of the earlier one - elements outside a device's share keep a CLEARED record
+    that names no sign candidate (tools/fuzz_fan_out.py found 145 wrong signs here before elem_prep_kernel cleared it)"""
+    from rho2sdf_jl_amd import synthetic
+    monkeypatch.setenv("R2S_MULTI_OVERSUBSCRIBE", "1")
+    Xa, Ia, ra = synthetic.tet_mesh(7, jitter=0.25, seed=59)
+    ga = pkg.Grid(Xa.min(0), Xa.max(0), synthetic.grid_n_max_for_points(67), 3)
+    Xb, Ib, rb = synthetic.tet_mesh(6, jitter=0.12, seed=63)
+    gb = pkg.Grid(Xb.min(0), Xb.max(0), synthetic.grid_n_max_for_points(66), 3)
+    rng = np.random.default_rng(63)
+    rb = np.clip(rb + rng.normal(0, 0.2, len(rb)), 0, 1)
+    want = pkg.sdf_fused(pkg.Mesh(Xb, Ib), gb, rb, 0.5)
+    for Ga, Gb in ((5, 8), (3, 8), (8, 5)):
+        pkg.sdf_fused(pkg.Mesh(Xa, Ia), ga, ra, 0.5, n_gpus=Ga)
+        got = pkg.sdf_fused(pkg.Mesh(Xb, Ib), gb, rb, 0.5, n_gpus=Gb)
+        assert np.array_equal(got, want), (Ga, Gb, int((got != want).sum()))
+    pkg._lib.lib().r2s_release_cache()
+
